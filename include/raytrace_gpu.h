@@ -1,0 +1,126 @@
+/*
+ * raytrace_gpu.h — C ABI of libraytrace_gpu.so, the MI355X (gfx950) render path that replaces the
+ * per-pixel Repa loop of alexandervandenbroucke/raytrace:
+ *     parallelTrace w h camera (trace depth lights world)     reference src/Main.hs:623-637, 571
+ *     parallel      w h trace                                 reference src/Talk.hs:171-182
+ *
+ * The reference has no FFI/plugin interface of its own: its seam is a Haskell closure
+ * (Ray -> PixelRGB8), which cannot cross a C ABI.  The boundary therefore sits at the scene
+ * constructors the closure is built from; every entry point below names the reference function
+ * (file:line under /root/reference/) that it reifies as data.  INTEGRATION.md shows the Haskell
+ * `foreign import ccall` stubs that bind these symbols and keep the reference's scene API.
+ *
+ * Conventions: plain C types only; every function returns 0 (RT_OK) or a negative rt_status and
+ * stores a message retrievable with rt_last_error() (thread-local).  No exception or abort crosses
+ * the boundary.  rt_add_* return the index (>= 0) of the first leaf they created: leaf indices are
+ * the depth-first, left-to-right leaf order of the reference's mconcat/mappend tree, which is the
+ * order in which the reference resolves equal-distance hits (Main.hs:213-214), and they are the
+ * values written to the hit-ID buffer.  There is NO CPU fallback: rendering without a usable HIP
+ * device fails with RT_ERR_HIP.
+ */
+#ifndef RAYTRACE_GPU_H
+#define RAYTRACE_GPU_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rt_scene rt_scene;   /* opaque; owned by the library */
+
+typedef enum {
+    RT_OK              =  0,
+    RT_ERR_ARG         = -1,   /* null pointer, bad size, bad index            */
+    RT_ERR_HIP         = -2,   /* HIP runtime error / no device                */
+    RT_ERR_UNSUPPORTED = -3,   /* feature of the reference not built yet       */
+    RT_ERR_NOMEM       = -4
+} rt_status;
+
+/* Material — Main.hs:178-185 (mat_diffuse, mat_specular, mat_specularity, mat_reflectivity) */
+typedef struct {
+    uint8_t diffuse[3];
+    uint8_t specular[3];
+    uint8_t _pad[2];
+    double  specularity;
+    double  reflectivity;
+} rt_material;
+
+/* How the shading normal of a leaf is produced */
+typedef enum {
+    RT_NORMAL_GEOMETRIC = 0,  /* rectangle Main.hs:228 / triangle Main.hs:371                        */
+    RT_NORMAL_MANTLE    = 1,  /* cylinder mantle: lerped, y forced to 0, not renormalised (:769-771) */
+    RT_NORMAL_GAUSSIAN  = 2   /* linearInterpolation's `normals` wrapper with main's gaussian fnorm
+                                 (Main.hs:956-965, 580-584); params = {scaleInv, offset x,y,z}      */
+} rt_normal_mode;
+
+/* Per-render statistics (filled by rt_get_stats after a render) */
+typedef struct {
+    uint64_t primary_rays;       /* w * nrows * spp                                           */
+    uint64_t shadow_rays;        /* shadow rays actually cast (hit pixel, L.N > 0), all lights */
+    uint64_t tri_tests;          /* ray x triangle  filter tests executed (brute force)        */
+    uint64_t rect_tests;         /* ray x rectangle filter tests executed                      */
+    uint64_t exact_evals;        /* FP64 exact leaf evaluations (candidates of the filter)     */
+    double   ms_primary;         /* HIP-event time of the nearest-hit kernel(s)                */
+    double   ms_shade;           /* HIP-event time of the shading + shadow kernel(s)           */
+    double   ms_total;           /* first launch to last kernel end                            */
+} rt_stats;
+
+/* ---- library / device ------------------------------------------------------------------- */
+int  rt_init(int device);                       /* hipSetDevice + stream; call once per process/thread  */
+const char *rt_last_error(void);
+const char *rt_version(void);
+
+/* ---- scene construction (replaces the closure-building constructors) -------------------- */
+int  rt_scene_create(rt_scene **out);
+void rt_scene_destroy(rt_scene *);
+/* rectangle material point width height                                   Main.hs:226-246 */
+int  rt_add_rectangle(rt_scene *, const rt_material *, const double point[3],
+                      const double width[3], const double height[3]);
+/* triangle material pa pb pc                                              Main.hs:363-385 */
+int  rt_add_triangle(rt_scene *, const rt_material *, const double pa[3],
+                     const double pb[3], const double pc[3]);
+/* colorcuboid materials point l h d (cube/colorcube/cuboid are special cases) Main.hs:286-320 */
+int  rt_add_cuboid(rt_scene *, const rt_material *mats, int nmats, const double point[3],
+                   double l, double h, double d);
+/* cylinder topM botM mantleM point n h r                                  Main.hs:725-774 */
+int  rt_add_cylinder(rt_scene *, const rt_material *top, const rt_material *bot,
+                     const rt_material *mantle, const double point[3], int n, double h, double r);
+/* the `normals` wrapper of linearInterpolation                            Main.hs:956-965 */
+int  rt_set_normal_mode(rt_scene *, int first_leaf, int nleaves, int mode,
+                        const double *params, int nparams);
+/* pointLight world diffuse specular lpos (world = this scene)             Main.hs:467-487 */
+int  rt_add_point_light(rt_scene *, double diffuse, double specular, const double pos[3]);
+/* ambient f                                                               Main.hs:490-492 */
+int  rt_add_ambient(rt_scene *, double f);
+
+/* ---- introspection (host logic tests; no device needed) --------------------------------- */
+int  rt_scene_num_leaves(const rt_scene *);
+int  rt_scene_num_lights(const rt_scene *);
+/* out[0..19]: kind(0 rect,1 tri), normal mode, normal xyz, d, p0 xyz, e1 xyz, e2 xyz, c0..c3 */
+int  rt_scene_get_leaf(const rt_scene *, int leaf, double out[20]);
+/* fixedCamera w h: out = {scaleX, scaleY, dX, dY, d}                      Main.hs:506-527 */
+int  rt_camera_params(int w, int h, double out[5]);
+
+/* ---- render: parallelTrace w h (fixedCamera w h) (trace depth lights world) -------------- */
+/* Rows [row0, row0+nrows) of the w x h image (y = 0 is the top row, Main.hs:629-632).
+ *   rgba_out   nrows*w*4 bytes, R,G,B,255 per pixel, row-major            (nullable)
+ *   hit_id_out nrows*w int32, leaf index of the primary hit, -1 = miss    (nullable)
+ * spp = 1 is the reference (one ray through the integer pixel coordinate, Main.hs:529-530);
+ * spp > 1 (jittered supersampling, seed) is an extension documented in DESIGN.md.
+ * rt_render takes HOST buffers (what a Haskell caller hands over); rt_render_device takes DEVICE
+ * pointers on the current device and an optional hipStream_t (NULL = the library's stream) and
+ * does not synchronise. */
+int  rt_render(rt_scene *, int w, int h, int depth, int spp, uint64_t seed,
+               int row0, int nrows, uint8_t *rgba_out, int32_t *hit_id_out);
+int  rt_render_device(rt_scene *, int w, int h, int depth, int spp, uint64_t seed,
+                      int row0, int nrows, void *d_rgba, void *d_hit_id, void *stream);
+int  rt_synchronize(void);
+int  rt_get_stats(rt_scene *, rt_stats *out);   /* synchronises; stats of the last render of this scene */
+
+/* ---- saveBmpImage "trace.bmp" (ImageRGB8 ...)                           Main.hs:621 ------ */
+/* 24-bit uncompressed BMP from an RGBA8 buffer, so that a harness runs without JuicyPixels. */
+int  rt_write_bmp(const char *path, const uint8_t *rgba, int w, int h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

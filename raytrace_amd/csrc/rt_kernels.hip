@@ -1,0 +1,661 @@
+// rt_kernels.hip — gfx950 (MI355X, CDNA4) kernels of the render path and the render entry points.
+//
+// Replaces parallelTrace / computeP (reference src/Main.hs:623-637) and everything its element
+// function calls: cast (506-533), trace (541-557), intersect world (196-217, 226-277, 363-385),
+// light lights (436-492).
+//
+// Design (DESIGN.md has the long form):
+//   * One wavefront (64 lanes) owns a 32 x 8 pixel tile; a lane owns 4 horizontally adjacent
+//     pixels, held as two float2 pairs so the O(rays x leaves) loops run on v_pk_fma_f32 /
+//     v_pk_add_f32 (packed FP32 issues at twice the FLOP rate of v_fma_f32 on gfx950).
+//   * Leaf data in those loops is wave-uniform, so it is read with scalar loads (s_load_dwordx4/8)
+//     and used as SGPR operands: no VGPRs, no LDS bandwidth, no bank conflicts.  Each FP32 test is
+//     a conservative filter (linear forms of the ray direction from a common apex, rt_scene.cpp).
+//   * (ray, leaf) pairs that pass the filter — a handful per ray — are re-evaluated in IEEE double
+//     with the reference's own expression order (planeLineIsect etc.), which decides the hit, the
+//     tie-break (left-most leaf, Main.hs:213-214) and the colour exactly.  The file is compiled with
+//     -ffp-contract=off; the FP32 loops use explicit fma builtins.
+//   * Shadow rays of one light all end at that light, so the same apex filter serves them
+//     (apex = light position, D = shadow-ray origin - light).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <string>
+
+#include "rt_scene.h"
+
+using namespace rt;
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+#define RT_TILE_W 32
+#define RT_TILE_H 8
+#define RT_WAVES_PER_BLOCK 4
+
+namespace {
+
+struct RenderParams {
+    const LeafD *leaves;
+    const AuxD *aux;
+    const MaterialD *mats;
+    const LightD *lights;
+    const FilterRec *tri_rec;
+    const FilterRec *rect_rec;
+    const int32_t *tri_gid;
+    const int32_t *rect_gid;
+    unsigned long long *counters;   // [0] shadow rays cast, [1] exact evals (primary), [2] exact evals (shadow)
+    int32_t *hit_id;                // band-local, nrows * w
+    uint8_t *rgba;                  // band-local, nrows * w * 4 (spp == 1) or nullptr
+    uint32_t *accum;                // band-local, nrows * w * 3 sums (spp > 1) or nullptr
+    CameraD cam;
+    double eps;
+    int ntri, nrect, nlights, nleaves;
+    int w, h, row0, nrows;
+    int spp, sample;
+    uint32_t seed_lo, seed_hi;
+    int tiles_x, tiles_y;
+};
+
+// ------------------------------------------------------------------------------------------
+// Exact path (IEEE double, reference expression order)
+
+struct RayD { double px, py, pz, dx, dy, dz, rz; };
+
+__device__ __forceinline__ double clampd(double d, double eps) { return fabs(d) <= eps ? eps : d; } // Main.hs:112
+
+// mkray position direction — Main.hs:107-115 (only recip.z is ever read by plane leaves, :122-126)
+__device__ __forceinline__ RayD mkray(double px, double py, double pz, double dx, double dy, double dz, double eps) {
+    RayD r;
+    r.px = px; r.py = py; r.pz = pz;
+    r.dx = clampd(dx, eps); r.dy = clampd(dy, eps); r.dz = clampd(dz, eps);
+    r.rz = 1.0 / r.dz;
+    return r;
+}
+
+// jittered supersampling offsets (extension): spp == 1 -> (0, 0) = the reference
+__device__ __forceinline__ uint32_t mix32(uint32_t h) {
+    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16; return h;
+}
+__device__ __forceinline__ void sample_offset(const RenderParams &P, int x, int y, double &ox, double &oy) {
+    if (P.spp <= 1) { ox = 0; oy = 0; return; }
+    uint32_t h = mix32(P.seed_lo ^ mix32(P.seed_hi + 0x9e3779b9u));
+    h = mix32(h ^ (uint32_t)x);
+    h = mix32(h ^ ((uint32_t)y + 0x9e3779b9u));
+    h = mix32(h ^ ((uint32_t)P.sample + 0x7f4a7c15u));
+    const uint32_t h2 = mix32(h ^ 0x68bc21ebu);
+    const double u1 = (double)(h >> 8) * (1.0 / 16777216.0), u2 = (double)(h2 >> 8) * (1.0 / 16777216.0);
+    const int k = (int)floor(sqrt((double)P.spp) + 0.5);
+    if (k * k == P.spp) {
+        const int sx = P.sample % k, sy = P.sample / k;
+        ox = ((double)sx + u1) / (double)k - 0.5;
+        oy = ((double)sy + u2) / (double)k - 0.5;
+    } else { ox = u1 - 0.5; oy = u2 - 0.5; }
+}
+
+// cast camera x y — Main.hs:528-533
+__device__ __forceinline__ RayD camera_ray(const RenderParams &P, int x, int y) {
+    double ox, oy;
+    sample_offset(P, x, y, ox, oy);
+    const double posX = P.cam.scaleX * ((double)x + ox) + P.cam.dX;
+    const double posY = P.cam.scaleY * ((double)y + oy) + P.cam.dY;
+    const double n = sqrt(posX * posX + posY * posY + P.cam.d * P.cam.d);
+    return mkray(posX, posY, 0.0, posX / n, posY / n, P.cam.d / n, P.eps);
+}
+
+// planeRayIsect + the inside test of rectangle (Main.hs:234-242) / triangle (Main.hs:374-383).
+// KIND is the leaf type; L is wave-uniform in the filter loops (scalar loads).
+template <int KIND>
+__device__ __forceinline__ bool leaf_isect(const LeafD &L, const RayD &r, double &ix, double &iy, double &iz, double &t) {
+    const double a = L.nx, b = L.ny, c = L.nz;
+    const double frac = (a * r.dx + b * r.dy + c * r.dz) / r.dz;                       // Main.hs:269
+    const double z = (-L.d - a * r.px - b * r.py + (frac - c) * r.pz) / frac;          // :270
+    const double x = (r.dx * (z - r.pz) / r.dz) + r.px;                                // :271
+    const double y = (r.dy * (z - r.pz) / r.dz) + r.py;                                // :272
+    if (fabs(frac) <= 0.00001) return false;                                           // :273
+    t = (z - r.pz) * r.rz;                                                             // :256, 122-126
+    if (!(t >= 0)) return false;                                                       // :257
+    ix = x; iy = y; iz = z;
+    const double wx = x - L.p0x, wy = y - L.p0y, wz = z - L.p0z;
+    if (KIND == LEAF_RECT) {
+        const double dw = wx * L.e1x + wy * L.e1y + wz * L.e1z;                        // :239
+        const double dh = wx * L.e2x + wy * L.e2y + wz * L.e2z;                        // :240
+        return 0 <= dw && dw <= L.c0 && 0 <= dh && dh <= L.c1;                         // :241
+    } else {
+        const double wv = wx * L.e2x + wy * L.e2y + wz * L.e2z;                        // :377
+        const double wu = wx * L.e1x + wy * L.e1y + wz * L.e1z;                        // :378
+        const double rr = (L.c0 * wv - L.c2 * wu) / L.c3;                              // :379
+        const double ss = (L.c0 * wu - L.c1 * wv) / L.c3;                              // :380
+        return rr >= 0 && ss >= 0 && rr + ss <= 1;                                     // :382
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// FP32 filter: 4 rays of one lane against one leaf record (wave-uniform -> SGPR operands)
+
+__device__ __forceinline__ f2 splat(float v) { f2 r = {v, v}; return r; }
+__device__ __forceinline__ f2 pkfma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+struct Dir4 { f2 x[2], y[2], z[2]; };   // directions of the lane's 4 rays from the apex
+
+// Returns z[r] for the lane's 4 rays: ray r passes the filter iff z[r] >= R.c[10] (= -margin).
+//   triangle : z = min(q1*N, q2*N, (1-q1-q2)*N [, N - Kq])      q1, q2 = barycentrics r, s
+//   rectangle: z = min(N - max(|a'N|, |b'N|)     [, N - Kq])     a', b' in [-1, 1]
+// CLIP adds the "not beyond the ray origin" test u* = K/N <= 1 used by shadow rays.
+template <int KIND, bool CLIP>
+__device__ __forceinline__ bool filter4(const FilterRec &R, const Dir4 &D, float z[4]) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const f2 q1 = pkfma(splat(R.c[0]), D.x[p], pkfma(splat(R.c[1]), D.y[p], splat(R.c[2]) * D.z[p]));
+        const f2 q2 = pkfma(splat(R.c[3]), D.x[p], pkfma(splat(R.c[4]), D.y[p], splat(R.c[5]) * D.z[p]));
+        const f2 n = pkfma(splat(R.c[6]), D.x[p], pkfma(splat(R.c[7]), D.y[p], splat(R.c[8]) * D.z[p]));
+        f2 zz;
+        if (KIND == LEAF_TRI) {
+            const f2 w = n - q1 - q2;
+            zz = f2{__builtin_fminf(__builtin_fminf(q1[0], q2[0]), w[0]), __builtin_fminf(__builtin_fminf(q1[1], q2[1]), w[1])};
+        } else {
+            const f2 m = f2{__builtin_fmaxf(__builtin_fabsf(q1[0]), __builtin_fabsf(q2[0])),
+                            __builtin_fmaxf(__builtin_fabsf(q1[1]), __builtin_fabsf(q2[1]))};
+            zz = n - m;
+        }
+        if (CLIP) {
+            const f2 c = n - splat(R.c[9]);
+            zz = f2{__builtin_fminf(zz[0], c[0]), __builtin_fminf(zz[1], c[1])};
+        }
+        z[2 * p] = zz[0]; z[2 * p + 1] = zz[1];
+    }
+    const float mx = __builtin_fmaxf(__builtin_fmaxf(z[0], z[1]), __builtin_fmaxf(z[2], z[3]));
+    return mx >= R.c[10];
+}
+
+__device__ __forceinline__ void tile_coords(const RenderParams &P, int &x0, int &y, bool &row_ok) {
+    const int wave = (int)(blockIdx.x * RT_WAVES_PER_BLOCK + (threadIdx.x >> 6));
+    const int lane = (int)(threadIdx.x & 63);
+    const int tx = wave % P.tiles_x, ty = wave / P.tiles_x;
+    x0 = tx * RT_TILE_W + (lane & 7) * 4;
+    const int ly = ty * RT_TILE_H + (lane >> 3);
+    row_ok = ly < P.nrows;
+    y = P.row0 + ly;             // absolute image row
+}
+
+// ------------------------------------------------------------------------------------------
+// Kernel 1: nearest hit of the primary rays -> hit_id
+//   replaces `intersect world (cast camera x y)` of trace (Main.hs:543) for every pixel of the band
+
+template <int KIND>
+__device__ __forceinline__ void primary_loop(const RenderParams &P, const FilterRec *__restrict__ recs,
+                                             const int32_t *__restrict__ gids, int n, const Dir4 &D,
+                                             const bool act[4], int x0, int y, double bt[4], int bid[4],
+                                             unsigned &nexact) {
+    for (int i = 0; i < n; ++i) {
+        float z[4];
+        if (filter4<KIND, false>(recs[i], D, z)) {
+            const int gid = gids[i];
+            const LeafD &L = P.leaves[gid];
+            const float negm = recs[i].c[10];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if ((z[r] >= negm) & act[r]) {
+                    int xr = x0 + r;
+                    asm volatile("" : "+v"(xr));   // keep the exact-path ray set-up inside this rare branch
+                    const RayD ray = camera_ray(P, xr, y);
+                    double ix, iy, iz, t;
+                    ++nexact;
+                    if (leaf_isect<KIND>(L, ray, ix, iy, iz, t)) {
+                        // nearest wins; equal t -> the left-most leaf of the tree (Main.hs:213-214)
+                        if (t < bt[r] || (t == bt[r] && gid < bid[r]) || bid[r] < 0) { bt[r] = t; bid[r] = gid; }
+                    }
+                }
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(RT_WAVES_PER_BLOCK * 64) k_primary(const RenderParams P) {
+    int x0, y; bool row_ok;
+    tile_coords(P, x0, y, row_ok);
+    bool act[4];
+    Dir4 D;
+    {
+        float dx[4], dy[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            act[r] = row_ok && (x0 + r) < P.w;
+            double ox, oy;
+            sample_offset(P, x0 + r, y, ox, oy);
+            dx[r] = (float)(P.cam.scaleX * ((double)(x0 + r) + ox) + P.cam.dX);
+            dy[r] = (float)(P.cam.scaleY * ((double)y + oy) + P.cam.dY);
+        }
+        const float dz = (float)P.cam.d;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            D.x[p] = f2{dx[2 * p], dx[2 * p + 1]};
+            D.y[p] = f2{dy[2 * p], dy[2 * p + 1]};
+            D.z[p] = f2{dz, dz};
+        }
+    }
+    double bt[4]; int bid[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { bt[r] = INFINITY; bid[r] = -1; }
+    unsigned nexact = 0;
+    primary_loop<LEAF_TRI>(P, P.tri_rec, P.tri_gid, P.ntri, D, act, x0, y, bt, bid, nexact);
+    primary_loop<LEAF_RECT>(P, P.rect_rec, P.rect_gid, P.nrect, D, act, x0, y, bt, bid, nexact);
+    const size_t row = (size_t)(y - P.row0) * (size_t)P.w;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (act[r]) P.hit_id[row + (size_t)(x0 + r)] = bid[r];
+    for (int o = 32; o > 0; o >>= 1) nexact += __shfl_down(nexact, o);
+    if ((threadIdx.x & 63) == 0 && nexact) atomicAdd(&P.counters[1], (unsigned long long)nexact);
+}
+
+// ------------------------------------------------------------------------------------------
+// Kernel 2: shading with shadow rays -> RGBA8
+//   replaces `light lights hit ray` (Main.hs:545, 436-441) = pointLight (467-487) + ambient (490-492)
+
+struct Hit4 { double px[4], py[4], pz[4], nx[4], ny[4], nz[4]; };
+
+// Haskell `round` (half-even) then fromInteger to Word8 (wraps) — Main.hs:451-456
+__device__ __forceinline__ int round8(double v) {
+    const double r = __builtin_rint(v);
+    if (!(fabs(r) < 9.0e18)) return 0;
+    return (int)((long long)r & 0xff);
+}
+__device__ __forceinline__ double hs_max0(double v) { return 0.0 <= v ? v : 0.0; }    // max 0 v
+
+template <int KIND>
+__device__ __forceinline__ void shadow_loop(const RenderParams &P, const FilterRec *__restrict__ recs,
+                                            const int32_t *__restrict__ gids, int n, const Dir4 &D,
+                                            const Hit4 &H, const int own[4], const LightD &Lt,
+                                            bool need[4], unsigned &nexact) {
+    for (int i = 0; i < n; ++i) {
+        float z[4];
+        if (filter4<KIND, true>(recs[i], D, z)) {
+            const int gid = gids[i];
+            const LeafD &L = P.leaves[gid];
+            const float negm = recs[i].c[10];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                // the hit leaf itself lies 1e-5 behind the shadow-ray origin (Main.hs:472): t < 0
+                if ((z[r] >= negm) & need[r] & (gid != own[r])) {
+                    double hx = H.px[r];
+                    asm volatile("" : "+v"(hx));   // keep the exact-path ray set-up inside this rare branch
+                    const double lx = Lt.px - hx, ly = Lt.py - H.py[r], lz = Lt.pz - H.pz[r];
+                    const double ln = sqrt(lx * lx + ly * ly + lz * lz);
+                    const double tx = lx / ln, ty = ly / ln, tz = lz / ln;             // to_light, :470
+                    const RayD ray = mkray(hx + 0.00001 * tx, H.py[r] + 0.00001 * ty, H.pz[r] + 0.00001 * tz,
+                                           tx, ty, tz, P.eps);                         // :472
+                    double ix, iy, iz, t;
+                    ++nexact;
+                    if (leaf_isect<KIND>(L, ray, ix, iy, iz, t)) {
+                        const double tl = (Lt.pz - ray.pz) * ray.rz;                   // rayDistance ray lpos
+                        if (t <= tl) need[r] = false;                                  // :474 -> black
+                    }
+                }
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(RT_WAVES_PER_BLOCK * 64) k_shade(const RenderParams P) {
+    int x0, y; bool row_ok;
+    tile_coords(P, x0, y, row_ok);
+    const size_t row = (size_t)(y - P.row0) * (size_t)P.w;
+    bool hit[4]; int own[4]; int mat[4];
+    Hit4 H;
+    int cr[4], cg[4], cb[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        cr[r] = cg[r] = cb[r] = 0;
+        const bool act = row_ok && (x0 + r) < P.w;
+        own[r] = act ? P.hit_id[row + (size_t)(x0 + r)] : -1;
+        hit[r] = own[r] >= 0;
+        mat[r] = 0;
+        H.px[r] = H.py[r] = H.pz[r] = 0; H.nx[r] = H.ny[r] = H.nz[r] = 0;
+        if (hit[r]) {
+            // recompute the intersection (isect, normal) of the winning leaf exactly
+            const LeafD L = P.leaves[own[r]];
+            const RayD ray = camera_ray(P, x0 + r, y);
+            double ix, iy, iz, t;
+            if (L.kind == LEAF_RECT) leaf_isect<LEAF_RECT>(L, ray, ix, iy, iz, t);
+            else leaf_isect<LEAF_TRI>(L, ray, ix, iy, iz, t);
+            H.px[r] = ix; H.py[r] = iy; H.pz[r] = iz;
+            mat[r] = L.mat;
+            double nx = L.nx, ny = L.ny, nz = L.nz;
+            if (L.nmode == RT_NORMAL_MANTLE) {                                         // Main.hs:769-771
+                const AuxD A = P.aux[L.aux];
+                nx = A.a[0] + (ix - A.a[3]) * A.a[6];
+                nz = A.a[2] + (iz - A.a[5]) * A.a[8];
+                ny = 0;
+            } else if (L.nmode == RT_NORMAL_GAUSSIAN) {                                // Main.hs:959-963, 580-584
+                const AuxD A = P.aux[L.aux];
+                const double gx = A.a[0] * (ix - A.a[1]), gy = A.a[0] * (iz - A.a[3]);
+                const double f = exp(-(gx * gx + gy * gy) * 4);
+                const double dfdx = -8 * gx * f, dfdy = -8 * gy * f;
+                // normalize (MkV3D 1 dfdx 0 *# MkV3D 0 dfdy 1)
+                const double vx = dfdx * 1 - 0 * dfdy, vy = 0 * 0 - 1 * 1, vz = 1 * dfdy - 0 * dfdx;
+                const double vn = sqrt(vx * vx + vy * vy + vz * vz);
+                const double ux = vx / vn, uy = vy / vn, uz = vz / vn;
+                const double dt = nx * ux + ny * uy + nz * uz;
+                const double sg = dt > 0 ? 1.0 : (dt < 0 ? -1.0 : dt);                  // signum
+                nx = sg * ux; ny = sg * uy; nz = sg * uz;
+            }
+            H.nx[r] = nx; H.ny[r] = ny; H.nz[r] = nz;
+        }
+    }
+    unsigned nshadow = 0, nexact = 0;
+    for (int li = 0; li < P.nlights; ++li) {
+        const LightD &Lt = P.lights[li];
+        if (Lt.kind == 1) {                                                            // ambient, :490-492
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (hit[r]) {
+                    const MaterialD M = P.mats[mat[r]];
+                    cr[r] = min(255, cr[r] + round8(Lt.f * (double)M.diffuse[0]));
+                    cg[r] = min(255, cg[r] + round8(Lt.f * (double)M.diffuse[1]));
+                    cb[r] = min(255, cb[r] + round8(Lt.f * (double)M.diffuse[2]));
+                }
+            continue;
+        }
+        // point light: decide which pixels need a shadow ray.  When L.N <= 0 both Phong terms are
+        // exactly 0 (Main.hs:480-484), so the shadow ray cannot change the pixel and is not cast.
+        bool need[4];
+        Dir4 D;
+        float ddx[4], ddy[4], ddz[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            need[r] = false;
+            ddx[r] = ddy[r] = ddz[r] = 0.f;
+            if (hit[r]) {
+                const double lx = Lt.px - H.px[r], ly = Lt.py - H.py[r], lz = Lt.pz - H.pz[r];
+                const double ln = sqrt(lx * lx + ly * ly + lz * lz);
+                const double tx = lx / ln, ty = ly / ln, tz = lz / ln;
+                const double lndot = tx * H.nx[r] + ty * H.ny[r] + tz * H.nz[r];
+                need[r] = !(lndot <= 0);
+                // D = shadow-ray origin - light position
+                ddx[r] = (float)((H.px[r] + 0.00001 * tx) - Lt.px);
+                ddy[r] = (float)((H.py[r] + 0.00001 * ty) - Lt.py);
+                ddz[r] = (float)((H.pz[r] + 0.00001 * tz) - Lt.pz);
+            }
+            nshadow += need[r] ? 1u : 0u;
+        }
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            D.x[p] = f2{ddx[2 * p], ddx[2 * p + 1]};
+            D.y[p] = f2{ddy[2 * p], ddy[2 * p + 1]};
+            D.z[p] = f2{ddz[2 * p], ddz[2 * p + 1]};
+        }
+        if (__any(need[0] | need[1] | need[2] | need[3])) {
+            const size_t ro = (size_t)Lt.rec_offset;
+            shadow_loop<LEAF_TRI>(P, P.tri_rec + ro * (size_t)P.ntri, P.tri_gid, P.ntri, D, H, own, Lt, need, nexact);
+            shadow_loop<LEAF_RECT>(P, P.rect_rec + ro * (size_t)P.nrect, P.rect_gid, P.nrect, D, H, own, Lt, need, nexact);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (need[r]) {                                                             // lit: Main.hs:476-487
+                const MaterialD M = P.mats[mat[r]];
+                const RayD ray = camera_ray(P, x0 + r, y);
+                const double lx = Lt.px - H.px[r], ly = Lt.py - H.py[r], lz = Lt.pz - H.pz[r];
+                const double ln = sqrt(lx * lx + ly * ly + lz * lz);
+                const double tx = lx / ln, ty = ly / ln, tz = lz / ln;
+                const double lndot = tx * H.nx[r] + ty * H.ny[r] + tz * H.nz[r];
+                const double k2 = 2 * lndot;
+                const double rx = tx - k2 * H.nx[r], ry = ty - k2 * H.ny[r], rz = tz - k2 * H.nz[r];
+                const double fDiffuse = Lt.diffuse * hs_max0(lndot);
+                const double fSpecular = (lndot <= 0) ? 0.0
+                    : Lt.specular * pow(hs_max0(rx * ray.dx + ry * ray.dy + rz * ray.dz), M.specularity);
+                cr[r] = min(255, cr[r] + min(255, round8(fDiffuse * (double)M.diffuse[0]) + round8(fSpecular * (double)M.specular[0])));
+                cg[r] = min(255, cg[r] + min(255, round8(fDiffuse * (double)M.diffuse[1]) + round8(fSpecular * (double)M.specular[1])));
+                cb[r] = min(255, cb[r] + min(255, round8(fDiffuse * (double)M.diffuse[2]) + round8(fSpecular * (double)M.specular[2])));
+            }
+    }
+    if (P.rgba) {
+        uint32_t px[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) px[r] = (uint32_t)cr[r] | ((uint32_t)cg[r] << 8) | ((uint32_t)cb[r] << 16) | 0xff000000u;
+        uint32_t *dst = reinterpret_cast<uint32_t *>(P.rgba) + row + (size_t)x0;
+        if (row_ok && x0 + 3 < P.w && ((P.w & 3) == 0)) {
+            *reinterpret_cast<uint4 *>(dst) = make_uint4(px[0], px[1], px[2], px[3]);  // 16 B per lane, coalesced
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (row_ok && x0 + r < P.w) dst[r] = px[r];
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (row_ok && x0 + r < P.w) {
+                uint32_t *a = P.accum + 3 * (row + (size_t)(x0 + r));
+                a[0] += (uint32_t)cr[r]; a[1] += (uint32_t)cg[r]; a[2] += (uint32_t)cb[r];
+            }
+    }
+    // wave-level reduction of the counters: one atomic per wave
+    for (int o = 32; o > 0; o >>= 1) { nshadow += __shfl_down(nshadow, o); nexact += __shfl_down(nexact, o); }
+    if ((threadIdx.x & 63) == 0) {
+        if (nshadow) atomicAdd(&P.counters[0], (unsigned long long)nshadow);
+        if (nexact) atomicAdd(&P.counters[2], (unsigned long long)nexact);
+    }
+}
+
+// spp > 1: mean of the per-sample 8-bit colours, (sum + spp/2) / spp
+__global__ void k_resolve(const uint32_t *__restrict__ accum, uint8_t *__restrict__ rgba, size_t npix, uint32_t spp) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix) return;
+    const uint32_t r = (accum[3 * i] + spp / 2) / spp, g = (accum[3 * i + 1] + spp / 2) / spp, b = (accum[3 * i + 2] + spp / 2) / spp;
+    reinterpret_cast<uint32_t *>(rgba)[i] = r | (g << 8) | (b << 16) | 0xff000000u;
+}
+
+// ------------------------------------------------------------------------------------------
+// Host side
+
+hipStream_t g_stream = nullptr;
+int g_device = -1;
+
+bool hip_ok(hipError_t e, const char *what) {
+    if (e == hipSuccess) return true;
+    set_error(std::string(what) + ": " + hipGetErrorString(e));
+    return false;
+}
+#define HIP_TRY(expr) do { if (!hip_ok((expr), #expr)) return RT_ERR_HIP; } while (0)
+
+template <typename T>
+int upload(T *&dst, const std::vector<T> &src) {
+    if (dst) { HIP_TRY(hipFree(dst)); dst = nullptr; }
+    const size_t bytes = sizeof(T) * (src.empty() ? 1 : src.size());
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dst), bytes));
+    if (!src.empty()) HIP_TRY(hipMemcpy(dst, src.data(), sizeof(T) * src.size(), hipMemcpyHostToDevice));
+    return RT_OK;
+}
+
+template <typename T>
+int ensure(T *&buf, size_t &cap, size_t need) {
+    if (cap >= need && buf) return RT_OK;
+    if (buf) { HIP_TRY(hipFree(buf)); buf = nullptr; cap = 0; }
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&buf), sizeof(T) * need));
+    cap = need;
+    return RT_OK;
+}
+
+int ensure_init() {
+    if (g_device >= 0) return RT_OK;
+    return rt_init(0);
+}
+
+int prepare(rt_scene &s, int w, int h) {
+    int rc;
+    if (s.dirty || s.rec_w != w || s.rec_h != h || s.dev.device != g_device) {
+        for (const MaterialD &m : s.mats)
+            if (m.reflectivity > 0) { /* handled by caller: depth check */ }
+        build_filter_records(s, w, h);
+        if ((rc = upload(s.dev.leaves, s.leaves))) return rc;
+        if ((rc = upload(s.dev.aux, s.aux))) return rc;
+        if ((rc = upload(s.dev.mats, s.mats))) return rc;
+        if ((rc = upload(s.dev.lights, s.lights))) return rc;
+        if ((rc = upload(s.dev.tri_rec, s.tri_rec))) return rc;
+        if ((rc = upload(s.dev.rect_rec, s.rect_rec))) return rc;
+        if ((rc = upload(s.dev.tri_gid, s.tri_gid))) return rc;
+        if ((rc = upload(s.dev.rect_gid, s.rect_gid))) return rc;
+        if (!s.dev.counters) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s.dev.counters), 8 * sizeof(unsigned long long)));
+        s.dev.device = g_device;
+        s.dirty = false;
+    }
+    for (int i = 0; i < 3; ++i)
+        if (!s.ev[i]) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); s.ev[i] = e; }
+    return RT_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int rt_init(int device) {
+    int n = 0;
+    if (!hip_ok(hipGetDeviceCount(&n), "hipGetDeviceCount") || n <= 0) {
+        set_error("rt_init: no HIP device available (this library has no CPU fallback)");
+        return RT_ERR_HIP;
+    }
+    if (device < 0 || device >= n) { set_error("rt_init: device index out of range"); return RT_ERR_ARG; }
+    HIP_TRY(hipSetDevice(device));
+    if (g_stream && g_device != device) { (void)hipStreamDestroy(g_stream); g_stream = nullptr; }
+    if (!g_stream) HIP_TRY(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+    g_device = device;
+    return RT_OK;
+}
+
+void rt_scene_destroy(rt_scene *s) {
+    if (!s) return;
+    DeviceScene &d = s->dev;
+    void *ptrs[] = {d.leaves, d.aux, d.mats, d.lights, d.tri_rec, d.rect_rec, d.tri_gid, d.rect_gid,
+                    d.counters, d.hit_id, d.accum, d.rgba};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    for (void *e : s->ev) if (e) (void)hipEventDestroy((hipEvent_t)e);
+    delete s;
+}
+
+int rt_render_device(rt_scene *s, int w, int h, int depth, int spp, uint64_t seed, int row0, int nrows,
+                     void *d_rgba, void *d_hit_id, void *stream) {
+    if (!s) { set_error("rt_render: scene is NULL"); return RT_ERR_ARG; }
+    if (w <= 0 || h <= 0 || spp < 1 || row0 < 0 || nrows < 0 || row0 + nrows > h) {
+        set_error("rt_render: bad image size or row band"); return RT_ERR_ARG;
+    }
+    if (depth < 0) { set_error("rt_render: depth must be >= 0"); return RT_ERR_ARG; }
+    if (depth > 1)
+        for (const MaterialD &m : s->mats)
+            if (m.reflectivity > 0) {
+                set_error("rt_render: reflective materials (trace depth > 1, Main.hs:546-556) are not built yet");
+                return RT_ERR_UNSUPPORTED;
+            }
+    int rc;
+    if ((rc = ensure_init())) return rc;
+    if ((rc = prepare(*s, w, h))) return rc;
+    hipStream_t st = stream ? (hipStream_t)stream : g_stream;
+    const size_t npix = (size_t)w * (size_t)nrows;
+    s->last_primary = (uint64_t)npix * (uint64_t)spp;
+    if (npix == 0) return RT_OK;
+    int32_t *hit = (int32_t *)d_hit_id;
+    if (!hit || spp > 1) {
+        if ((rc = ensure(s->dev.hit_id, s->dev.hit_id_cap, npix))) return rc;
+        if (!hit) hit = s->dev.hit_id;
+    }
+    if (spp > 1 && d_rgba) {
+        if ((rc = ensure(s->dev.accum, s->dev.accum_cap, 3 * npix))) return rc;
+        HIP_TRY(hipMemsetAsync(s->dev.accum, 0, 3 * npix * sizeof(uint32_t), st));
+    }
+    HIP_TRY(hipMemsetAsync(s->dev.counters, 0, 8 * sizeof(unsigned long long), st));
+
+    RenderParams P{};
+    P.leaves = s->dev.leaves; P.aux = s->dev.aux; P.mats = s->dev.mats; P.lights = s->dev.lights;
+    P.tri_rec = s->dev.tri_rec; P.rect_rec = s->dev.rect_rec;
+    P.tri_gid = s->dev.tri_gid; P.rect_gid = s->dev.rect_gid;
+    P.counters = s->dev.counters;
+    P.cam = fixed_camera(w, h);
+    P.eps = ray_eps();
+    P.ntri = (int)s->tri_gid.size(); P.nrect = (int)s->rect_gid.size();
+    P.nlights = (int)s->lights.size(); P.nleaves = (int)s->leaves.size();
+    P.w = w; P.h = h; P.row0 = row0; P.nrows = nrows;
+    P.spp = spp; P.seed_lo = (uint32_t)seed; P.seed_hi = (uint32_t)(seed >> 32);
+    P.tiles_x = (w + RT_TILE_W - 1) / RT_TILE_W;
+    P.tiles_y = (nrows + RT_TILE_H - 1) / RT_TILE_H;
+    const long long tiles = (long long)P.tiles_x * P.tiles_y;
+    const unsigned blocks = (unsigned)((tiles + RT_WAVES_PER_BLOCK - 1) / RT_WAVES_PER_BLOCK);
+    const dim3 block(RT_WAVES_PER_BLOCK * 64);
+
+    HIP_TRY(hipEventRecord((hipEvent_t)s->ev[0], st));
+    for (int sample = 0; sample < spp; ++sample) {
+        P.sample = sample;
+        // sample 0 writes the caller's hit-ID buffer; later samples use the scratch one
+        P.hit_id = (sample == 0) ? hit : s->dev.hit_id;
+        if (depth == 0) {      // trace 0 = black (Main.hs:542): every pixel misses
+            HIP_TRY(hipMemsetAsync(P.hit_id, 0xff, npix * sizeof(int32_t), st));
+        } else {
+            hipLaunchKernelGGL(k_primary, dim3(blocks), block, 0, st, P);
+        }
+        if (sample == 0) HIP_TRY(hipEventRecord((hipEvent_t)s->ev[1], st));
+        if (d_rgba) {
+            P.rgba = (spp == 1) ? (uint8_t *)d_rgba : nullptr;
+            P.accum = (spp == 1) ? nullptr : s->dev.accum;
+            hipLaunchKernelGGL(k_shade, dim3(blocks), block, 0, st, P);
+        }
+    }
+    if (d_rgba && spp > 1)
+        hipLaunchKernelGGL(k_resolve, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st,
+                           s->dev.accum, (uint8_t *)d_rgba, npix, (uint32_t)spp);
+    HIP_TRY(hipEventRecord((hipEvent_t)s->ev[2], st));
+    HIP_TRY(hipGetLastError());
+    s->stats_pending = true;
+    return RT_OK;
+}
+
+int rt_render(rt_scene *s, int w, int h, int depth, int spp, uint64_t seed, int row0, int nrows,
+              uint8_t *rgba_out, int32_t *hit_id_out) {
+    if (!s) { set_error("rt_render: scene is NULL"); return RT_ERR_ARG; }
+    if (w <= 0 || h <= 0 || nrows < 0 || row0 < 0 || row0 + nrows > h) { set_error("rt_render: bad image size or row band"); return RT_ERR_ARG; }
+    int rc;
+    if ((rc = ensure_init())) return rc;
+    const size_t npix = (size_t)w * (size_t)nrows;
+    if (npix == 0) return RT_OK;
+    if ((rc = ensure(s->dev.rgba, s->dev.rgba_cap, 4 * npix))) return rc;
+    if ((rc = ensure(s->dev.hit_id, s->dev.hit_id_cap, npix))) return rc;
+    // the scratch hit buffer doubles as the output buffer for sample 0; spp > 1 needs a second one
+    int32_t *d_hit = s->dev.hit_id;
+    int32_t *tmp_hit = nullptr;
+    if (spp > 1) { HIP_TRY(hipMalloc(reinterpret_cast<void **>(&tmp_hit), npix * sizeof(int32_t))); d_hit = tmp_hit; }
+    rc = rt_render_device(s, w, h, depth, spp, seed, row0, nrows, rgba_out ? s->dev.rgba : nullptr, d_hit, g_stream);
+    if (rc == RT_OK) {
+        if (rgba_out && !hip_ok(hipMemcpyAsync(rgba_out, s->dev.rgba, 4 * npix, hipMemcpyDeviceToHost, g_stream), "hipMemcpyAsync")) rc = RT_ERR_HIP;
+        if (rc == RT_OK && hit_id_out && !hip_ok(hipMemcpyAsync(hit_id_out, d_hit, npix * sizeof(int32_t), hipMemcpyDeviceToHost, g_stream), "hipMemcpyAsync")) rc = RT_ERR_HIP;
+        if (!hip_ok(hipStreamSynchronize(g_stream), "hipStreamSynchronize")) rc = RT_ERR_HIP;
+    }
+    if (tmp_hit) (void)hipFree(tmp_hit);
+    return rc;
+}
+
+int rt_synchronize(void) {
+    if (g_device < 0) return RT_OK;
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    return RT_OK;
+}
+
+int rt_get_stats(rt_scene *s, rt_stats *out) {
+    if (!s || !out) { set_error("rt_get_stats: NULL argument"); return RT_ERR_ARG; }
+    if (s->stats_pending) {
+        HIP_TRY(hipEventSynchronize((hipEvent_t)s->ev[2]));
+        unsigned long long c[8];
+        HIP_TRY(hipMemcpy(c, s->dev.counters, sizeof c, hipMemcpyDeviceToHost));
+        float a = 0, b = 0, t = 0;
+        HIP_TRY(hipEventElapsedTime(&a, (hipEvent_t)s->ev[0], (hipEvent_t)s->ev[1]));
+        HIP_TRY(hipEventElapsedTime(&b, (hipEvent_t)s->ev[1], (hipEvent_t)s->ev[2]));
+        HIP_TRY(hipEventElapsedTime(&t, (hipEvent_t)s->ev[0], (hipEvent_t)s->ev[2]));
+        rt_stats st{};
+        st.primary_rays = s->last_primary;
+        st.shadow_rays = c[0];
+        st.tri_tests = (st.primary_rays + st.shadow_rays) * (uint64_t)s->tri_gid.size();
+        st.rect_tests = (st.primary_rays + st.shadow_rays) * (uint64_t)s->rect_gid.size();
+        st.exact_evals = c[1] + c[2];
+        st.ms_primary = a; st.ms_shade = b; st.ms_total = t;
+        s->stats = st;
+        s->stats_pending = false;
+    }
+    *out = s->stats;
+    return RT_OK;
+}
+
+} // extern "C"

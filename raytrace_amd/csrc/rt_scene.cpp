@@ -1,0 +1,381 @@
+// rt_scene.cpp — host scene builder behind the C ABI (include/raytrace_gpu.h).
+//
+// Every rt_add_* reifies one constructor of the reference as leaves: the constants the reference
+// closes over (normal, d, point', ww, hh / u, v, uv, uu, vv, n) are computed here once, in IEEE
+// double and in the reference's own expression order (no FMA contraction: build with
+// -ffp-contract=off), because the kernels' exact path must reproduce the reference bit for bit.
+#include "rt_scene.h"
+
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+namespace rt {
+
+static thread_local std::string g_err;
+void set_error(const std::string &msg) { g_err = msg; }
+
+struct D3 { double x, y, z; };
+static inline D3 operator+(D3 a, D3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+static inline D3 operator-(D3 a, D3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+static inline D3 scale(double s, D3 v) { return {s * v.x, s * v.y, s * v.z}; }
+static inline double dot3(D3 a, D3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }          // Main.hs:63
+static inline D3 cross3(D3 a, D3 b) {                                                         // Main.hs:68-69
+    return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - b.x * a.y};
+}
+static inline D3 unit(D3 v) { double n = std::sqrt(dot3(v, v)); return {v.x / n, v.y / n, v.z / n}; } // :79
+static inline D3 from(const double p[3]) { return {p[0], p[1], p[2]}; }
+
+double ray_eps() { return 2.2 * std::pow(10.0, -308.0); }                                     // Main.hs:114
+
+CameraD fixed_camera(int width, int height) {                                                 // Main.hs:506-527
+    CameraD c;
+    const double w = (double)width, h = (double)height;
+    const double fov = M_PI / 2;
+    c.scaleX = 1.0 / w;
+    c.scaleY = c.scaleX * (-h / w);
+    c.dX = -(c.scaleX * w / 2);
+    c.dY = -(c.scaleY * h / 2);
+    c.d = std::tan(fov / 2) * c.dX;
+    return c;
+}
+
+static int add_material(rt_scene &s, const rt_material &m) {
+    MaterialD d{};
+    d.specularity = m.specularity;
+    d.reflectivity = m.reflectivity;
+    std::memcpy(d.diffuse, m.diffuse, 3);
+    std::memcpy(d.specular, m.specular, 3);
+    s.mats.push_back(d);
+    return (int)s.mats.size() - 1;
+}
+
+static int push_leaf(rt_scene &s, LeafD &L) {
+    L.aux = -1;
+    L.nmode = RT_NORMAL_GEOMETRIC;
+    if (L.kind == LEAF_TRI) { L.slot = (int)s.tri_gid.size(); s.tri_gid.push_back((int)s.leaves.size()); }
+    else { L.slot = (int)s.rect_gid.size(); s.rect_gid.push_back((int)s.leaves.size()); }
+    s.leaves.push_back(L);
+    s.dirty = true;
+    return (int)s.leaves.size() - 1;
+}
+
+// rectangle material point width height — Main.hs:226-232
+static int add_rect(rt_scene &s, const rt_material &m, D3 point, D3 width, D3 height) {
+    LeafD L{};
+    L.kind = LEAF_RECT;
+    L.mat = add_material(s, m);
+    const D3 normal = unit(cross3(width, height));
+    const D3 corner = (point - scale(0.5, width)) - scale(0.5, height);
+    L.nx = normal.x; L.ny = normal.y; L.nz = normal.z;
+    L.d = -(dot3(point, normal));
+    L.p0x = corner.x; L.p0y = corner.y; L.p0z = corner.z;
+    L.e1x = width.x; L.e1y = width.y; L.e1z = width.z;
+    L.e2x = height.x; L.e2y = height.y; L.e2z = height.z;
+    L.c0 = dot3(width, width);
+    L.c1 = dot3(height, height);
+    return push_leaf(s, L);
+}
+
+// triangle material pa pb pc — Main.hs:363-372
+static int add_tri(rt_scene &s, const rt_material &m, D3 pa, D3 pb, D3 pc) {
+    LeafD L{};
+    L.kind = LEAF_TRI;
+    L.mat = add_material(s, m);
+    const D3 u = pb - pa, v = pc - pa;
+    const double uv = dot3(u, v), uu = dot3(u, u), vv = dot3(v, v);
+    const D3 normal = unit(cross3(u, v));
+    L.nx = normal.x; L.ny = normal.y; L.nz = normal.z;
+    L.d = dot3(scale(-1, pa), normal);
+    L.p0x = pa.x; L.p0y = pa.y; L.p0z = pa.z;
+    L.e1x = u.x; L.e1y = u.y; L.e1z = u.z;
+    L.e2x = v.x; L.e2y = v.y; L.e2z = v.z;
+    L.c0 = uv; L.c1 = uu; L.c2 = vv;
+    L.c3 = uv * uv - uu * vv;
+    return push_leaf(s, L);
+}
+
+// ------------------------------------------------------------------------------------------
+// FP32 filter records.
+//
+// For rays p(u) = A + u*D leaving a common apex A, the plane of a leaf is met at u* = K / N with
+// K = n.(p0 - A) and N = n.D, and every inside-test quantity q of the reference (the barycentrics
+// r, s of Main.hs:379-380, the normalised rectangle coordinates of Main.hs:238-241) is affine in
+// the hit point, so q*N is LINEAR in D:  q*N = D . (q(A) n + K grad q).  The filter evaluates those
+// linear forms in FP32 and accepts when they are within a per-leaf error margin of the accepting
+// side — no division, so no NaN/inf can hide a hit.  Records are sign-normalised to K >= 0, so a
+// hit in front of the apex has N > 0.
+static inline float f_down(double v) {
+    float f = (float)v;
+    if ((double)f > v) f = std::nextafterf(f, -std::numeric_limits<float>::infinity());
+    return f;
+}
+
+static FilterRec never_rec() {   // degenerate leaf (NaN normal): the reference never hits it
+    FilterRec r{};
+    r.c[9] = 0.0f;
+    r.c[10] = 1.0f;     // z <= 0 < 1: never passes
+    return r;
+}
+static FilterRec always_rec() {  // apex (numerically) in the leaf's plane: let the exact path decide
+    FilterRec r{};
+    r.c[9] = -1.0f;
+    r.c[10] = -1.0f;
+    return r;
+}
+
+static FilterRec make_rec(const LeafD &L, const double A[3], const double dmax[3]) {
+    const double n[3] = {L.nx, L.ny, L.nz};
+    const double e1[3] = {L.e1x, L.e1y, L.e1z}, e2[3] = {L.e2x, L.e2y, L.e2z};
+    double g1[3], g2[3], q1A, q2A;   // gradients of the two inside coordinates and their value at A
+    if (L.kind == LEAF_TRI) {
+        // r = w.gr, s = w.gs with w = p - pa (Main.hs:376-380)
+        for (int i = 0; i < 3; ++i) {
+            g1[i] = (L.c0 * e2[i] - L.c2 * e1[i]) / L.c3;
+            g2[i] = (L.c0 * e1[i] - L.c1 * e2[i]) / L.c3;
+        }
+        const double w[3] = {A[0] - L.p0x, A[1] - L.p0y, A[2] - L.p0z};
+        q1A = g1[0] * w[0] + g1[1] * w[1] + g1[2] * w[2];
+        q2A = g2[0] * w[0] + g2[1] * w[1] + g2[2] * w[2];
+    } else {
+        // a' = 2*dw/ww - 1, b' = 2*dh/hh - 1 in [-1, 1] (Main.hs:238-241), measured from the centre
+        const double c[3] = {L.p0x + 0.5 * e1[0] + 0.5 * e2[0], L.p0y + 0.5 * e1[1] + 0.5 * e2[1],
+                             L.p0z + 0.5 * e1[2] + 0.5 * e2[2]};
+        for (int i = 0; i < 3; ++i) { g1[i] = 2.0 * e1[i] / L.c0; g2[i] = 2.0 * e2[i] / L.c1; }
+        const double w[3] = {A[0] - c[0], A[1] - c[1], A[2] - c[2]};
+        q1A = g1[0] * w[0] + g1[1] * w[1] + g1[2] * w[2];
+        q2A = g2[0] * w[0] + g2[1] * w[1] + g2[2] * w[2];
+    }
+    double K = -(L.d + (n[0] * A[0] + n[1] * A[1] + n[2] * A[2]));
+    double c1[3], c2[3], cn[3];
+    for (int i = 0; i < 3; ++i) { c1[i] = q1A * n[i] + K * g1[i]; c2[i] = q2A * n[i] + K * g2[i]; cn[i] = n[i]; }
+    if (K < 0) { K = -K; for (int i = 0; i < 3; ++i) { c1[i] = -c1[i]; c2[i] = -c2[i]; cn[i] = -cn[i]; } }
+    double S = 0, SN = 0;
+    for (int i = 0; i < 3; ++i) {
+        S += (std::fabs(c1[i]) + std::fabs(c2[i]) + std::fabs(cn[i])) * dmax[i];
+        SN += std::fabs(cn[i]) * dmax[i];
+    }
+    if (!std::isfinite(S) || !std::isfinite(K)) return never_rec();
+    // margins: every input is rounded to FP32 once (2^-24 relative) and each linear form takes
+    // three FP32 operations, W two more; 2^-20 of the magnitude sum leaves a factor > 3 of slack.
+    const double m = std::ldexp(S, -20) + 1e-30;
+    const double mK = std::ldexp(SN + K, -20) + 1e-30;
+    if (K <= 4 * mK) return always_rec();
+    FilterRec r{};
+    for (int i = 0; i < 3; ++i) { r.c[i] = (float)c1[i]; r.c[3 + i] = (float)c2[i]; r.c[6 + i] = (float)cn[i]; }
+    r.c[10] = f_down(-m);
+    r.c[9] = f_down((K - mK) - (double)r.c[10]);   // Kq: N - Kq >= -m  <=>  N >= K - mK
+    r.c[11] = 0.0f;
+    for (int i = 0; i < 11; ++i) if (!std::isfinite(r.c[i])) return always_rec();   // FP32 overflow
+    return r;
+}
+
+void build_filter_records(rt_scene &s, int w, int h) {
+    const size_t ntri = s.tri_gid.size(), nrect = s.rect_gid.size();
+    const int napex = 1 + s.npoint;
+    s.tri_rec.assign(ntri * (size_t)napex, FilterRec{});
+    s.rect_rec.assign(nrect * (size_t)napex, FilterRec{});
+    // scene extent (leaf corners), for the per-light bound on |D| = |hit - light|
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (const LeafD &L : s.leaves) {
+        const double p[4][3] = {
+            {L.p0x, L.p0y, L.p0z},
+            {L.p0x + L.e1x, L.p0y + L.e1y, L.p0z + L.e1z},
+            {L.p0x + L.e2x, L.p0y + L.e2y, L.p0z + L.e2z},
+            {L.p0x + L.e1x + L.e2x, L.p0y + L.e1y + L.e2y, L.p0z + L.e1z + L.e2z}};
+        const int np = L.kind == LEAF_TRI ? 3 : 4;
+        for (int k = 0; k < np; ++k)
+            for (int i = 0; i < 3; ++i)
+                if (std::isfinite(p[k][i])) { lo[i] = std::fmin(lo[i], p[k][i]); hi[i] = std::fmax(hi[i], p[k][i]); }
+    }
+    const CameraD cam = fixed_camera(w, h);
+    int apex = 0;
+    auto fill = [&](const double A[3], const double dmax[3]) {
+        for (size_t k = 0; k < ntri; ++k) s.tri_rec[(size_t)apex * ntri + k] = make_rec(s.leaves[s.tri_gid[k]], A, dmax);
+        for (size_t k = 0; k < nrect; ++k) s.rect_rec[(size_t)apex * nrect + k] = make_rec(s.leaves[s.rect_gid[k]], A, dmax);
+        ++apex;
+    };
+    {   // the eye: every primary ray o = (posX, posY, 0), D = (posX, posY, d) passes through o - D
+        const double A[3] = {0.0, 0.0, -cam.d};
+        // |posX| <= |dX| (+ half a pixel of jitter), |posY| <= |dY| (+ ...), D.z = d
+        const double dmax[3] = {std::fabs(cam.dX) + 2 * std::fabs(cam.scaleX),
+                                std::fabs(cam.dY) + 2 * std::fabs(cam.scaleY), std::fabs(cam.d)};
+        fill(A, dmax);
+    }
+    for (LightD &Lt : s.lights) {
+        if (Lt.kind != 0) continue;
+        Lt.rec_offset = apex;
+        const double A[3] = {Lt.px, Lt.py, Lt.pz};
+        double dmax[3];
+        for (int i = 0; i < 3; ++i) {
+            const double a = std::fabs(lo[i] - A[i]), b = std::fabs(hi[i] - A[i]);
+            dmax[i] = (s.leaves.empty() ? 1.0 : std::fmax(a, b)) * 1.001 + 1e-3;
+        }
+        fill(A, dmax);
+    }
+    s.rec_w = w; s.rec_h = h;
+}
+
+} // namespace rt
+
+using namespace rt;
+
+// ------------------------------------------------------------------------------------------
+// C ABI: construction and introspection (no device needed)
+
+extern "C" {
+
+const char *rt_last_error(void) { return g_err.c_str(); }
+const char *rt_version(void) { return "raytrace_amd 0.1 (gfx950)"; }
+
+int rt_scene_create(rt_scene **out) {
+    if (!out) { set_error("rt_scene_create: out is NULL"); return RT_ERR_ARG; }
+    *out = new (std::nothrow) rt_scene();
+    if (!*out) { set_error("rt_scene_create: out of memory"); return RT_ERR_NOMEM; }
+    return RT_OK;
+}
+
+int rt_add_rectangle(rt_scene *s, const rt_material *m, const double point[3],
+                     const double width[3], const double height[3]) {
+    if (!s || !m || !point || !width || !height) { set_error("rt_add_rectangle: NULL argument"); return RT_ERR_ARG; }
+    return add_rect(*s, *m, from(point), from(width), from(height));
+}
+
+int rt_add_triangle(rt_scene *s, const rt_material *m, const double pa[3], const double pb[3],
+                    const double pc[3]) {
+    if (!s || !m || !pa || !pb || !pc) { set_error("rt_add_triangle: NULL argument"); return RT_ERR_ARG; }
+    return add_tri(*s, *m, from(pa), from(pb), from(pc));
+}
+
+// colorcuboid materials point l h d — Main.hs:301-320: six rectangles in the order
+// top, bottom, front, back, left(+x), right(-x), materials cycled over that order.
+int rt_add_cuboid(rt_scene *s, const rt_material *mats, int nmats, const double point[3],
+                  double l, double h, double d) {
+    if (!s || !mats || !point) { set_error("rt_add_cuboid: NULL argument"); return RT_ERR_ARG; }
+    if (nmats <= 0) { set_error("colorcuboid: list of materials must not be empty."); return RT_ERR_ARG; } // :302
+    const D3 p = from(point);
+    const double l2 = l / 2, h2 = h / 2, d2 = d / 2;
+    const int first = add_rect(*s, mats[0 % nmats], p + D3{0, h2, 0}, D3{l, 0, 0}, D3{0, 0, -d});
+    add_rect(*s, mats[1 % nmats], p - D3{0, h2, 0}, D3{l, 0, 0}, D3{0, 0, d});
+    add_rect(*s, mats[2 % nmats], p + D3{0, 0, d2}, D3{l, 0, 0}, D3{0, h, 0});
+    add_rect(*s, mats[3 % nmats], p - D3{0, 0, d2}, D3{l, 0, 0}, D3{0, -h, 0});
+    add_rect(*s, mats[4 % nmats], p + D3{l2, 0, 0}, D3{0, h, 0}, D3{0, 0, d});
+    add_rect(*s, mats[5 % nmats], p - D3{l2, 0, 0}, D3{0, h, 0}, D3{0, 0, -d});
+    return first;
+}
+
+// cylinder topM botM mantleM point n h r — Main.hs:725-774.  Leaves: n bottom triangles, n top
+// triangles, n mantle rectangles (`bot <> top <> mantle`).  Reproduced quirks: botPoint equals
+// topPoint (:735), mantle normals are lerped and not renormalised (:769-771).
+int rt_add_cylinder(rt_scene *s, const rt_material *top, const rt_material *bot,
+                    const rt_material *mantle, const double point[3], int n, double h, double r) {
+    if (!s || !top || !bot || !mantle || !point) { set_error("rt_add_cylinder: NULL argument"); return RT_ERR_ARG; }
+    if (n < 1) { set_error("rt_add_cylinder: n must be >= 1"); return RT_ERR_ARG; }
+    const D3 c = from(point);
+    const double nn = (double)n, alpha = 2 * M_PI / nn, h2 = h / 2;
+    std::vector<double> rx((size_t)n + 1), rz((size_t)n + 1);
+    for (int i = 0; i < n; ++i) { const double fi = (double)i; rx[i] = r * std::cos(fi * alpha); rz[i] = r * std::sin(fi * alpha); }
+    rx[n] = r; rz[n] = 0;                                                             // :729
+    const D3 topPoint = c + D3{0, h2, 0};                                             // :734
+    const D3 botPoint = c - D3{0, -h2, 0};                                            // :735 (sic)
+    const int first = (int)s->leaves.size();
+    for (int i = 0; i < n; ++i)                                                       // bot, :747-751
+        add_tri(*s, *bot, botPoint, c + D3{rx[i], -h2, rz[i]}, c + D3{rx[i + 1], -h2, rz[i + 1]});
+    for (int i = 0; i < n; ++i)                                                       // top, :742-746
+        add_tri(*s, *top, topPoint, c + D3{rx[i + 1], h2, rz[i + 1]}, c + D3{rx[i], h2, rz[i]});
+    for (int i = 0; i < n; ++i) {                                                     // mantle, :752-773
+        const D3 p1 = c + D3{rx[i], 0, rz[i]}, p2 = c + D3{rx[i + 1], 0, rz[i + 1]};
+        const D3 n1 = {rx[i] / r, 0, rz[i] / r}, n2 = {rx[i + 1] / r, 0, rz[i + 1] / r};
+        const D3 mid = scale(0.5, p1 + p2), dP = p1 - p2, dN = n1 - n2;
+        const int leaf = add_rect(*s, *mantle, mid, dP, D3{0, h, 0});
+        AuxD a{};
+        a.a[0] = n2.x; a.a[1] = n2.y; a.a[2] = n2.z;
+        a.a[3] = p2.x; a.a[4] = p2.y; a.a[5] = p2.z;
+        a.a[6] = dN.x / dP.x; a.a[7] = dN.y / dP.y; a.a[8] = dN.z / dP.z;             // :764
+        s->aux.push_back(a);
+        s->leaves[leaf].nmode = RT_NORMAL_MANTLE;
+        s->leaves[leaf].aux = (int)s->aux.size() - 1;
+    }
+    return first;
+}
+
+int rt_set_normal_mode(rt_scene *s, int first_leaf, int nleaves, int mode, const double *params, int nparams) {
+    if (!s || first_leaf < 0 || nleaves < 0 || (size_t)first_leaf + (size_t)nleaves > s->leaves.size()) {
+        set_error("rt_set_normal_mode: leaf range out of bounds"); return RT_ERR_ARG;
+    }
+    int aux = -1;
+    if (mode == RT_NORMAL_GAUSSIAN) {
+        if (!params || nparams != 4) { set_error("rt_set_normal_mode: gaussian mode takes {scaleInv, ox, oy, oz}"); return RT_ERR_ARG; }
+        AuxD a{};
+        for (int i = 0; i < 4; ++i) a.a[i] = params[i];
+        s->aux.push_back(a);
+        aux = (int)s->aux.size() - 1;
+    } else if (mode != RT_NORMAL_GEOMETRIC) {
+        set_error("rt_set_normal_mode: mode must be RT_NORMAL_GEOMETRIC or RT_NORMAL_GAUSSIAN"); return RT_ERR_ARG;
+    }
+    for (int i = first_leaf; i < first_leaf + nleaves; ++i) { s->leaves[i].nmode = mode; s->leaves[i].aux = aux; }
+    s->dirty = true;
+    return RT_OK;
+}
+
+int rt_add_point_light(rt_scene *s, double diffuse, double specular, const double pos[3]) {
+    if (!s || !pos) { set_error("rt_add_point_light: NULL argument"); return RT_ERR_ARG; }
+    LightD L{};
+    L.kind = 0; L.px = pos[0]; L.py = pos[1]; L.pz = pos[2];
+    L.diffuse = diffuse; L.specular = specular; L.rec_offset = -1;
+    s->lights.push_back(L);
+    s->npoint++;
+    s->dirty = true;
+    return (int)s->lights.size() - 1;
+}
+
+int rt_add_ambient(rt_scene *s, double f) {
+    if (!s) { set_error("rt_add_ambient: NULL scene"); return RT_ERR_ARG; }
+    LightD L{};
+    L.kind = 1; L.f = f; L.rec_offset = -1;
+    s->lights.push_back(L);
+    s->dirty = true;
+    return (int)s->lights.size() - 1;
+}
+
+int rt_scene_num_leaves(const rt_scene *s) { return s ? (int)s->leaves.size() : RT_ERR_ARG; }
+int rt_scene_num_lights(const rt_scene *s) { return s ? (int)s->lights.size() : RT_ERR_ARG; }
+
+int rt_scene_get_leaf(const rt_scene *s, int leaf, double out[20]) {
+    if (!s || !out || leaf < 0 || (size_t)leaf >= s->leaves.size()) { set_error("rt_scene_get_leaf: bad argument"); return RT_ERR_ARG; }
+    const LeafD &L = s->leaves[leaf];
+    const double v[20] = {(double)L.kind, (double)L.nmode, L.nx, L.ny, L.nz, L.d, L.p0x, L.p0y, L.p0z,
+                          L.e1x, L.e1y, L.e1z, L.e2x, L.e2y, L.e2z, L.c0, L.c1, L.c2, L.c3, (double)L.mat};
+    std::memcpy(out, v, sizeof v);
+    return RT_OK;
+}
+
+int rt_camera_params(int w, int h, double out[5]) {
+    if (!out || w <= 0 || h <= 0) { set_error("rt_camera_params: bad argument"); return RT_ERR_ARG; }
+    const CameraD c = fixed_camera(w, h);
+    out[0] = c.scaleX; out[1] = c.scaleY; out[2] = c.dX; out[3] = c.dY; out[4] = c.d;
+    return RT_OK;
+}
+
+// saveBmpImage path (ImageRGB8 img) — Main.hs:621.  24-bit, bottom-up, BGR, rows padded to 4 bytes.
+int rt_write_bmp(const char *path, const uint8_t *rgba, int w, int h) {
+    if (!path || !rgba || w <= 0 || h <= 0) { set_error("rt_write_bmp: bad argument"); return RT_ERR_ARG; }
+    FILE *f = std::fopen(path, "wb");
+    if (!f) { set_error(std::string("rt_write_bmp: cannot open ") + path); return RT_ERR_ARG; }
+    const uint32_t row = ((uint32_t)w * 3u + 3u) & ~3u, size = 54u + row * (uint32_t)h;
+    uint8_t hdr[54] = {'B', 'M'};
+    auto put32 = [&](int o, uint32_t v) { hdr[o] = v & 255; hdr[o + 1] = (v >> 8) & 255; hdr[o + 2] = (v >> 16) & 255; hdr[o + 3] = (v >> 24) & 255; };
+    put32(2, size); put32(10, 54); put32(14, 40); put32(18, (uint32_t)w); put32(22, (uint32_t)h);
+    hdr[26] = 1; hdr[28] = 24; put32(34, row * (uint32_t)h); put32(38, 2835); put32(42, 2835);
+    std::fwrite(hdr, 1, 54, f);
+    std::vector<uint8_t> line(row, 0);
+    for (int y = h - 1; y >= 0; --y) {
+        const uint8_t *src = rgba + (size_t)y * (size_t)w * 4;
+        for (int x = 0; x < w; ++x) { line[3 * x] = src[4 * x + 2]; line[3 * x + 1] = src[4 * x + 1]; line[3 * x + 2] = src[4 * x]; }
+        std::fwrite(line.data(), 1, row, f);
+    }
+    std::fclose(f);
+    return RT_OK;
+}
+
+} // extern "C"

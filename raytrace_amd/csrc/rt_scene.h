@@ -1,0 +1,62 @@
+// rt_scene.h — host-side scene: the reference's Shape/Light values reified as data.
+//
+// The reference builds `world :: Shape` as a tree of closures (Main.hs:189-217) and `lights ::
+// Light` as a sum of closures (Main.hs:423-441).  Here a scene is the flat list of leaves in the
+// tree's depth-first order (that order decides equal-distance hits, Main.hs:213-214), the list of
+// lights, and the per-(apex, leaf) FP32 filter records derived from them.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "../../include/raytrace_gpu.h"
+#include "rt_types.h"
+
+namespace rt {
+
+struct DeviceScene {          // device copies (HBM), owned by the scene
+    LeafD *leaves = nullptr;
+    AuxD *aux = nullptr;
+    MaterialD *mats = nullptr;
+    LightD *lights = nullptr;
+    FilterRec *tri_rec = nullptr;    // (1 + npoint) blocks of ntri records: eye, then each point light
+    FilterRec *rect_rec = nullptr;   // (1 + npoint) blocks of nrect records
+    int32_t *tri_gid = nullptr;      // per-type slot -> leaf index
+    int32_t *rect_gid = nullptr;
+    unsigned long long *counters = nullptr;  // 8 x u64
+    // work buffers, grown on demand
+    int32_t *hit_id = nullptr;  size_t hit_id_cap = 0;     // per band pixel
+    uint32_t *accum = nullptr;  size_t accum_cap = 0;      // spp > 1: 3 x u32 per pixel
+    uint8_t *rgba = nullptr;    size_t rgba_cap = 0;       // rt_render (host buffers) staging
+    int device = -1;
+};
+
+} // namespace rt
+
+struct rt_scene {
+    std::vector<rt::LeafD> leaves;
+    std::vector<rt::AuxD> aux;
+    std::vector<rt::MaterialD> mats;
+    std::vector<rt::LightD> lights;
+    std::vector<int32_t> tri_gid, rect_gid;
+    int npoint = 0;                       // number of point lights
+
+    // filter records, rebuilt when the camera (w, h) or the scene changes
+    std::vector<rt::FilterRec> tri_rec, rect_rec;
+    int rec_w = -1, rec_h = -1;
+    bool dirty = true;                    // host scene changed since the last upload
+    rt::DeviceScene dev;
+    rt_stats stats{};
+    void *ev[4] = {nullptr, nullptr, nullptr, nullptr};   // hipEvent_t: start, after primary, after shade
+    bool stats_pending = false;
+    uint64_t last_primary = 0;
+};
+
+namespace rt {
+
+void set_error(const std::string &msg);
+CameraD fixed_camera(int w, int h);                       // Main.hs:506-527
+double ray_eps();                                         // Main.hs:114
+// (Re)build the FP32 filter records for the eye of a w x h camera and for every point light.
+void build_filter_records(rt_scene &s, int w, int h);
+
+} // namespace rt

@@ -1,0 +1,54 @@
+// rt_types.h — data layout shared by the host scene builder and the gfx950 kernels.
+//
+// Two representations of every leaf live in HBM:
+//   * LeafD  — the exact one (IEEE double), with the constants the reference precomputes in its
+//              constructors (rectangle Main.hs:228-232, triangle Main.hs:365-372).  Only the few
+//              candidate (ray, leaf) pairs that survive the FP32 filter are evaluated on it, with
+//              the reference's own expression order, so hit IDs and colours agree bit for bit.
+//   * FilterRec — 12 floats per (apex, leaf): linear forms of the ray direction D from a common
+//              apex (the eye for primary rays, a light for shadow rays).  This is what the
+//              brute-force O(rays x leaves) loops read, as wave-uniform scalar operands.
+#pragma once
+#include <stdint.h>
+
+namespace rt {
+
+enum : int32_t { LEAF_RECT = 0, LEAF_TRI = 1 };
+
+struct LeafD {                 // 176 bytes
+    double nx, ny, nz, d;      // unit normal, plane offset (normal . p + d = 0)
+    double p0x, p0y, p0z;      // rect: point' (corner, Main.hs:231); tri: pa
+    double e1x, e1y, e1z;      // rect: width;  tri: u = pb - pa
+    double e2x, e2y, e2z;      // rect: height; tri: v = pc - pa
+    double c0, c1, c2, c3;     // rect: ww, hh, 0, 0;  tri: uv, uu, vv, n
+    int32_t kind;              // LEAF_RECT / LEAF_TRI
+    int32_t nmode;             // rt_normal_mode
+    int32_t mat;               // material index
+    int32_t aux;               // index into AuxD (mantle / gaussian parameters), -1 if none
+    int32_t slot;              // index of this leaf inside its per-type filter array
+    int32_t _pad;
+};
+
+struct AuxD { double a[10]; }; // mantle: n2 xyz, p2 xyz, dNdP xyz ; gaussian: scaleInv, offset xyz
+
+struct MaterialD {             // Main.hs:178-185
+    double specularity, reflectivity;
+    uint8_t diffuse[3], specular[3], _pad[2];
+};
+
+struct LightD {                // kind 0: pointLight (Main.hs:467), kind 1: ambient (Main.hs:490)
+    double px, py, pz;
+    double diffuse, specular, f;
+    int32_t kind;
+    int32_t rec_offset;        // index of this light's filter records block (point lights)
+};
+
+// 12 floats.  Triangle: U xyz, V xyz, N xyz, Kq, negm, 0.  Rectangle: A xyz, B xyz, N xyz, Kq, negm, 0.
+// (negm = -margin; Kq = K - mK + margin, so that the clip test N >= K - mK reads N - Kq >= negm)
+struct FilterRec { float c[12]; };
+
+struct CameraD {               // fixedCamera, Main.hs:506-527
+    double scaleX, scaleY, dX, dY, d;
+};
+
+} // namespace rt
