@@ -84,6 +84,20 @@ int  rt_add_cuboid(rt_scene *, const rt_material *mats, int nmats, const double 
 /* cylinder topM botM mantleM point n h r                                  Main.hs:725-774 */
 int  rt_add_cylinder(rt_scene *, const rt_material *top, const rt_material *bot,
                      const rt_material *mantle, const double point[3], int n, double h, double r);
+/* Tree structure: the reference's Shape is a tree of mappend nodes (Main.hs:205-216), and every
+ * mappend node guards its subtree with a bounding-box test (Main.hs:209, 152-174).  The boxes of
+ * rectangles whose two edge vectors share an axis plane are too small (Main.hs:243-245 takes only
+ * two opposite corners), so the guards clip such rectangles — visible in the reference's output and
+ * reproduced here.  Which box guards a leaf depends on the tree, so the tree is passed as brackets:
+ *   mconcat [a, b, c]   =  rt_begin_mconcat; a; b; c; rt_end_mconcat      (foldr mappend mempty)
+ *   a `mappend` b       =  rt_begin_mappend; a; b; rt_end_mappend         (exactly two children)
+ * where a, b, c are rt_add_* calls or nested brackets.  rt_add_cuboid and rt_add_cylinder emit their
+ * own inner structure.  Children added outside any bracket form an implicit top-level mconcat,
+ * unless there is exactly one, which then is the world itself. */
+int  rt_begin_mconcat(rt_scene *);
+int  rt_end_mconcat(rt_scene *);
+int  rt_begin_mappend(rt_scene *);
+int  rt_end_mappend(rt_scene *);
 /* the `normals` wrapper of linearInterpolation                            Main.hs:956-965 */
 int  rt_set_normal_mode(rt_scene *, int first_leaf, int nleaves, int mode,
                         const double *params, int nparams);

@@ -90,6 +90,27 @@ static int intersectBB(bbox b, const ray *r) {                                  
 #undef XZ
 }
 
+/* Is the outcome of intersectBB numerically fragile?  tol-widened and tol-narrowed versions of the
+ * six face tests disagree.  Only used for the ORC_FLAG_BBOX_EDGE diagnostic. */
+static int bb_face(double t, double a, double alo, double ahi, double c, double clo, double chi, double s) {
+    double ta = s * 1e-9 * (1 + fabs(a) + fabs(alo) + fabs(ahi)), tc = s * 1e-9 * (1 + fabs(c) + fabs(clo) + fabs(chi));
+    return t >= -s * 1e-9 * (1 + fabs(t)) && alo - ta <= a && a <= ahi + ta && clo - tc <= c && c <= chi + tc;
+}
+static int bb_any(bbox b, const ray *r, double s) {
+    const double px = r->pos.x, py = r->pos.y, pz = r->pos.z, dx = r->dir.x, dy = r->dir.y, dz = r->dir.z;
+    const double zs[2] = { b.lo.z, b.hi.z }, ys[2] = { b.lo.y, b.hi.y }, xs[2] = { b.lo.x, b.hi.x };
+    for (int k = 0; k < 2; ++k) {
+        double t = (zs[k] - pz) * r->recip.z;
+        if (bb_face(t, px + t * dx, b.lo.x, b.hi.x, py + t * dy, b.lo.y, b.hi.y, s)) return 1;
+        t = (ys[k] - py) * r->recip.y;
+        if (bb_face(t, px + t * dx, b.lo.x, b.hi.x, pz + t * dz, b.lo.z, b.hi.z, s)) return 1;
+        t = (xs[k] - px) * r->recip.x;
+        if (bb_face(t, py + t * dy, b.lo.y, b.hi.y, pz + t * dz, b.lo.z, b.hi.z, s)) return 1;
+    }
+    return 0;
+}
+static int bb_fragile(bbox b, const ray *r) { return bb_any(b, r, 1.0) != bb_any(b, r, -1.0); }
+
 /* ------------------------------------------------------------------------------------------ */
 /* Scene tree                                                                                  */
 
@@ -653,9 +674,24 @@ static int leaf_margin(const node *n, const ray *r, double *t_out, double *margi
     return 1;
 }
 
-static uint8_t analyze(const orc_scene *s, const int *leaves, int nleaves, const ray *r,
+static int guards_fragile(const orc_scene *s, int idx, const ray *r) {
+    const node *n = &s->nodes[idx];
+    switch (n->kind) {
+    case N_GAUSS: return guards_fragile(s, n->left, r);
+    case N_APPEND:
+        return bb_fragile(n->bb, r) || guards_fragile(s, n->left, r) || guards_fragile(s, n->right, r);
+    case N_LIST:
+        for (int k = 0; k < n->nkids; ++k)
+            if (bb_fragile(n->sfx[k], r) || guards_fragile(s, n->kids[k], r)) return 1;
+        return 0;
+    default: return 0;
+    }
+}
+
+static uint8_t analyze(const orc_scene *s, int root, const int *leaves, int nleaves, const ray *r,
                        int guarded_ok, int guarded_leaf) {
     uint8_t flags = 0;
+    if (guards_fragile(s, root, r)) flags |= ORC_FLAG_BBOX_EDGE;
     double t1 = INFINITY, t2 = INFINITY; int id1 = -1;
     for (int k = 0; k < nleaves; ++k) {
         hit h;
@@ -704,7 +740,7 @@ static void *render_rows(void *arg) {
                 if (sidx == 0) {
                     if (j->hit_id) j->hit_id[o] = ok ? h.leaf : -1;
                     if (j->hit_t) j->hit_t[o] = ok ? h.t : INFINITY;
-                    if (j->flags) j->flags[o] = analyze(j->s, j->leaves, j->nleaves, &r, ok, ok ? h.leaf : -1);
+                    if (j->flags) j->flags[o] = analyze(j->s, j->root, j->leaves, j->nleaves, &r, ok, ok ? h.leaf : -1);
                 }
             }
             unsigned n = (unsigned)j->spp;

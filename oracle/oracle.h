@@ -36,6 +36,8 @@ typedef struct {
 /* flags written by orc_render (one byte per pixel) */
 #define ORC_FLAG_TIE   1u  /* two accepted leaf hits (guards ignored) have |t1-t2| <= 1e-5          */
 #define ORC_FLAG_BBOX  2u  /* a bounding-box guard (Main.hs:209) changed the primary nearest hit   */
+#define ORC_FLAG_BBOX_EDGE 8u /* the outcome of some bounding-box guard hinges on a comparison that is
+                                within 1e-9 (relative) of equality: not reproducible across formulations */
 #define ORC_FLAG_EDGE  4u  /* an accept/reject predicate of a leaf at or in front of the hit is    */
                            /* within 1e-5 of its boundary                                           */
 

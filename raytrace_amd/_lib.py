@@ -1,0 +1,84 @@
+"""ctypes binding of libraytrace_gpu.so (the C ABI declared in include/raytrace_gpu.h).
+
+The product has no CPU fallback: if the shared library is missing this module raises at import of
+the symbols, and rendering without a HIP device returns RT_ERR_HIP (raised as RuntimeError).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libraytrace_gpu.so")
+
+
+class rt_material(C.Structure):
+    _fields_ = [("diffuse", C.c_uint8 * 3), ("specular", C.c_uint8 * 3), ("_pad", C.c_uint8 * 2),
+                ("specularity", C.c_double), ("reflectivity", C.c_double)]
+
+
+class rt_stats(C.Structure):
+    _fields_ = [("primary_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("tri_tests", C.c_uint64),
+                ("rect_tests", C.c_uint64), ("exact_evals", C.c_uint64), ("ms_primary", C.c_double),
+                ("ms_shade", C.c_double), ("ms_total", C.c_double)]
+
+
+# every symbol include/raytrace_gpu.h declares: name -> (restype, argtypes)
+_D3 = C.POINTER(C.c_double)
+_MAT = C.POINTER(rt_material)
+SYMBOLS = {
+    "rt_init": (C.c_int, [C.c_int]),
+    "rt_last_error": (C.c_char_p, []),
+    "rt_version": (C.c_char_p, []),
+    "rt_scene_create": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "rt_scene_destroy": (None, [C.c_void_p]),
+    "rt_add_rectangle": (C.c_int, [C.c_void_p, _MAT, _D3, _D3, _D3]),
+    "rt_add_triangle": (C.c_int, [C.c_void_p, _MAT, _D3, _D3, _D3]),
+    "rt_add_cuboid": (C.c_int, [C.c_void_p, _MAT, C.c_int, _D3, C.c_double, C.c_double, C.c_double]),
+    "rt_add_cylinder": (C.c_int, [C.c_void_p, _MAT, _MAT, _MAT, _D3, C.c_int, C.c_double, C.c_double]),
+    "rt_begin_mconcat": (C.c_int, [C.c_void_p]),
+    "rt_end_mconcat": (C.c_int, [C.c_void_p]),
+    "rt_begin_mappend": (C.c_int, [C.c_void_p]),
+    "rt_end_mappend": (C.c_int, [C.c_void_p]),
+    "rt_set_normal_mode": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, _D3, C.c_int]),
+    "rt_add_point_light": (C.c_int, [C.c_void_p, C.c_double, C.c_double, _D3]),
+    "rt_add_ambient": (C.c_int, [C.c_void_p, C.c_double]),
+    "rt_scene_num_leaves": (C.c_int, [C.c_void_p]),
+    "rt_scene_num_lights": (C.c_int, [C.c_void_p]),
+    "rt_scene_get_leaf": (C.c_int, [C.c_void_p, C.c_int, _D3]),
+    "rt_camera_params": (C.c_int, [C.c_int, C.c_int, _D3]),
+    "rt_render": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int,
+                            C.c_void_p, C.c_void_p]),
+    "rt_render_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int,
+                                   C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rt_synchronize": (C.c_int, []),
+    "rt_get_stats": (C.c_int, [C.c_void_p, C.POINTER(rt_stats)]),
+    "rt_write_bmp": (C.c_int, [C.c_char_p, C.c_void_p, C.c_int, C.c_int]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libraytrace_gpu.so (built by __graft_entry__.build() / raytrace_amd/csrc/Makefile)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`"
+                               " (there is no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc, what="raytrace_gpu"):
+    if rc < 0:
+        msg = lib().rt_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what} failed (rt_status {rc}): {msg}")
+    return rc
+
+
+def vec3(p):
+    return (C.c_double * 3)(float(p[0]), float(p[1]), float(p[2]))

@@ -1,0 +1,415 @@
+"""Host-side mirror of the reference's scene API (reference src/Main.hs), over the C ABI.
+
+The reference builds `world :: Shape` and `lights :: Light` from closures; here the same
+constructor names build plain data (a tree of shapes in the reference's mconcat/mappend order),
+and `parallelTrace` flattens it into the leaf list of libraytrace_gpu.so and renders on the GPU.
+Names, argument order and meaning follow the reference:
+
+    rectangle material point width height            Main.hs:226
+    triangle material pa pb pc                       Main.hs:363
+    cube / colorcube / cuboid / colorcuboid          Main.hs:286-320
+    cylinder topM botM mantleM point n h r           Main.hs:725
+    pointLight diffuse specular lpos, ambient f      Main.hs:467, 490   (world is bound at render time)
+    linearInterpolation f fnorm (x1,y1) (x2,y2) step origin scale        Main.hs:937
+    fixedCamera w h, trace depth lights world, parallelTrace w h camera tracer      Main.hs:506, 541, 623
+    saveBmpImage path image                          Main.hs:621
+"""
+import ctypes as C
+import math
+from dataclasses import dataclass, field
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+
+Vec = Tuple[float, float, float]
+
+
+# ---------------------------------------------------------------------------------------------
+# Materials and colours — Main.hs:178-185, 326-355
+
+@dataclass(frozen=True)
+class Material:
+    diffuse: Tuple[int, int, int]
+    specular: Tuple[int, int, int]
+    specularity: float = 1.0
+    reflectivity: float = 0.0
+
+    def replace(self, **kw):
+        d = dict(diffuse=self.diffuse, specular=self.specular, specularity=self.specularity,
+                 reflectivity=self.reflectivity)
+        d.update(kw)
+        return Material(**d)
+
+
+def _colour(rgb):
+    return Material(rgb, rgb, 1.0, 0.0)
+
+
+black = _colour((0, 0, 0))
+white = _colour((255, 255, 255))
+red = _colour((255, 0, 0))
+green = _colour((0, 255, 0))
+blue = _colour((0, 0, 255))
+magenta = _colour((255, 0, 255))
+cyan = _colour((0, 255, 255))
+yellow = _colour((255, 255, 0))
+orange = _colour((255, 134, 0))
+orchid = _colour((153, 50, 204))
+aquamarine = _colour((69, 139, 116))
+COLOURS = [black, white, red, green, blue, magenta, cyan, yellow, orange, orchid, aquamarine]
+
+
+# ---------------------------------------------------------------------------------------------
+# Shapes: a tree mirroring the reference's Monoid Shape (Main.hs:196-217)
+
+class Shape:
+    """Base class.  `a + b` is `a <> b` (mappend)."""
+
+    def __add__(self, other):
+        return MAppend(self, other)
+
+
+@dataclass
+class Empty(Shape):          # mempty, Main.hs:204
+    pass
+
+
+@dataclass
+class Rectangle(Shape):
+    material: Material
+    point: Vec
+    width: Vec
+    height: Vec
+
+
+@dataclass
+class Triangle(Shape):
+    material: Material
+    pa: Vec
+    pb: Vec
+    pc: Vec
+
+
+@dataclass
+class Cuboid(Shape):
+    materials: Sequence[Material]
+    point: Vec
+    l: float
+    h: float
+    d: float
+
+
+@dataclass
+class Cylinder(Shape):
+    top: Material
+    bot: Material
+    mantle: Material
+    point: Vec
+    n: int
+    h: float
+    r: float
+
+
+@dataclass
+class MAppend(Shape):
+    left: Shape
+    right: Shape
+
+
+@dataclass
+class MConcat(Shape):
+    children: List[Shape]
+
+
+@dataclass
+class GaussianNormals(Shape):
+    """linearInterpolation's `normals` wrapper with the gaussian fnorm of main (Main.hs:956-965, 580-584)."""
+    child: Shape
+    scale_inv: float
+    offset: Vec
+
+
+mempty = Empty()
+
+
+def mappend(a: Shape, b: Shape) -> Shape:
+    return MAppend(a, b)
+
+
+def mconcat(xs: Sequence[Shape]) -> Shape:
+    return MConcat(list(xs))
+
+
+def rectangle(material, point, width, height) -> Shape:
+    return Rectangle(material, tuple(point), tuple(width), tuple(height))
+
+
+def triangle(material, pa, pb, pc) -> Shape:
+    return Triangle(material, tuple(pa), tuple(pb), tuple(pc))
+
+
+def colorcuboid(materials, point, l, h, d) -> Shape:
+    if len(materials) == 0:
+        raise ValueError("colorcuboid: list of materials must not be empty.")   # Main.hs:302
+    return Cuboid(list(materials), tuple(point), l, h, d)
+
+
+def cuboid(material, point, l, h, d) -> Shape:
+    return colorcuboid([material], point, l, h, d)
+
+
+def colorcube(materials, point, l) -> Shape:
+    return colorcuboid(materials, point, l, l, l)
+
+
+def cube(material, point, l) -> Shape:
+    return colorcube([material], point, l)
+
+
+def cylinder(topM, botM, mantleM, point, n, h, r) -> Shape:
+    return Cylinder(topM, botM, mantleM, tuple(point), int(n), h, r)
+
+
+# ---------------------------------------------------------------------------------------------
+# Lights — Main.hs:423-492.  A Light value is a list of sources (`mconcat`); the world a point
+# light casts its shadow rays against is the world being traced.
+
+@dataclass
+class PointLight:
+    diffuse: float
+    specular: float
+    pos: Vec
+
+
+@dataclass
+class Ambient:
+    f: float
+
+
+def pointLight(diffuse, specular, lpos):
+    return [PointLight(diffuse, specular, tuple(lpos))]
+
+
+def ambient(f):
+    return [Ambient(f)]
+
+
+def mconcat_lights(ls):
+    out = []
+    for l in ls:
+        out.extend(l)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# linearInterpolation — Main.hs:937-988
+
+def gaussian(x, y):                      # Main.hs:580
+    return math.exp(-(x * x + y * y) * 4)
+
+
+GAUSSIAN_FNORM = "gaussian"              # Main.hs:581-584 (evaluated on the GPU)
+
+
+def _steps(a, b, step):                  # Main.hs:948
+    out = []
+    v = a
+    while v < b:
+        out.append(v)
+        v = v + step
+    return out
+
+
+def linearInterpolation(f: Callable[[float, float], float], fnorm, p1, p2, step, origin, scale):
+    """Returns (world, lights).  fnorm is None (geometric normals) or GAUSSIAN_FNORM."""
+    (x1, y1), (x2, y2) = p1, p2
+    x = (x2 + x1) / 2
+    y = (y2 + y1) / 2
+    w = x2 - x1
+    h = y2 - y1
+    scale_inv = 1.0 / scale
+    offset = tuple(o - scale * c for o, c in zip(origin, (x, 0, y)))           # :982
+    mat = white.replace(specularity=1)
+
+    def fp(a, b):                                                               # :981
+        fa = f(a, b)
+        return (offset[0] + scale * a, offset[1] + scale * fa, offset[2] + scale * b)
+
+    cells = []
+    for gx in _steps(x1, x2, step):
+        for gy in _steps(y1, y2, step):
+            xp, yp = gx + step, gy + step
+            two = mconcat([triangle(mat, fp(gx, yp), fp(xp, yp), fp(gx, gy)),
+                           triangle(mat, fp(gx, gy), fp(xp, yp), fp(xp, gy))])
+            if fnorm is None:
+                cells.append(two)
+            elif fnorm == GAUSSIAN_FNORM:
+                cells.append(GaussianNormals(two, scale_inv, offset))
+            else:
+                raise NotImplementedError("only the gaussian fnorm of main (Main.hs:581-584) is available on the GPU")
+    shape = mconcat([mconcat(cells),
+                     rectangle(aquamarine, origin, (1.5 * scale * w, 0, 0), (0, 0, -(1.5 * scale * h)))])
+    light = mconcat_lights([
+        pointLight(0.3, 0.6, (origin[0] + scale * w / 4, origin[1] + scale * 10, origin[2] + scale * w / 4)),
+        ambient(0.3)])
+    return shape, light
+
+
+# ---------------------------------------------------------------------------------------------
+# Scene: the flat leaf list behind the C ABI
+
+def _cmat(m: Material):
+    cm = _lib.rt_material()
+    for i in range(3):
+        cm.diffuse[i] = m.diffuse[i]
+        cm.specular[i] = m.specular[i]
+    cm.specularity = float(m.specularity)
+    cm.reflectivity = float(m.reflectivity)
+    return cm
+
+
+class Scene:
+    """Owns an rt_scene.  Built from (world, lights) in the reference's depth-first leaf order."""
+
+    def __init__(self, world: Shape, lights):
+        self._L = _lib.lib()
+        h = C.c_void_p()
+        _lib.check(self._L.rt_scene_create(C.byref(h)), "rt_scene_create")
+        self._h = h
+        self._add(world)
+        for l in lights:
+            if isinstance(l, PointLight):
+                _lib.check(self._L.rt_add_point_light(self._h, l.diffuse, l.specular, _lib.vec3(l.pos)))
+            elif isinstance(l, Ambient):
+                _lib.check(self._L.rt_add_ambient(self._h, l.f))
+            else:
+                raise TypeError(f"not a light: {l!r}")
+
+    def _add(self, s: Shape):
+        L, h = self._L, self._h
+        if isinstance(s, Empty):                 # mempty = mconcat []
+            _lib.check(L.rt_begin_mconcat(h))
+            _lib.check(L.rt_end_mconcat(h))
+            return
+        if isinstance(s, Rectangle):
+            _lib.check(L.rt_add_rectangle(h, C.byref(_cmat(s.material)), _lib.vec3(s.point), _lib.vec3(s.width), _lib.vec3(s.height)))
+        elif isinstance(s, Triangle):
+            _lib.check(L.rt_add_triangle(h, C.byref(_cmat(s.material)), _lib.vec3(s.pa), _lib.vec3(s.pb), _lib.vec3(s.pc)))
+        elif isinstance(s, Cuboid):
+            arr = (_lib.rt_material * len(s.materials))(*[_cmat(m) for m in s.materials])
+            _lib.check(L.rt_add_cuboid(h, arr, len(s.materials), _lib.vec3(s.point), s.l, s.h, s.d))
+        elif isinstance(s, Cylinder):
+            _lib.check(L.rt_add_cylinder(h, C.byref(_cmat(s.top)), C.byref(_cmat(s.bot)), C.byref(_cmat(s.mantle)),
+                                         _lib.vec3(s.point), s.n, s.h, s.r))
+        elif isinstance(s, MAppend):
+            _lib.check(L.rt_begin_mappend(h))
+            self._add(s.left)
+            self._add(s.right)
+            _lib.check(L.rt_end_mappend(h))
+        elif isinstance(s, MConcat):
+            _lib.check(L.rt_begin_mconcat(h))
+            for c in s.children:
+                self._add(c)
+            _lib.check(L.rt_end_mconcat(h))
+        elif isinstance(s, GaussianNormals):
+            first = L.rt_scene_num_leaves(h)
+            self._add(s.child)
+            n = L.rt_scene_num_leaves(h) - first
+            params = (C.c_double * 4)(s.scale_inv, *s.offset)
+            _lib.check(L.rt_set_normal_mode(h, first, n, 2, params, 4))
+        else:
+            raise TypeError(f"not a shape: {s!r}")
+
+    @property
+    def handle(self):
+        return self._h
+
+    @property
+    def num_leaves(self):
+        return self._L.rt_scene_num_leaves(self._h)
+
+    def leaf(self, i):
+        out = (C.c_double * 20)()
+        _lib.check(self._L.rt_scene_get_leaf(self._h, i, out))
+        return list(out)
+
+    def render(self, w, h, depth=4, spp=1, seed=0, row0=0, nrows=None, want_rgba=True, want_hit=True):
+        """Host-buffer render (rt_render).  Returns (rgba[nrows,w,4] uint8, hit_id[nrows,w] int32)."""
+        nrows = h - row0 if nrows is None else nrows
+        rgba = np.empty((nrows, w, 4), np.uint8) if want_rgba else None
+        hit = np.empty((nrows, w), np.int32) if want_hit else None
+        _lib.check(self._L.rt_render(self._h, w, h, depth, spp, seed, row0, nrows,
+                                     rgba.ctypes.data if want_rgba else None,
+                                     hit.ctypes.data if want_hit else None), "rt_render")
+        return rgba, hit
+
+    def render_device(self, w, h, d_rgba, d_hit, depth=4, spp=1, seed=0, row0=0, nrows=None, stream=None):
+        """Device-buffer render (rt_render_device); d_rgba/d_hit are device addresses (int) or None."""
+        nrows = h - row0 if nrows is None else nrows
+        _lib.check(self._L.rt_render_device(self._h, w, h, depth, spp, seed, row0, nrows, d_rgba, d_hit, stream),
+                   "rt_render_device")
+
+    def stats(self):
+        st = _lib.rt_stats()
+        _lib.check(self._L.rt_get_stats(self._h, C.byref(st)))
+        return {k: getattr(st, k) for k, _ in st._fields_}
+
+    def close(self):
+        if self._h:
+            self._L.rt_scene_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ---------------------------------------------------------------------------------------------
+# Camera / trace / parallelTrace / saveBmpImage
+
+@dataclass
+class Camera:
+    width: int
+    height: int
+
+
+def fixedCamera(width, height):                 # Main.hs:506
+    return Camera(width, height)
+
+
+@dataclass
+class Tracer:
+    """`trace depth lights world` partially applied (Main.hs:541, 571)."""
+    depth: int
+    lights: list
+    world: Shape
+    _scene: Optional[Scene] = field(default=None, repr=False)
+
+    def scene(self):
+        if self._scene is None:
+            self._scene = Scene(self.world, self.lights)
+        return self._scene
+
+
+def trace(depth, lights, world):
+    return Tracer(depth, lights, world)
+
+
+def parallelTrace(w, h, camera: Camera, tracer: Tracer):
+    """Main.hs:623-637: the whole h x w image at once, on the GPU.  Returns uint8 [h, w, 3]."""
+    if (camera.width, camera.height) != (w, h):
+        raise ValueError("parallelTrace: camera and image size differ")
+    rgba, _ = tracer.scene().render(w, h, depth=tracer.depth, want_hit=False)
+    return rgba[:, :, :3].copy()
+
+
+def saveBmpImage(path, image):                  # Main.hs:621
+    img = np.ascontiguousarray(image, dtype=np.uint8)
+    h, w = img.shape[:2]
+    if img.shape[2] == 3:
+        img = np.concatenate([img, np.full((h, w, 1), 255, np.uint8)], axis=2)
+    _lib.check(_lib.lib().rt_write_bmp(str(path).encode(), img.ctypes.data, w, h), "rt_write_bmp")

@@ -38,6 +38,7 @@ namespace {
 struct RenderParams {
     const LeafD *leaves;
     const AuxD *aux;
+    const GuardD *guards;
     const MaterialD *mats;
     const LightD *lights;
     const FilterRec *tri_rec;
@@ -60,16 +61,16 @@ struct RenderParams {
 // ------------------------------------------------------------------------------------------
 // Exact path (IEEE double, reference expression order)
 
-struct RayD { double px, py, pz, dx, dy, dz, rz; };
+struct RayD { double px, py, pz, dx, dy, dz, rx, ry, rz; };
 
 __device__ __forceinline__ double clampd(double d, double eps) { return fabs(d) <= eps ? eps : d; } // Main.hs:112
 
-// mkray position direction — Main.hs:107-115 (only recip.z is ever read by plane leaves, :122-126)
+// mkray position direction — Main.hs:107-115
 __device__ __forceinline__ RayD mkray(double px, double py, double pz, double dx, double dy, double dz, double eps) {
     RayD r;
     r.px = px; r.py = py; r.pz = pz;
     r.dx = clampd(dx, eps); r.dy = clampd(dy, eps); r.dz = clampd(dz, eps);
-    r.rz = 1.0 / r.dz;
+    r.rx = 1.0 / r.dx; r.ry = 1.0 / r.dy; r.rz = 1.0 / r.dz;
     return r;
 }
 
@@ -128,6 +129,29 @@ __device__ __forceinline__ bool leaf_isect(const LeafD &L, const RayD &r, double
         const double ss = (L.c0 * wu - L.c1 * wv) / L.c3;                              // :380
         return rr >= 0 && ss >= 0 && rr + ss <= 1;                                     // :382
     }
+}
+
+// intersectBB — Main.hs:152-174 — for every mappend node above the leaf (Main.hs:209)
+__device__ __forceinline__ bool guards_ok(const GuardD *__restrict__ G, int g, const RayD &r) {
+    while (g >= 0) {
+        const GuardD B = G[g];
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            double t = ((k ? B.z1 : B.z0) - r.pz) * r.rz;
+            double a = r.px + t * r.dx, c = r.py + t * r.dy;
+            any |= t >= 0 && B.x0 <= a && a <= B.x1 && B.y0 <= c && c <= B.y1;          // isectXY
+            t = ((k ? B.y1 : B.y0) - r.py) * r.ry;
+            a = r.px + t * r.dx; c = r.pz + t * r.dz;
+            any |= t >= 0 && B.x0 <= a && a <= B.x1 && B.z0 <= c && c <= B.z1;          // isectXZ
+            t = ((k ? B.x1 : B.x0) - r.px) * r.rx;
+            a = r.py + t * r.dy; c = r.pz + t * r.dz;
+            any |= t >= 0 && B.y0 <= a && a <= B.y1 && B.z0 <= c && c <= B.z1;          // isectYZ
+        }
+        if (!any) return false;
+        g = B.parent;
+    }
+    return true;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -201,7 +225,7 @@ __device__ __forceinline__ void primary_loop(const RenderParams &P, const Filter
                     const RayD ray = camera_ray(P, xr, y);
                     double ix, iy, iz, t;
                     ++nexact;
-                    if (leaf_isect<KIND>(L, ray, ix, iy, iz, t)) {
+                    if (leaf_isect<KIND>(L, ray, ix, iy, iz, t) && guards_ok(P.guards, L.guard, ray)) {
                         // nearest wins; equal t -> the left-most leaf of the tree (Main.hs:213-214)
                         if (t < bt[r] || (t == bt[r] && gid < bid[r]) || bid[r] < 0) { bt[r] = t; bid[r] = gid; }
                     }
@@ -286,7 +310,7 @@ __device__ __forceinline__ void shadow_loop(const RenderParams &P, const FilterR
                                            tx, ty, tz, P.eps);                         // :472
                     double ix, iy, iz, t;
                     ++nexact;
-                    if (leaf_isect<KIND>(L, ray, ix, iy, iz, t)) {
+                    if (leaf_isect<KIND>(L, ray, ix, iy, iz, t) && guards_ok(P.guards, L.guard, ray)) {
                         const double tl = (Lt.pz - ray.pz) * ray.rz;                   // rayDistance ray lpos
                         if (t <= tl) need[r] = false;                                  // :474 -> black
                     }
@@ -484,9 +508,11 @@ int prepare(rt_scene &s, int w, int h) {
     if (s.dirty || s.rec_w != w || s.rec_h != h || s.dev.device != g_device) {
         for (const MaterialD &m : s.mats)
             if (m.reflectivity > 0) { /* handled by caller: depth check */ }
+        if (!compute_guards(s)) return RT_ERR_ARG;
         build_filter_records(s, w, h);
         if ((rc = upload(s.dev.leaves, s.leaves))) return rc;
         if ((rc = upload(s.dev.aux, s.aux))) return rc;
+        if ((rc = upload(s.dev.guards, s.guards))) return rc;
         if ((rc = upload(s.dev.mats, s.mats))) return rc;
         if ((rc = upload(s.dev.lights, s.lights))) return rc;
         if ((rc = upload(s.dev.tri_rec, s.tri_rec))) return rc;
@@ -523,7 +549,7 @@ int rt_init(int device) {
 void rt_scene_destroy(rt_scene *s) {
     if (!s) return;
     DeviceScene &d = s->dev;
-    void *ptrs[] = {d.leaves, d.aux, d.mats, d.lights, d.tri_rec, d.rect_rec, d.tri_gid, d.rect_gid,
+    void *ptrs[] = {d.leaves, d.aux, d.guards, d.mats, d.lights, d.tri_rec, d.rect_rec, d.tri_gid, d.rect_gid,
                     d.counters, d.hit_id, d.accum, d.rgba};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (void *e : s->ev) if (e) (void)hipEventDestroy((hipEvent_t)e);
@@ -562,7 +588,7 @@ int rt_render_device(rt_scene *s, int w, int h, int depth, int spp, uint64_t see
     HIP_TRY(hipMemsetAsync(s->dev.counters, 0, 8 * sizeof(unsigned long long), st));
 
     RenderParams P{};
-    P.leaves = s->dev.leaves; P.aux = s->dev.aux; P.mats = s->dev.mats; P.lights = s->dev.lights;
+    P.leaves = s->dev.leaves; P.aux = s->dev.aux; P.guards = s->dev.guards; P.mats = s->dev.mats; P.lights = s->dev.lights;
     P.tri_rec = s->dev.tri_rec; P.rect_rec = s->dev.rect_rec;
     P.tri_gid = s->dev.tri_gid; P.rect_gid = s->dev.rect_gid;
     P.counters = s->dev.counters;

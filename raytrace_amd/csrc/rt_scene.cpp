@@ -50,7 +50,33 @@ static int add_material(rt_scene &s, const rt_material &m) {
     return (int)s.mats.size() - 1;
 }
 
-static int push_leaf(rt_scene &s, LeafD &L) {
+static inline double hmin(double x, double y) { return x <= y ? x : y; }   // Haskell min / max on Double
+static inline double hmax(double x, double y) { return x <= y ? y : x; }
+
+static void attach(rt_scene &s, int node) {
+    if (s.open.empty()) s.top.push_back(node);
+    else s.nodes[s.open.back()].kids.push_back(node);
+}
+static int open_group(rt_scene &s, int kind) {
+    s.nodes.push_back(GNode{kind, -1, {}});
+    const int id = (int)s.nodes.size() - 1;
+    attach(s, id);
+    s.open.push_back(id);
+    s.dirty = true;
+    return RT_OK;
+}
+static int close_group(rt_scene &s, int kind, const char *who) {
+    if (s.open.empty() || s.nodes[s.open.back()].kind != kind) { set_error(std::string(who) + ": no matching open bracket"); return RT_ERR_ARG; }
+    if (kind == 2 && s.nodes[s.open.back()].kids.size() != 2) { set_error(std::string(who) + ": mappend takes exactly two children"); return RT_ERR_ARG; }
+    s.open.pop_back();
+    return RT_OK;
+}
+
+static int push_leaf(rt_scene &s, LeafD &L, const Box &bb) {
+    s.leaf_bb.push_back(bb);
+    s.nodes.push_back(GNode{0, (int)s.leaves.size(), {}});
+    attach(s, (int)s.nodes.size() - 1);
+    L.guard = 0;
     L.aux = -1;
     L.nmode = RT_NORMAL_GEOMETRIC;
     if (L.kind == LEAF_TRI) { L.slot = (int)s.tri_gid.size(); s.tri_gid.push_back((int)s.leaves.size()); }
@@ -74,7 +100,10 @@ static int add_rect(rt_scene &s, const rt_material &m, D3 point, D3 width, D3 he
     L.e2x = height.x; L.e2y = height.y; L.e2z = height.z;
     L.c0 = dot3(width, width);
     L.c1 = dot3(height, height);
-    return push_leaf(s, L);
+    const D3 far = (corner + width) + height;                                         // Main.hs:244
+    Box bb = {{hmin(corner.x, far.x), hmin(corner.y, far.y), hmin(corner.z, far.z)},   // :245 (two corners only)
+              {hmax(corner.x, far.x), hmax(corner.y, far.y), hmax(corner.z, far.z)}};
+    return push_leaf(s, L, bb);
 }
 
 // triangle material pa pb pc — Main.hs:363-372
@@ -92,7 +121,9 @@ static int add_tri(rt_scene &s, const rt_material &m, D3 pa, D3 pb, D3 pc) {
     L.e2x = v.x; L.e2y = v.y; L.e2z = v.z;
     L.c0 = uv; L.c1 = uu; L.c2 = vv;
     L.c3 = uv * uv - uu * vv;
-    return push_leaf(s, L);
+    Box bb = {{hmin(pa.x, hmin(pb.x, pc.x)), hmin(pa.y, hmin(pb.y, pc.y)), hmin(pa.z, hmin(pb.z, pc.z))},   // :384
+              {hmax(pa.x, hmax(pb.x, pc.x)), hmax(pa.y, hmax(pb.y, pc.y)), hmax(pa.z, hmax(pb.z, pc.z))}};
+    return push_leaf(s, L, bb);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -168,6 +199,69 @@ static FilterRec make_rec(const LeafD &L, const double A[3], const double dmax[3
     r.c[11] = 0.0f;
     for (int i = 0; i < 11; ++i) if (!std::isfinite(r.c[i])) return always_rec();   // FP32 overflow
     return r;
+}
+
+// ------------------------------------------------------------------------------------------
+// Guard boxes.  Monoid BoundingBox (Main.hs:142-150): MkBB 0 0 is the identity.  Every mappend node on
+// the path from the root to a leaf tests its box (Main.hs:209); the distinct boxes of that path form
+// the leaf's guard chain.
+static const Box BOX_EMPTY = {{0, 0, 0}, {0, 0, 0}};
+static bool box_is_empty(const Box &b) {
+    for (int i = 0; i < 3; ++i) if (b.lo[i] != 0 || b.hi[i] != 0) return false;
+    return true;
+}
+static Box box_append(const Box &a, const Box &b) {
+    if (box_is_empty(a)) return b;
+    if (box_is_empty(b)) return a;
+    Box r;
+    for (int i = 0; i < 3; ++i) { r.lo[i] = hmin(a.lo[i], b.lo[i]); r.hi[i] = hmax(a.hi[i], b.hi[i]); }
+    return r;
+}
+static Box node_box(const rt_scene &s, int id) {
+    const GNode &n = s.nodes[id];
+    if (n.kind == 0) return s.leaf_bb[n.leaf];
+    if (n.kind == 2) return box_append(node_box(s, n.kids[0]), node_box(s, n.kids[1]));
+    Box acc = BOX_EMPTY;                                   // foldr mappend mempty
+    for (size_t k = n.kids.size(); k-- > 0;) acc = box_append(node_box(s, n.kids[k]), acc);
+    return acc;
+}
+static bool box_eq(const Box &a, const GuardD &g) {
+    return a.lo[0] == g.x0 && a.lo[1] == g.y0 && a.lo[2] == g.z0 && a.hi[0] == g.x1 && a.hi[1] == g.y1 && a.hi[2] == g.z1;
+}
+// A new link of the guard chain below `parent`; an identical box directly above is reused (the
+// test is a pure function of box and ray, so evaluating it once is exact).
+static int new_guard(rt_scene &s, const Box &b, int parent) {
+    if (parent >= 0 && box_eq(b, s.guards[parent])) return parent;
+    s.guards.push_back(GuardD{b.lo[0], b.lo[1], b.lo[2], b.hi[0], b.hi[1], b.hi[2], parent, 0});
+    return (int)s.guards.size() - 1;
+}
+static void assign_guards(rt_scene &s, int id, int parent) {
+    const GNode &n = s.nodes[id];
+    if (n.kind == 0) { s.leaves[n.leaf].guard = parent; return; }
+    if (n.kind == 2) {                                      // shape1 <> shape2: bb = bb1 <> bb2, Main.hs:215
+        const int g = new_guard(s, node_box(s, id), parent);
+        assign_guards(s, n.kids[0], g);
+        assign_guards(s, n.kids[1], g);
+        return;
+    }
+    // mconcat: x_0 <> (x_1 <> ( ... (x_n-1 <> mempty))): child k sits below the nodes of suffixes 0..k
+    std::vector<Box> sfx(n.kids.size() + 1, BOX_EMPTY);
+    for (size_t k = n.kids.size(); k-- > 0;) sfx[k] = box_append(node_box(s, n.kids[k]), sfx[k + 1]);
+    int cur = parent;
+    for (size_t k = 0; k < n.kids.size(); ++k) {
+        cur = new_guard(s, sfx[k], cur);
+        assign_guards(s, n.kids[k], cur);
+    }
+}
+bool compute_guards(rt_scene &s) {
+    if (!s.open.empty()) { set_error("rt_render: an rt_begin_mconcat/rt_begin_mappend bracket is still open"); return false; }
+    s.guards.clear();
+    if (s.top.empty()) return true;
+    if (s.top.size() == 1) { assign_guards(s, s.top[0], -1); return true; }
+    s.nodes.push_back(GNode{1, -1, s.top});                // implicit top-level mconcat
+    assign_guards(s, (int)s.nodes.size() - 1, -1);
+    s.nodes.pop_back();
+    return true;
 }
 
 void build_filter_records(rt_scene &s, int w, int h) {
@@ -255,12 +349,14 @@ int rt_add_cuboid(rt_scene *s, const rt_material *mats, int nmats, const double 
     if (nmats <= 0) { set_error("colorcuboid: list of materials must not be empty."); return RT_ERR_ARG; } // :302
     const D3 p = from(point);
     const double l2 = l / 2, h2 = h / 2, d2 = d / 2;
+    open_group(*s, 1);                                                                // mconcat [...], :308
     const int first = add_rect(*s, mats[0 % nmats], p + D3{0, h2, 0}, D3{l, 0, 0}, D3{0, 0, -d});
     add_rect(*s, mats[1 % nmats], p - D3{0, h2, 0}, D3{l, 0, 0}, D3{0, 0, d});
     add_rect(*s, mats[2 % nmats], p + D3{0, 0, d2}, D3{l, 0, 0}, D3{0, h, 0});
     add_rect(*s, mats[3 % nmats], p - D3{0, 0, d2}, D3{l, 0, 0}, D3{0, -h, 0});
     add_rect(*s, mats[4 % nmats], p + D3{l2, 0, 0}, D3{0, h, 0}, D3{0, 0, d});
     add_rect(*s, mats[5 % nmats], p - D3{l2, 0, 0}, D3{0, h, 0}, D3{0, 0, -d});
+    close_group(*s, 1, "rt_add_cuboid");
     return first;
 }
 
@@ -279,10 +375,17 @@ int rt_add_cylinder(rt_scene *s, const rt_material *top, const rt_material *bot,
     const D3 topPoint = c + D3{0, h2, 0};                                             // :734
     const D3 botPoint = c - D3{0, -h2, 0};                                            // :735 (sic)
     const int first = (int)s->leaves.size();
+    open_group(*s, 2); open_group(*s, 2);                                             // (bot <> top) <> mantle, :774
+    open_group(*s, 1);
     for (int i = 0; i < n; ++i)                                                       // bot, :747-751
         add_tri(*s, *bot, botPoint, c + D3{rx[i], -h2, rz[i]}, c + D3{rx[i + 1], -h2, rz[i + 1]});
+    close_group(*s, 1, "rt_add_cylinder");
+    open_group(*s, 1);
     for (int i = 0; i < n; ++i)                                                       // top, :742-746
         add_tri(*s, *top, topPoint, c + D3{rx[i + 1], h2, rz[i + 1]}, c + D3{rx[i], h2, rz[i]});
+    close_group(*s, 1, "rt_add_cylinder");
+    close_group(*s, 2, "rt_add_cylinder");
+    open_group(*s, 1);
     for (int i = 0; i < n; ++i) {                                                     // mantle, :752-773
         const D3 p1 = c + D3{rx[i], 0, rz[i]}, p2 = c + D3{rx[i + 1], 0, rz[i + 1]};
         const D3 n1 = {rx[i] / r, 0, rz[i] / r}, n2 = {rx[i + 1] / r, 0, rz[i + 1] / r};
@@ -296,8 +399,15 @@ int rt_add_cylinder(rt_scene *s, const rt_material *top, const rt_material *bot,
         s->leaves[leaf].nmode = RT_NORMAL_MANTLE;
         s->leaves[leaf].aux = (int)s->aux.size() - 1;
     }
+    close_group(*s, 1, "rt_add_cylinder");
+    close_group(*s, 2, "rt_add_cylinder");
     return first;
 }
+
+int rt_begin_mconcat(rt_scene *s) { if (!s) { set_error("rt_begin_mconcat: NULL scene"); return RT_ERR_ARG; } return open_group(*s, 1); }
+int rt_end_mconcat(rt_scene *s) { if (!s) { set_error("rt_end_mconcat: NULL scene"); return RT_ERR_ARG; } return close_group(*s, 1, "rt_end_mconcat"); }
+int rt_begin_mappend(rt_scene *s) { if (!s) { set_error("rt_begin_mappend: NULL scene"); return RT_ERR_ARG; } return open_group(*s, 2); }
+int rt_end_mappend(rt_scene *s) { if (!s) { set_error("rt_end_mappend: NULL scene"); return RT_ERR_ARG; } return close_group(*s, 2, "rt_end_mappend"); }
 
 int rt_set_normal_mode(rt_scene *s, int first_leaf, int nleaves, int mode, const double *params, int nparams) {
     if (!s || first_leaf < 0 || nleaves < 0 || (size_t)first_leaf + (size_t)nleaves > s->leaves.size()) {

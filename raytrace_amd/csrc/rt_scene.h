@@ -16,6 +16,7 @@ namespace rt {
 struct DeviceScene {          // device copies (HBM), owned by the scene
     LeafD *leaves = nullptr;
     AuxD *aux = nullptr;
+    GuardD *guards = nullptr;
     MaterialD *mats = nullptr;
     LightD *lights = nullptr;
     FilterRec *tri_rec = nullptr;    // (1 + npoint) blocks of ntri records: eye, then each point light
@@ -32,9 +33,19 @@ struct DeviceScene {          // device copies (HBM), owned by the scene
 
 } // namespace rt
 
+namespace rt {
+struct Box { double lo[3], hi[3]; };                     // BoundingBox, Main.hs:134-139
+struct GNode { int kind; int leaf; std::vector<int> kids; };   // kind: 0 leaf, 1 mconcat, 2 mappend
+}
+
 struct rt_scene {
     std::vector<rt::LeafD> leaves;
+    std::vector<rt::Box> leaf_bb;         // boundingBox of every leaf (Main.hs:243-245, 384)
+    std::vector<rt::GNode> nodes;         // the mappend/mconcat tree
+    std::vector<int> open;                // stack of open brackets (node indices)
+    std::vector<int> top;                 // children outside any bracket
     std::vector<rt::AuxD> aux;
+    std::vector<rt::GuardD> guards;       // guard-box chains, rebuilt by compute_guards
     std::vector<rt::MaterialD> mats;
     std::vector<rt::LightD> lights;
     std::vector<int32_t> tri_gid, rect_gid;
@@ -58,5 +69,7 @@ CameraD fixed_camera(int w, int h);                       // Main.hs:506-527
 double ray_eps();                                         // Main.hs:114
 // (Re)build the FP32 filter records for the eye of a w x h camera and for every point light.
 void build_filter_records(rt_scene &s, int w, int h);
+// Compute every leaf's guard box from the bracket tree; false (and set_error) on an open bracket.
+bool compute_guards(rt_scene &s);
 
 } // namespace rt

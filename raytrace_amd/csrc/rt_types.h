@@ -26,6 +26,15 @@ struct LeafD {                 // 176 bytes
     int32_t mat;               // material index
     int32_t aux;               // index into AuxD (mantle / gaussian parameters), -1 if none
     int32_t slot;              // index of this leaf inside its per-type filter array
+    int32_t guard;             // innermost GuardD above this leaf (-1: none); a hit counts only if the ray
+                               // meets every box on the chain guard -> parent -> ... (Main.hs:209)
+};
+
+// Bounding box of one mappend node of the reference's Shape tree (Main.hs:215) and the next
+// different box further up.  Runs of equal boxes along a path are stored once.
+struct GuardD {
+    double x0, y0, z0, x1, y1, z1;
+    int32_t parent;            // -1 at the root
     int32_t _pad;
 };
 

@@ -1,0 +1,173 @@
+"""Scenes: the reference's demo scenes re-expressed through the mirrored API (scene DATA only),
+and the synthetic benchmark scenes of BASELINE.json / SURVEY.md §8(d).
+
+Every function returns (world, lights).  Scenes for which the reference's `main` gives no lights use
+the commented-out light set of Main.hs:607-609.
+"""
+import numpy as np
+
+from .api import (GAUSSIAN_FNORM, COLOURS, ambient, aquamarine, black, blue, colorcube, colorcuboid, cube, cyan,
+                  cylinder, gaussian, green, linearInterpolation, magenta, mconcat, mconcat_lights, orange, orchid,
+                  pointLight, rectangle, red, triangle, white, yellow)
+
+
+def main_lights():                                   # Main.hs:607-609
+    return mconcat_lights([pointLight(0.03, 0.2, (2, 0, 0)), pointLight(0.3, 1.0, (0, 4, -10)), ambient(0.2)])
+
+
+def default_scene():                                 # Main.hs:578-585: gaussian height field
+    return linearInterpolation(gaussian, GAUSSIAN_FNORM, (-1.0, -1.0), (1.0, 1.0), 0.2, (0.01, -7, -25), 10)
+
+
+def planes():                                        # Main.hs:639-642
+    return mconcat([
+        rectangle(red, (-0.5, -0.5, -2), (1, 0, 0), (0, 1, 0)),
+        rectangle(blue, (-1, -0.5, -1.5), (0, 1, 0), (0, 0, 1)),
+        rectangle(green, (-0.5, -1, -1.5), (1, 0, 0), (0, 0, -1))]), main_lights()
+
+
+def axes_shape():                                    # Main.hs:644-658
+    c = (-0.5, -0.5, -1)
+
+    def at(dx, dy, dz):
+        return (c[0] + dx, c[1] + dy, c[2] + dz)
+    return mconcat([
+        rectangle(red, c, (1, 0, 0), (0, 0.1, 0)),
+        rectangle(blue, c, (0, 1, 0), (0, 0, 0.1)),
+        rectangle(green, c, (0.1, 0, 0), (0, 0, -1)),
+        triangle(red, at(0.6, 0, 0), at(0.5, 0.05, 0), at(0.5, -0.05, 0)),
+        triangle(blue, at(0, 0.6, 0), at(0, 0.5, 0.05), at(0, 0.5, -0.05)),
+        triangle(green, at(0, 0, 0.6), at(0.05, 0, 0.5), at(-0.05, 0, 0.5))])
+
+
+def axes():
+    return axes_shape(), main_lights()
+
+
+def cubes():                                         # Main.hs:661-668
+    colors = [red, green, blue, magenta, cyan, aquamarine, yellow, orange, orchid]
+    return mconcat([colorcube(colors, p, 1) for p in
+                    [(-2, 0, -6), (0, -2, -6), (2, 0, -6), (0, 2, -6), (0, 0, -6)]]), main_lights()
+
+
+def stacked_cubes():                                 # Main.hs:692-709
+    colors = [red, green, yellow]
+    return mconcat([
+        rectangle(blue, (0, -2, 0), (20, 0, 0), (0, 0, -40)),
+        rectangle(blue, (0, 4.5, 0), (20, 0, 0), (0, 0, 40)),
+        colorcube(colors, (-2, -1.5, -6), 1),
+        cube(white, (0, 4.2, -10), 0.1),
+        cube(white, (0, 3.8, -10), 0.1),
+        rectangle(green, (-0.2, 4, -10), (0, -0.5, 0), (0, 0, -0.3)),
+        rectangle(green, (0.2, 4, -10), (0, -0.5, 0), (0, 0, 0.3)),
+        rectangle(green, (0, 4, -9.8), (0, 0.5, 0), (0.3, 0, 0)),
+        rectangle(green, (0, 4, -10.2), (0, -0.5, 0), (0.3, 0, 0)),
+        rectangle(orange, (2.2, -0.5, -10), (0, 12, 0), (-5, 0, -10))]), main_lights()
+
+
+def triangle_example():                              # Main.hs:711-723
+    return mconcat([
+        rectangle(cyan, (0, 0, -10), (4.0, 0, 0), (0, 4.0, 0)),
+        rectangle(cyan, (-3, 0, -9), (2.0, 0, -2.0), (0, 4.0, 0)),
+        rectangle(cyan, (3, 0, -9), (2.0, 0, 2.0), (0, 4.0, 0)),
+        cube(yellow, (0, -1.5, -5), 1.0),
+        triangle(orange, (0, 1, -4), (-1, 0, -4), (1, 0, -4)),
+        rectangle(green, (0, 0, -3), (1, 0, 0), (0, 1, 0)),
+        rectangle(blue, (0, -2, 0), (20, 0, 0), (0, 0, -40))]), main_lights()
+
+
+def spec_test():                                     # Main.hs:776-788
+    spec_white = white.replace(specularity=400)
+    world = mconcat([
+        rectangle(blue, (0, -2, 0), (20, 0, 0), (0, 0, -40)),
+        rectangle(blue, (0, 10, 0), (20, 0, 0), (0, 0, -40)),
+        rectangle(white, (-2, 0, -4), (0, 6, 0), (0, 0, 6)),
+        rectangle(spec_white, (2, 0, -4), (-0.5, 0, 6), (0, 6, 0))])
+    return world, pointLight(0.3, 0.6, (0, 0, -4)) + pointLight(0.0, 1.0, (-3, 0, -10))
+
+
+def intersection():                                  # Main.hs:790-797
+    world = mconcat([
+        cylinder(red, red, red, (0, -1, -3), 20, 2, 0.02),
+        rectangle(orange, (0, -1, -3), (1, 0, 1), (2, 0, -2))])
+    return world, ambient(0.5) + pointLight(0.5, 0.2, (1, 1, -3))
+
+
+def cylinder_axes():                                 # Main.hs:572 (commented world)
+    return cylinder(blue, blue, green, (0, -2, -10), 20, 1, 5) + axes_shape(), main_lights()
+
+
+def talk_main2():                                    # Talk.hs:263-273 geometry, lit with Main.hs's Phong lights
+    world = colorcube([red, green, blue, white, black], (1, -2, -6), 2.0) + \
+        rectangle(blue, (0, -5, 0), (20, 0, 0), (0, 0, -50))
+    return world, mconcat_lights([ambient(0.1), pointLight(0.3, 0.0, (0, 0, 0)), pointLight(0.6, 0.0, (-1, 3, -3))])
+
+
+REFERENCE_SCENES = {
+    "default": default_scene, "planes": planes, "axes": axes, "cubes": cubes, "stacked_cubes": stacked_cubes,
+    "triangle_example": triangle_example, "spec_test": spec_test, "intersection": intersection,
+    "cylinder_axes": cylinder_axes, "talk_main2": talk_main2,
+}
+
+
+# ---------------------------------------------------------------------------------------------
+# Synthetic benchmark scenes (SURVEY.md §8 d)
+
+SYNTH_SEED = 20260355
+
+
+def _unit(rng):
+    v = rng.normal(size=3)
+    return v / np.linalg.norm(v)
+
+
+def _centre(rng):
+    return np.array([rng.uniform(-8, 8), rng.uniform(-6, 6), rng.uniform(-30, -6)])
+
+
+def synthetic(ntri=10000, ncuboid=1000, seed=SYNTH_SEED, specularities=(1, 20, 100)):
+    """configs[2]/[3]: ntri triangles (edge U[0.05,0.3]) + ncuboid axis-aligned cuboids (sides U[0.1,0.6]),
+    centres U[-8,8]x[-6,6]x[-30,-6], 4 point lights (kd 0.25, ks 0.3) above the box, ambient 0.1.
+    Leaf order: triangles, then cuboids (6 rectangles each)."""
+    rng = np.random.default_rng(seed)
+    shapes = []
+
+    def mat():
+        return COLOURS[int(rng.integers(len(COLOURS)))].replace(specularity=float(specularities[int(rng.integers(len(specularities)))]))
+
+    for _ in range(ntri):
+        c = _centre(rng)
+        a, b = _unit(rng), _unit(rng)
+        while abs(float(a @ b)) > 0.95:
+            b = _unit(rng)
+        pa, pb, pc = c, c + rng.uniform(0.05, 0.3) * a, c + rng.uniform(0.05, 0.3) * b
+        shapes.append(triangle(mat(), tuple(map(float, pa)), tuple(map(float, pb)), tuple(map(float, pc))))
+    for _ in range(ncuboid):
+        c = _centre(rng)
+        l, h, d = (float(rng.uniform(0.1, 0.6)) for _ in range(3))
+        shapes.append(colorcuboid([mat()], tuple(map(float, c)), l, h, d))
+    lights = mconcat_lights([pointLight(0.25, 0.3, p) for p in
+                             [(-6.0, 10.0, -10.0), (6.0, 10.0, -10.0), (-6.0, 10.0, -26.0), (6.0, 10.0, -26.0)]]
+                            + [ambient(0.1)])
+    return mconcat(shapes), lights
+
+
+def synthetic_cylinders(ncyl=200, ncuboid=500, seed=SYNTH_SEED + 1, specularities=(100, 400)):
+    """configs[4]: upright cylinders (n=16) + cuboids, specular-heavy materials."""
+    rng = np.random.default_rng(seed)
+    shapes = []
+
+    def mat():
+        return COLOURS[int(rng.integers(len(COLOURS)))].replace(specularity=float(specularities[int(rng.integers(len(specularities)))]))
+
+    for _ in range(ncyl):
+        c = _centre(rng)
+        shapes.append(cylinder(mat(), mat(), mat(), tuple(map(float, c)), 16, float(rng.uniform(0.5, 2.0)), float(rng.uniform(0.1, 0.5))))
+    for _ in range(ncuboid):
+        c = _centre(rng)
+        l, h, d = (float(rng.uniform(0.1, 0.6)) for _ in range(3))
+        shapes.append(colorcuboid([mat()], tuple(map(float, c)), l, h, d))
+    lights = mconcat_lights([pointLight(0.25, 0.3, p) for p in
+                             [(-6.0, 10.0, -10.0), (6.0, 10.0, -10.0), (-6.0, 10.0, -26.0), (6.0, 10.0, -26.0)]]
+                            + [ambient(0.1)])
+    return mconcat(shapes), lights
