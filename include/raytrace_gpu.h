@@ -59,8 +59,10 @@ typedef struct {
     uint64_t tri_tests;          /* ray x triangle  filter tests executed (brute force)        */
     uint64_t rect_tests;         /* ray x rectangle filter tests executed                      */
     uint64_t exact_evals;        /* FP64 exact leaf evaluations (candidates of the filter)     */
-    double   ms_primary;         /* HIP-event time of the nearest-hit kernel(s)                */
-    double   ms_shade;           /* HIP-event time of the shading + shadow kernel(s)           */
+    double   ms_primary;         /* HIP-event time of k_primary (nearest hit)                  */
+    double   ms_setup;           /* ... of k_setup (exact hit records + shadow-job queues)     */
+    double   ms_shadow;          /* ... of k_shadow (shadow rays, the dominant kernel)         */
+    double   ms_final;           /* ... of k_final (Phong + RGBA8 store)                       */
     double   ms_total;           /* first launch to last kernel end                            */
 } rt_stats;
 

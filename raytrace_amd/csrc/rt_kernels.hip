@@ -35,6 +35,7 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
+struct HitRec;
 struct RenderParams {
     const LeafD *leaves;
     const AuxD *aux;
@@ -46,17 +47,26 @@ struct RenderParams {
     const int32_t *tri_gid;
     const int32_t *rect_gid;
     unsigned long long *counters;   // [0] shadow rays cast, [1] exact evals (primary), [2] exact evals (shadow)
-    int32_t *hit_id;                // band-local, nrows * w
-    uint8_t *rgba;                  // band-local, nrows * w * 4 (spp == 1) or nullptr
-    uint32_t *accum;                // band-local, nrows * w * 3 sums (spp > 1) or nullptr
+    int32_t *hit_id;                // band-local output, indexed out_off + pix
+    uint8_t *rgba;                  // band-local output (spp == 1) or nullptr
+    uint32_t *accum;                // band-local 3 x u32 sums (spp > 1) or nullptr
+    HitRec *hitrec;                 // per chunk pixel: exact hit point and shading normal
+    uint32_t *queue;                // npoint blocks of qcap shadow jobs (chunk pixel indices)
+    unsigned *qcount;               // shadow jobs per point light
+    uint32_t *lit;                  // per chunk pixel: bit l set = point light l reaches it
     CameraD cam;
     double eps;
-    int ntri, nrect, nlights, nleaves;
-    int w, h, row0, nrows;
+    int ntri, nrect, nlights, nleaves, npoint;
+    int w, h;
+    int row0, nrows;                // this chunk: first absolute image row, rows
+    long long out_off;              // index of the chunk's first pixel inside the band-local outputs
+    int qcap;                       // pixels in the chunk = capacity of one shadow queue
     int spp, sample;
     uint32_t seed_lo, seed_hi;
     int tiles_x, tiles_y;
 };
+
+struct HitRec { double px, py, pz, nx, ny, nz; };
 
 // ------------------------------------------------------------------------------------------
 // Exact path (IEEE double, reference expression order)
@@ -204,7 +214,9 @@ __device__ __forceinline__ void tile_coords(const RenderParams &P, int &x0, int 
 
 // ------------------------------------------------------------------------------------------
 // Kernel 1: nearest hit of the primary rays -> hit_id
-//   replaces `intersect world (cast camera x y)` of trace (Main.hs:543) for every pixel of the band
+//   replaces `intersect world (cast camera x y)` of trace (Main.hs:543) for every pixel of the chunk.
+//   One wave = 32 x 8 pixel tile, 4 pixels per lane.  Apex = the eye (all primary rays pass through
+//   (0, 0, -d)), D = (posX, posY, d).
 
 template <int KIND>
 __device__ __forceinline__ void primary_loop(const RenderParams &P, const FilterRec *__restrict__ recs,
@@ -264,19 +276,177 @@ __global__ void __launch_bounds__(RT_WAVES_PER_BLOCK * 64) k_primary(const Rende
     unsigned nexact = 0;
     primary_loop<LEAF_TRI>(P, P.tri_rec, P.tri_gid, P.ntri, D, act, x0, y, bt, bid, nexact);
     primary_loop<LEAF_RECT>(P, P.rect_rec, P.rect_gid, P.nrect, D, act, x0, y, bt, bid, nexact);
-    const size_t row = (size_t)(y - P.row0) * (size_t)P.w;
+    const long long row = P.out_off + (long long)(y - P.row0) * P.w;
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-        if (act[r]) P.hit_id[row + (size_t)(x0 + r)] = bid[r];
+        if (act[r]) P.hit_id[row + (x0 + r)] = bid[r];
     for (int o = 32; o > 0; o >>= 1) nexact += __shfl_down(nexact, o);
     if ((threadIdx.x & 63) == 0 && nexact) atomicAdd(&P.counters[1], (unsigned long long)nexact);
 }
 
 // ------------------------------------------------------------------------------------------
-// Kernel 2: shading with shadow rays -> RGBA8
-//   replaces `light lights hit ray` (Main.hs:545, 436-441) = pointLight (467-487) + ambient (490-492)
+// Kernel 2: per hit pixel, the exact hit point and shading normal; shadow jobs for every point light
+//   with L.N > 0, compacted into one queue per light (wave-aggregated atomics).
+//   When L.N <= 0 both Phong terms are exactly 0 (Main.hs:480-484), so the shadow ray cannot change
+//   the pixel and is not cast.
 
-struct Hit4 { double px[4], py[4], pz[4], nx[4], ny[4], nz[4]; };
+__device__ __forceinline__ void to_light(const LightD &Lt, double hx, double hy, double hz, double &tx, double &ty, double &tz) {
+    const double lx = Lt.px - hx, ly = Lt.py - hy, lz = Lt.pz - hz;                    // Main.hs:470
+    const double ln = sqrt(lx * lx + ly * ly + lz * lz);
+    tx = lx / ln; ty = ly / ln; tz = lz / ln;
+}
+
+__global__ void __launch_bounds__(256) k_setup(const RenderParams P) {
+    const int pix = (int)(blockIdx.x * 256 + threadIdx.x);
+    const bool act = pix < P.qcap;
+    const int ly = act ? pix / P.w : 0, x = act ? pix - ly * P.w : 0, y = P.row0 + ly;
+    const int id = act ? P.hit_id[P.out_off + pix] : -1;
+    HitRec H = {0, 0, 0, 0, 0, 0};
+    if (id >= 0) {
+        const LeafD L = P.leaves[id];
+        const RayD ray = camera_ray(P, x, y);
+        double ix = 0, iy = 0, iz = 0, t;
+        if (L.kind == LEAF_RECT) leaf_isect<LEAF_RECT>(L, ray, ix, iy, iz, t);
+        else leaf_isect<LEAF_TRI>(L, ray, ix, iy, iz, t);
+        double nx = L.nx, ny = L.ny, nz = L.nz;
+        if (L.nmode == RT_NORMAL_MANTLE) {                                             // Main.hs:769-771
+            const AuxD A = P.aux[L.aux];
+            nx = A.a[0] + (ix - A.a[3]) * A.a[6];
+            nz = A.a[2] + (iz - A.a[5]) * A.a[8];
+            ny = 0;
+        } else if (L.nmode == RT_NORMAL_GAUSSIAN) {                                    // Main.hs:959-963, 580-584
+            const AuxD A = P.aux[L.aux];
+            const double gx = A.a[0] * (ix - A.a[1]), gy = A.a[0] * (iz - A.a[3]);
+            const double f = exp(-(gx * gx + gy * gy) * 4);
+            const double dfdx = -8 * gx * f, dfdy = -8 * gy * f;
+            // normalize (MkV3D 1 dfdx 0 *# MkV3D 0 dfdy 1)
+            const double vx = dfdx * 1 - 0 * dfdy, vy = 0 * 0 - 1 * 1, vz = 1 * dfdy - 0 * dfdx;
+            const double vn = sqrt(vx * vx + vy * vy + vz * vz);
+            const double ux = vx / vn, uy = vy / vn, uz = vz / vn;
+            const double dt = nx * ux + ny * uy + nz * uz;
+            const double sg = dt > 0 ? 1.0 : (dt < 0 ? -1.0 : dt);                      // signum
+            nx = sg * ux; ny = sg * uy; nz = sg * uz;
+        }
+        H.px = ix; H.py = iy; H.pz = iz; H.nx = nx; H.ny = ny; H.nz = nz;
+        P.hitrec[pix] = H;
+    }
+    if (act) P.lit[pix] = 0u;
+    const int lane = (int)(threadIdx.x & 63);
+    int pl = 0;
+    for (int li = 0; li < P.nlights; ++li) {
+        const LightD &Lt = P.lights[li];
+        if (Lt.kind != 0) continue;
+        bool need = false;
+        if (id >= 0) {
+            double tx, ty, tz;
+            to_light(Lt, H.px, H.py, H.pz, tx, ty, tz);
+            const double lndot = tx * H.nx + ty * H.ny + tz * H.nz;                    // Main.hs:476
+            need = !(lndot <= 0);
+        }
+        const unsigned long long m = __ballot(need);
+        if (m) {
+            const int leader = __ffsll((long long)m) - 1;
+            unsigned base = 0;
+            if (lane == leader) {
+                base = atomicAdd(&P.qcount[pl], (unsigned)__popcll(m));
+                atomicAdd(&P.counters[0], (unsigned long long)__popcll(m));
+            }
+            base = __shfl(base, leader);
+            if (need) P.queue[(size_t)pl * (size_t)P.qcap + base + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)pix;
+        }
+        ++pl;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Kernel 3: shadow rays of one point light (blockIdx.y), 4 jobs per lane, brute force over all leaves.
+//   replaces `intersect world ray_to_light` + the t <= distance test of pointLight (Main.hs:472-474).
+//   Apex = the light, D = shadow-ray origin - light; the filter's clip keeps leaves between them.
+
+template <int KIND>
+__device__ __forceinline__ void shadow_loop(const RenderParams &P, const FilterRec *__restrict__ recs,
+                                            const int32_t *__restrict__ gids, int n, const Dir4 &D,
+                                            const uint32_t pix[4], const LightD &Lt, bool need[4], unsigned &nexact) {
+    for (int i = 0; i < n; ++i) {
+        float z[4];
+        if (filter4<KIND, true>(recs[i], D, z)) {
+            const int gid = gids[i];
+            const LeafD &L = P.leaves[gid];
+            const float negm = recs[i].c[10];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if ((z[r] >= negm) & need[r]) {
+                    uint32_t pr = pix[r];
+                    asm volatile("" : "+v"(pr));   // keep the exact-path ray set-up inside this rare branch
+                    // the hit leaf itself lies 1e-5 behind the shadow-ray origin (Main.hs:472): t < 0
+                    if (P.hit_id[P.out_off + pr] != gid) {
+                        const HitRec H = P.hitrec[pr];
+                        double tx, ty, tz;
+                        to_light(Lt, H.px, H.py, H.pz, tx, ty, tz);
+                        const RayD ray = mkray(H.px + 0.00001 * tx, H.py + 0.00001 * ty, H.pz + 0.00001 * tz,
+                                               tx, ty, tz, P.eps);                     // Main.hs:472
+                        double ix, iy, iz, t;
+                        ++nexact;
+                        if (leaf_isect<KIND>(L, ray, ix, iy, iz, t) && guards_ok(P.guards, L.guard, ray)) {
+                            const double tl = (Lt.pz - ray.pz) * ray.rz;               // rayDistance ray lpos
+                            if (t <= tl) need[r] = false;                              // Main.hs:474 -> black
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(RT_WAVES_PER_BLOCK * 64) k_shadow(const RenderParams P) {
+    const int pl = (int)blockIdx.y;
+    const unsigned count = P.qcount[pl];
+    const unsigned wave = blockIdx.x * RT_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (wave * 256u >= count) return;
+    const int lane = (int)(threadIdx.x & 63);
+    // the pl-th point light
+    int li = 0;
+    for (int k = -1; li < P.nlights; ++li) if (P.lights[li].kind == 0 && ++k == pl) break;
+    const LightD &Lt = P.lights[li];
+    const uint32_t *q = P.queue + (size_t)pl * (size_t)P.qcap;
+    uint32_t pix[4]; bool need[4];
+    float ddx[4], ddy[4], ddz[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const unsigned j = wave * 256u + (unsigned)(r * 64 + lane);
+        need[r] = j < count;
+        pix[r] = need[r] ? q[j] : 0u;
+        ddx[r] = ddy[r] = ddz[r] = 0.f;
+        if (need[r]) {
+            const HitRec H = P.hitrec[pix[r]];
+            double tx, ty, tz;
+            to_light(Lt, H.px, H.py, H.pz, tx, ty, tz);
+            ddx[r] = (float)((H.px + 0.00001 * tx) - Lt.px);
+            ddy[r] = (float)((H.py + 0.00001 * ty) - Lt.py);
+            ddz[r] = (float)((H.pz + 0.00001 * tz) - Lt.pz);
+        }
+    }
+    Dir4 D;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        D.x[p] = f2{ddx[2 * p], ddx[2 * p + 1]};
+        D.y[p] = f2{ddy[2 * p], ddy[2 * p + 1]};
+        D.z[p] = f2{ddz[2 * p], ddz[2 * p + 1]};
+    }
+    unsigned nexact = 0;
+    const size_t ro = (size_t)Lt.rec_offset;
+    shadow_loop<LEAF_TRI>(P, P.tri_rec + ro * (size_t)P.ntri, P.tri_gid, P.ntri, D, pix, Lt, need, nexact);
+    shadow_loop<LEAF_RECT>(P, P.rect_rec + ro * (size_t)P.nrect, P.rect_gid, P.nrect, D, pix, Lt, need, nexact);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (need[r]) atomicOr(&P.lit[pix[r]], 1u << pl);
+    for (int o = 32; o > 0; o >>= 1) nexact += __shfl_down(nexact, o);
+    if (lane == 0 && nexact) atomicAdd(&P.counters[2], (unsigned long long)nexact);
+}
+
+// ------------------------------------------------------------------------------------------
+// Kernel 4: `light lights hit ray` (Main.hs:545, 436-441) = pointLight (467-487) + ambient (490-492),
+//   saturating 8-bit sums, coalesced RGBA8 store.
 
 // Haskell `round` (half-even) then fromInteger to Word8 (wraps) — Main.hs:451-456
 __device__ __forceinline__ int round8(double v) {
@@ -286,176 +456,48 @@ __device__ __forceinline__ int round8(double v) {
 }
 __device__ __forceinline__ double hs_max0(double v) { return 0.0 <= v ? v : 0.0; }    // max 0 v
 
-template <int KIND>
-__device__ __forceinline__ void shadow_loop(const RenderParams &P, const FilterRec *__restrict__ recs,
-                                            const int32_t *__restrict__ gids, int n, const Dir4 &D,
-                                            const Hit4 &H, const int own[4], const LightD &Lt,
-                                            bool need[4], unsigned &nexact) {
-    for (int i = 0; i < n; ++i) {
-        float z[4];
-        if (filter4<KIND, true>(recs[i], D, z)) {
-            const int gid = gids[i];
-            const LeafD &L = P.leaves[gid];
-            const float negm = recs[i].c[10];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                // the hit leaf itself lies 1e-5 behind the shadow-ray origin (Main.hs:472): t < 0
-                if ((z[r] >= negm) & need[r] & (gid != own[r])) {
-                    double hx = H.px[r];
-                    asm volatile("" : "+v"(hx));   // keep the exact-path ray set-up inside this rare branch
-                    const double lx = Lt.px - hx, ly = Lt.py - H.py[r], lz = Lt.pz - H.pz[r];
-                    const double ln = sqrt(lx * lx + ly * ly + lz * lz);
-                    const double tx = lx / ln, ty = ly / ln, tz = lz / ln;             // to_light, :470
-                    const RayD ray = mkray(hx + 0.00001 * tx, H.py[r] + 0.00001 * ty, H.pz[r] + 0.00001 * tz,
-                                           tx, ty, tz, P.eps);                         // :472
-                    double ix, iy, iz, t;
-                    ++nexact;
-                    if (leaf_isect<KIND>(L, ray, ix, iy, iz, t) && guards_ok(P.guards, L.guard, ray)) {
-                        const double tl = (Lt.pz - ray.pz) * ray.rz;                   // rayDistance ray lpos
-                        if (t <= tl) need[r] = false;                                  // :474 -> black
-                    }
-                }
+__global__ void __launch_bounds__(256) k_final(const RenderParams P) {
+    const int pix = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (pix >= P.qcap) return;
+    const int ly = pix / P.w, x = pix - ly * P.w, y = P.row0 + ly;
+    const int id = P.hit_id[P.out_off + pix];
+    int cr = 0, cg = 0, cb = 0;
+    if (id >= 0) {
+        const MaterialD M = P.mats[P.leaves[id].mat];
+        const HitRec H = P.hitrec[pix];
+        const uint32_t lit = P.lit[pix];
+        int pl = 0;
+        for (int li = 0; li < P.nlights; ++li) {
+            const LightD &Lt = P.lights[li];
+            if (Lt.kind == 1) {                                                        // ambient, Main.hs:490-492
+                cr = min(255, cr + round8(Lt.f * (double)M.diffuse[0]));
+                cg = min(255, cg + round8(Lt.f * (double)M.diffuse[1]));
+                cb = min(255, cb + round8(Lt.f * (double)M.diffuse[2]));
+                continue;
             }
-        }
-    }
-}
-
-__global__ void __launch_bounds__(RT_WAVES_PER_BLOCK * 64) k_shade(const RenderParams P) {
-    int x0, y; bool row_ok;
-    tile_coords(P, x0, y, row_ok);
-    const size_t row = (size_t)(y - P.row0) * (size_t)P.w;
-    bool hit[4]; int own[4]; int mat[4];
-    Hit4 H;
-    int cr[4], cg[4], cb[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        cr[r] = cg[r] = cb[r] = 0;
-        const bool act = row_ok && (x0 + r) < P.w;
-        own[r] = act ? P.hit_id[row + (size_t)(x0 + r)] : -1;
-        hit[r] = own[r] >= 0;
-        mat[r] = 0;
-        H.px[r] = H.py[r] = H.pz[r] = 0; H.nx[r] = H.ny[r] = H.nz[r] = 0;
-        if (hit[r]) {
-            // recompute the intersection (isect, normal) of the winning leaf exactly
-            const LeafD L = P.leaves[own[r]];
-            const RayD ray = camera_ray(P, x0 + r, y);
-            double ix, iy, iz, t;
-            if (L.kind == LEAF_RECT) leaf_isect<LEAF_RECT>(L, ray, ix, iy, iz, t);
-            else leaf_isect<LEAF_TRI>(L, ray, ix, iy, iz, t);
-            H.px[r] = ix; H.py[r] = iy; H.pz[r] = iz;
-            mat[r] = L.mat;
-            double nx = L.nx, ny = L.ny, nz = L.nz;
-            if (L.nmode == RT_NORMAL_MANTLE) {                                         // Main.hs:769-771
-                const AuxD A = P.aux[L.aux];
-                nx = A.a[0] + (ix - A.a[3]) * A.a[6];
-                nz = A.a[2] + (iz - A.a[5]) * A.a[8];
-                ny = 0;
-            } else if (L.nmode == RT_NORMAL_GAUSSIAN) {                                // Main.hs:959-963, 580-584
-                const AuxD A = P.aux[L.aux];
-                const double gx = A.a[0] * (ix - A.a[1]), gy = A.a[0] * (iz - A.a[3]);
-                const double f = exp(-(gx * gx + gy * gy) * 4);
-                const double dfdx = -8 * gx * f, dfdy = -8 * gy * f;
-                // normalize (MkV3D 1 dfdx 0 *# MkV3D 0 dfdy 1)
-                const double vx = dfdx * 1 - 0 * dfdy, vy = 0 * 0 - 1 * 1, vz = 1 * dfdy - 0 * dfdx;
-                const double vn = sqrt(vx * vx + vy * vy + vz * vz);
-                const double ux = vx / vn, uy = vy / vn, uz = vz / vn;
-                const double dt = nx * ux + ny * uy + nz * uz;
-                const double sg = dt > 0 ? 1.0 : (dt < 0 ? -1.0 : dt);                  // signum
-                nx = sg * ux; ny = sg * uy; nz = sg * uz;
-            }
-            H.nx[r] = nx; H.ny[r] = ny; H.nz[r] = nz;
-        }
-    }
-    unsigned nshadow = 0, nexact = 0;
-    for (int li = 0; li < P.nlights; ++li) {
-        const LightD &Lt = P.lights[li];
-        if (Lt.kind == 1) {                                                            // ambient, :490-492
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (hit[r]) {
-                    const MaterialD M = P.mats[mat[r]];
-                    cr[r] = min(255, cr[r] + round8(Lt.f * (double)M.diffuse[0]));
-                    cg[r] = min(255, cg[r] + round8(Lt.f * (double)M.diffuse[1]));
-                    cb[r] = min(255, cb[r] + round8(Lt.f * (double)M.diffuse[2]));
-                }
-            continue;
-        }
-        // point light: decide which pixels need a shadow ray.  When L.N <= 0 both Phong terms are
-        // exactly 0 (Main.hs:480-484), so the shadow ray cannot change the pixel and is not cast.
-        bool need[4];
-        Dir4 D;
-        float ddx[4], ddy[4], ddz[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            need[r] = false;
-            ddx[r] = ddy[r] = ddz[r] = 0.f;
-            if (hit[r]) {
-                const double lx = Lt.px - H.px[r], ly = Lt.py - H.py[r], lz = Lt.pz - H.pz[r];
-                const double ln = sqrt(lx * lx + ly * ly + lz * lz);
-                const double tx = lx / ln, ty = ly / ln, tz = lz / ln;
-                const double lndot = tx * H.nx[r] + ty * H.ny[r] + tz * H.nz[r];
-                need[r] = !(lndot <= 0);
-                // D = shadow-ray origin - light position
-                ddx[r] = (float)((H.px[r] + 0.00001 * tx) - Lt.px);
-                ddy[r] = (float)((H.py[r] + 0.00001 * ty) - Lt.py);
-                ddz[r] = (float)((H.pz[r] + 0.00001 * tz) - Lt.pz);
-            }
-            nshadow += need[r] ? 1u : 0u;
-        }
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            D.x[p] = f2{ddx[2 * p], ddx[2 * p + 1]};
-            D.y[p] = f2{ddy[2 * p], ddy[2 * p + 1]};
-            D.z[p] = f2{ddz[2 * p], ddz[2 * p + 1]};
-        }
-        if (__any(need[0] | need[1] | need[2] | need[3])) {
-            const size_t ro = (size_t)Lt.rec_offset;
-            shadow_loop<LEAF_TRI>(P, P.tri_rec + ro * (size_t)P.ntri, P.tri_gid, P.ntri, D, H, own, Lt, need, nexact);
-            shadow_loop<LEAF_RECT>(P, P.rect_rec + ro * (size_t)P.nrect, P.rect_gid, P.nrect, D, H, own, Lt, need, nexact);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (need[r]) {                                                             // lit: Main.hs:476-487
-                const MaterialD M = P.mats[mat[r]];
-                const RayD ray = camera_ray(P, x0 + r, y);
-                const double lx = Lt.px - H.px[r], ly = Lt.py - H.py[r], lz = Lt.pz - H.pz[r];
-                const double ln = sqrt(lx * lx + ly * ly + lz * lz);
-                const double tx = lx / ln, ty = ly / ln, tz = lz / ln;
-                const double lndot = tx * H.nx[r] + ty * H.ny[r] + tz * H.nz[r];
+            if ((lit >> pl) & 1u) {                                                    // lit: Main.hs:476-487
+                const RayD ray = camera_ray(P, x, y);
+                double tx, ty, tz;
+                to_light(Lt, H.px, H.py, H.pz, tx, ty, tz);
+                const double lndot = tx * H.nx + ty * H.ny + tz * H.nz;
                 const double k2 = 2 * lndot;
-                const double rx = tx - k2 * H.nx[r], ry = ty - k2 * H.ny[r], rz = tz - k2 * H.nz[r];
+                const double rx = tx - k2 * H.nx, ry = ty - k2 * H.ny, rz = tz - k2 * H.nz;
                 const double fDiffuse = Lt.diffuse * hs_max0(lndot);
                 const double fSpecular = (lndot <= 0) ? 0.0
                     : Lt.specular * pow(hs_max0(rx * ray.dx + ry * ray.dy + rz * ray.dz), M.specularity);
-                cr[r] = min(255, cr[r] + min(255, round8(fDiffuse * (double)M.diffuse[0]) + round8(fSpecular * (double)M.specular[0])));
-                cg[r] = min(255, cg[r] + min(255, round8(fDiffuse * (double)M.diffuse[1]) + round8(fSpecular * (double)M.specular[1])));
-                cb[r] = min(255, cb[r] + min(255, round8(fDiffuse * (double)M.diffuse[2]) + round8(fSpecular * (double)M.specular[2])));
+                cr = min(255, cr + min(255, round8(fDiffuse * (double)M.diffuse[0]) + round8(fSpecular * (double)M.specular[0])));
+                cg = min(255, cg + min(255, round8(fDiffuse * (double)M.diffuse[1]) + round8(fSpecular * (double)M.specular[1])));
+                cb = min(255, cb + min(255, round8(fDiffuse * (double)M.diffuse[2]) + round8(fSpecular * (double)M.specular[2])));
             }
+            ++pl;
+        }
     }
     if (P.rgba) {
-        uint32_t px[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) px[r] = (uint32_t)cr[r] | ((uint32_t)cg[r] << 8) | ((uint32_t)cb[r] << 16) | 0xff000000u;
-        uint32_t *dst = reinterpret_cast<uint32_t *>(P.rgba) + row + (size_t)x0;
-        if (row_ok && x0 + 3 < P.w && ((P.w & 3) == 0)) {
-            *reinterpret_cast<uint4 *>(dst) = make_uint4(px[0], px[1], px[2], px[3]);  // 16 B per lane, coalesced
-        } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) if (row_ok && x0 + r < P.w) dst[r] = px[r];
-        }
+        reinterpret_cast<uint32_t *>(P.rgba)[P.out_off + pix] =
+            (uint32_t)cr | ((uint32_t)cg << 8) | ((uint32_t)cb << 16) | 0xff000000u;   // 256 B per wave, coalesced
     } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (row_ok && x0 + r < P.w) {
-                uint32_t *a = P.accum + 3 * (row + (size_t)(x0 + r));
-                a[0] += (uint32_t)cr[r]; a[1] += (uint32_t)cg[r]; a[2] += (uint32_t)cb[r];
-            }
-    }
-    // wave-level reduction of the counters: one atomic per wave
-    for (int o = 32; o > 0; o >>= 1) { nshadow += __shfl_down(nshadow, o); nexact += __shfl_down(nexact, o); }
-    if ((threadIdx.x & 63) == 0) {
-        if (nshadow) atomicAdd(&P.counters[0], (unsigned long long)nshadow);
-        if (nexact) atomicAdd(&P.counters[2], (unsigned long long)nexact);
+        uint32_t *a = P.accum + 3 * (P.out_off + pix);
+        a[0] += (uint32_t)cr; a[1] += (uint32_t)cg; a[2] += (uint32_t)cb;
     }
 }
 
@@ -506,8 +548,6 @@ int ensure_init() {
 int prepare(rt_scene &s, int w, int h) {
     int rc;
     if (s.dirty || s.rec_w != w || s.rec_h != h || s.dev.device != g_device) {
-        for (const MaterialD &m : s.mats)
-            if (m.reflectivity > 0) { /* handled by caller: depth check */ }
         if (!compute_guards(s)) return RT_ERR_ARG;
         build_filter_records(s, w, h);
         if ((rc = upload(s.dev.leaves, s.leaves))) return rc;
@@ -520,13 +560,28 @@ int prepare(rt_scene &s, int w, int h) {
         if ((rc = upload(s.dev.tri_gid, s.tri_gid))) return rc;
         if ((rc = upload(s.dev.rect_gid, s.rect_gid))) return rc;
         if (!s.dev.counters) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s.dev.counters), 8 * sizeof(unsigned long long)));
+        if (!s.dev.qcount) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s.dev.qcount), 64 * sizeof(unsigned)));
         s.dev.device = g_device;
         s.dirty = false;
     }
-    for (int i = 0; i < 3; ++i)
-        if (!s.ev[i]) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); s.ev[i] = e; }
     return RT_OK;
 }
+
+// event pool: one event per kernel boundary, so that rt_get_stats can attribute time to each kernel
+int next_event(rt_scene &s, hipStream_t st, int kind) {
+    if (s.ev_used == (int)s.evpool.size()) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreate(&e));
+        s.evpool.push_back(e);
+        s.evkind.push_back(0);
+    }
+    s.evkind[s.ev_used] = kind;
+    HIP_TRY(hipEventRecord((hipEvent_t)s.evpool[s.ev_used], st));
+    ++s.ev_used;
+    return RT_OK;
+}
+
+constexpr size_t RT_CHUNK_PIXELS = 16u << 20;   // rows are processed in chunks of about 16 Mi pixels
 
 } // namespace
 
@@ -550,9 +605,9 @@ void rt_scene_destroy(rt_scene *s) {
     if (!s) return;
     DeviceScene &d = s->dev;
     void *ptrs[] = {d.leaves, d.aux, d.guards, d.mats, d.lights, d.tri_rec, d.rect_rec, d.tri_gid, d.rect_gid,
-                    d.counters, d.hit_id, d.accum, d.rgba};
+                    d.counters, d.qcount, d.hit_id, d.accum, d.rgba, d.hitrec, d.queue, d.lit};
     for (void *p : ptrs) if (p) (void)hipFree(p);
-    for (void *e : s->ev) if (e) (void)hipEventDestroy((hipEvent_t)e);
+    for (void *e : s->evpool) if (e) (void)hipEventDestroy((hipEvent_t)e);
     delete s;
 }
 
@@ -563,6 +618,7 @@ int rt_render_device(rt_scene *s, int w, int h, int depth, int spp, uint64_t see
         set_error("rt_render: bad image size or row band"); return RT_ERR_ARG;
     }
     if (depth < 0) { set_error("rt_render: depth must be >= 0"); return RT_ERR_ARG; }
+    if (s->npoint > 32) { set_error("rt_render: more than 32 point lights are not supported yet"); return RT_ERR_UNSUPPORTED; }
     if (depth > 1)
         for (const MaterialD &m : s->mats)
             if (m.reflectivity > 0) {
@@ -575,11 +631,23 @@ int rt_render_device(rt_scene *s, int w, int h, int depth, int spp, uint64_t see
     hipStream_t st = stream ? (hipStream_t)stream : g_stream;
     const size_t npix = (size_t)w * (size_t)nrows;
     s->last_primary = (uint64_t)npix * (uint64_t)spp;
+    s->ev_used = 0;
+    s->stats_pending = false;
     if (npix == 0) return RT_OK;
+    // rows per chunk: a multiple of the tile height
+    size_t crow = RT_CHUNK_PIXELS / (size_t)w;
+    crow = crow < RT_TILE_H ? RT_TILE_H : crow - crow % RT_TILE_H;
+    if (crow > (size_t)nrows) crow = (size_t)nrows;
+    const size_t cpix = crow * (size_t)w;
     int32_t *hit = (int32_t *)d_hit_id;
     if (!hit || spp > 1) {
         if ((rc = ensure(s->dev.hit_id, s->dev.hit_id_cap, npix))) return rc;
         if (!hit) hit = s->dev.hit_id;
+    }
+    if (d_rgba) {
+        if ((rc = ensure(s->dev.hitrec, s->dev.hitrec_cap, cpix * sizeof(HitRec)))) return rc;
+        if ((rc = ensure(s->dev.lit, s->dev.lit_cap, cpix))) return rc;
+        if ((rc = ensure(s->dev.queue, s->dev.queue_cap, cpix * (size_t)(s->npoint > 0 ? s->npoint : 1)))) return rc;
     }
     if (spp > 1 && d_rgba) {
         if ((rc = ensure(s->dev.accum, s->dev.accum_cap, 3 * npix))) return rc;
@@ -592,39 +660,55 @@ int rt_render_device(rt_scene *s, int w, int h, int depth, int spp, uint64_t see
     P.tri_rec = s->dev.tri_rec; P.rect_rec = s->dev.rect_rec;
     P.tri_gid = s->dev.tri_gid; P.rect_gid = s->dev.rect_gid;
     P.counters = s->dev.counters;
+    P.hitrec = reinterpret_cast<HitRec *>(s->dev.hitrec); P.queue = s->dev.queue; P.qcount = s->dev.qcount; P.lit = s->dev.lit;
     P.cam = fixed_camera(w, h);
     P.eps = ray_eps();
     P.ntri = (int)s->tri_gid.size(); P.nrect = (int)s->rect_gid.size();
-    P.nlights = (int)s->lights.size(); P.nleaves = (int)s->leaves.size();
-    P.w = w; P.h = h; P.row0 = row0; P.nrows = nrows;
+    P.nlights = (int)s->lights.size(); P.nleaves = (int)s->leaves.size(); P.npoint = s->npoint;
+    P.w = w; P.h = h;
     P.spp = spp; P.seed_lo = (uint32_t)seed; P.seed_hi = (uint32_t)(seed >> 32);
-    P.tiles_x = (w + RT_TILE_W - 1) / RT_TILE_W;
-    P.tiles_y = (nrows + RT_TILE_H - 1) / RT_TILE_H;
-    const long long tiles = (long long)P.tiles_x * P.tiles_y;
-    const unsigned blocks = (unsigned)((tiles + RT_WAVES_PER_BLOCK - 1) / RT_WAVES_PER_BLOCK);
-    const dim3 block(RT_WAVES_PER_BLOCK * 64);
 
-    HIP_TRY(hipEventRecord((hipEvent_t)s->ev[0], st));
+    if ((rc = next_event(*s, st, 0))) return rc;
     for (int sample = 0; sample < spp; ++sample) {
         P.sample = sample;
         // sample 0 writes the caller's hit-ID buffer; later samples use the scratch one
         P.hit_id = (sample == 0) ? hit : s->dev.hit_id;
-        if (depth == 0) {      // trace 0 = black (Main.hs:542): every pixel misses
-            HIP_TRY(hipMemsetAsync(P.hit_id, 0xff, npix * sizeof(int32_t), st));
-        } else {
-            hipLaunchKernelGGL(k_primary, dim3(blocks), block, 0, st, P);
-        }
-        if (sample == 0) HIP_TRY(hipEventRecord((hipEvent_t)s->ev[1], st));
-        if (d_rgba) {
-            P.rgba = (spp == 1) ? (uint8_t *)d_rgba : nullptr;
-            P.accum = (spp == 1) ? nullptr : s->dev.accum;
-            hipLaunchKernelGGL(k_shade, dim3(blocks), block, 0, st, P);
+        P.rgba = (spp == 1) ? (uint8_t *)d_rgba : nullptr;
+        P.accum = (spp == 1) ? nullptr : s->dev.accum;
+        for (size_t r = 0; r < (size_t)nrows; r += crow) {
+            const int rows = (int)((size_t)nrows - r < crow ? (size_t)nrows - r : crow);
+            P.row0 = row0 + (int)r; P.nrows = rows;
+            P.out_off = (long long)r * w;
+            P.qcap = rows * w;
+            P.tiles_x = (w + RT_TILE_W - 1) / RT_TILE_W;
+            P.tiles_y = (rows + RT_TILE_H - 1) / RT_TILE_H;
+            const long long tiles = (long long)P.tiles_x * P.tiles_y;
+            const unsigned tblocks = (unsigned)((tiles + RT_WAVES_PER_BLOCK - 1) / RT_WAVES_PER_BLOCK);
+            const unsigned pblocks = (unsigned)(((size_t)P.qcap + 255) / 256);
+            if (depth == 0) {      // trace 0 = black (Main.hs:542): every pixel misses
+                HIP_TRY(hipMemsetAsync(P.hit_id + P.out_off, 0xff, (size_t)P.qcap * sizeof(int32_t), st));
+            } else {
+                hipLaunchKernelGGL(k_primary, dim3(tblocks), dim3(RT_WAVES_PER_BLOCK * 64), 0, st, P);
+            }
+            if ((rc = next_event(*s, st, 1))) return rc;
+            if (!d_rgba) continue;
+            HIP_TRY(hipMemsetAsync(s->dev.qcount, 0, 64 * sizeof(unsigned), st));
+            hipLaunchKernelGGL(k_setup, dim3(pblocks), dim3(256), 0, st, P);
+            if ((rc = next_event(*s, st, 2))) return rc;
+            if (s->npoint > 0) {
+                const unsigned sblocks = (unsigned)(((size_t)P.qcap + 256 * RT_WAVES_PER_BLOCK - 1) / (256 * RT_WAVES_PER_BLOCK));
+                hipLaunchKernelGGL(k_shadow, dim3(sblocks, (unsigned)s->npoint), dim3(RT_WAVES_PER_BLOCK * 64), 0, st, P);
+            }
+            if ((rc = next_event(*s, st, 3))) return rc;
+            hipLaunchKernelGGL(k_final, dim3(pblocks), dim3(256), 0, st, P);
+            if ((rc = next_event(*s, st, 4))) return rc;
         }
     }
-    if (d_rgba && spp > 1)
+    if (d_rgba && spp > 1) {
         hipLaunchKernelGGL(k_resolve, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st,
                            s->dev.accum, (uint8_t *)d_rgba, npix, (uint32_t)spp);
-    HIP_TRY(hipEventRecord((hipEvent_t)s->ev[2], st));
+        if ((rc = next_event(*s, st, 4))) return rc;
+    }
     HIP_TRY(hipGetLastError());
     s->stats_pending = true;
     return RT_OK;
@@ -639,18 +723,13 @@ int rt_render(rt_scene *s, int w, int h, int depth, int spp, uint64_t seed, int 
     const size_t npix = (size_t)w * (size_t)nrows;
     if (npix == 0) return RT_OK;
     if ((rc = ensure(s->dev.rgba, s->dev.rgba_cap, 4 * npix))) return rc;
-    if ((rc = ensure(s->dev.hit_id, s->dev.hit_id_cap, npix))) return rc;
-    // the scratch hit buffer doubles as the output buffer for sample 0; spp > 1 needs a second one
-    int32_t *d_hit = s->dev.hit_id;
-    int32_t *tmp_hit = nullptr;
-    if (spp > 1) { HIP_TRY(hipMalloc(reinterpret_cast<void **>(&tmp_hit), npix * sizeof(int32_t))); d_hit = tmp_hit; }
-    rc = rt_render_device(s, w, h, depth, spp, seed, row0, nrows, rgba_out ? s->dev.rgba : nullptr, d_hit, g_stream);
+    if ((rc = ensure(s->dev.hit_out, s->dev.hit_out_cap, npix))) return rc;
+    rc = rt_render_device(s, w, h, depth, spp, seed, row0, nrows, rgba_out ? s->dev.rgba : nullptr, s->dev.hit_out, g_stream);
     if (rc == RT_OK) {
         if (rgba_out && !hip_ok(hipMemcpyAsync(rgba_out, s->dev.rgba, 4 * npix, hipMemcpyDeviceToHost, g_stream), "hipMemcpyAsync")) rc = RT_ERR_HIP;
-        if (rc == RT_OK && hit_id_out && !hip_ok(hipMemcpyAsync(hit_id_out, d_hit, npix * sizeof(int32_t), hipMemcpyDeviceToHost, g_stream), "hipMemcpyAsync")) rc = RT_ERR_HIP;
+        if (rc == RT_OK && hit_id_out && !hip_ok(hipMemcpyAsync(hit_id_out, s->dev.hit_out, npix * sizeof(int32_t), hipMemcpyDeviceToHost, g_stream), "hipMemcpyAsync")) rc = RT_ERR_HIP;
         if (!hip_ok(hipStreamSynchronize(g_stream), "hipStreamSynchronize")) rc = RT_ERR_HIP;
     }
-    if (tmp_hit) (void)hipFree(tmp_hit);
     return rc;
 }
 
@@ -662,21 +741,25 @@ int rt_synchronize(void) {
 
 int rt_get_stats(rt_scene *s, rt_stats *out) {
     if (!s || !out) { set_error("rt_get_stats: NULL argument"); return RT_ERR_ARG; }
-    if (s->stats_pending) {
-        HIP_TRY(hipEventSynchronize((hipEvent_t)s->ev[2]));
+    if (s->stats_pending && s->ev_used > 0) {
+        HIP_TRY(hipEventSynchronize((hipEvent_t)s->evpool[s->ev_used - 1]));
         unsigned long long c[8];
         HIP_TRY(hipMemcpy(c, s->dev.counters, sizeof c, hipMemcpyDeviceToHost));
-        float a = 0, b = 0, t = 0;
-        HIP_TRY(hipEventElapsedTime(&a, (hipEvent_t)s->ev[0], (hipEvent_t)s->ev[1]));
-        HIP_TRY(hipEventElapsedTime(&b, (hipEvent_t)s->ev[1], (hipEvent_t)s->ev[2]));
-        HIP_TRY(hipEventElapsedTime(&t, (hipEvent_t)s->ev[0], (hipEvent_t)s->ev[2]));
+        double ms[5] = {0, 0, 0, 0, 0};
+        for (int i = 1; i < s->ev_used; ++i) {
+            float t = 0;
+            HIP_TRY(hipEventElapsedTime(&t, (hipEvent_t)s->evpool[i - 1], (hipEvent_t)s->evpool[i]));
+            ms[s->evkind[i]] += t;
+        }
+        float tot = 0;
+        HIP_TRY(hipEventElapsedTime(&tot, (hipEvent_t)s->evpool[0], (hipEvent_t)s->evpool[s->ev_used - 1]));
         rt_stats st{};
         st.primary_rays = s->last_primary;
         st.shadow_rays = c[0];
         st.tri_tests = (st.primary_rays + st.shadow_rays) * (uint64_t)s->tri_gid.size();
         st.rect_tests = (st.primary_rays + st.shadow_rays) * (uint64_t)s->rect_gid.size();
         st.exact_evals = c[1] + c[2];
-        st.ms_primary = a; st.ms_shade = b; st.ms_total = t;
+        st.ms_primary = ms[1]; st.ms_setup = ms[2]; st.ms_shadow = ms[3]; st.ms_final = ms[4]; st.ms_total = tot;
         s->stats = st;
         s->stats_pending = false;
     }

@@ -28,6 +28,11 @@ struct DeviceScene {          // device copies (HBM), owned by the scene
     int32_t *hit_id = nullptr;  size_t hit_id_cap = 0;     // per band pixel
     uint32_t *accum = nullptr;  size_t accum_cap = 0;      // spp > 1: 3 x u32 per pixel
     uint8_t *rgba = nullptr;    size_t rgba_cap = 0;       // rt_render (host buffers) staging
+    int32_t *hit_out = nullptr; size_t hit_out_cap = 0;    // rt_render (host buffers) staging
+    char *hitrec = nullptr;     size_t hitrec_cap = 0;     // per chunk pixel: 48-byte HitRec (capacity in bytes)
+    uint32_t *queue = nullptr;  size_t queue_cap = 0;      // shadow-job queues, npoint x chunk pixels
+    uint32_t *lit = nullptr;    size_t lit_cap = 0;        // per chunk pixel: lit-by-light bit mask
+    unsigned *qcount = nullptr;                            // shadow jobs per point light
     int device = -1;
 };
 
@@ -57,7 +62,9 @@ struct rt_scene {
     bool dirty = true;                    // host scene changed since the last upload
     rt::DeviceScene dev;
     rt_stats stats{};
-    void *ev[4] = {nullptr, nullptr, nullptr, nullptr};   // hipEvent_t: start, after primary, after shade
+    std::vector<void *> evpool;           // hipEvent_t, one per kernel boundary of the last render
+    std::vector<int> evkind;              // which kernel ended at that event (1 primary .. 4 final)
+    int ev_used = 0;
     bool stats_pending = false;
     uint64_t last_primary = 0;
 };
