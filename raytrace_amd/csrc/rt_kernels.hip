@@ -202,6 +202,41 @@ __device__ __forceinline__ bool filter4(const FilterRec &R, const Dir4 &D, float
     return mx >= R.c[10];
 }
 
+// Eye-apex variant: the forms are affine in the pixel's viewport position (posX, posY); the lane's 4
+// pixels share posY (SHARED_Y, spp == 1), so the posY part of a form is computed once per lane.
+//   triangle : z = min(U, V, W)          rectangle: z = N - max(|A|, |B|)
+struct Eye4 { f2 x[2]; f2 y[2]; float ys; };
+
+template <int KIND, bool SHARED_Y>
+__device__ __forceinline__ bool filter4_eye(const FilterRec &R, const Eye4 &E, float z[4]) {
+    f2 q[3][2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (SHARED_Y) {
+            const float b = __builtin_fmaf(R.c[3 * k + 1], E.ys, R.c[3 * k + 2]);
+#pragma unroll
+            for (int p = 0; p < 2; ++p) q[k][p] = pkfma(splat(R.c[3 * k]), E.x[p], splat(b));
+        } else {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) q[k][p] = pkfma(splat(R.c[3 * k]), E.x[p], pkfma(splat(R.c[3 * k + 1]), E.y[p], splat(R.c[3 * k + 2])));
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        if (KIND == LEAF_TRI) {
+            z[2 * p] = __builtin_fminf(__builtin_fminf(q[0][p][0], q[1][p][0]), q[2][p][0]);
+            z[2 * p + 1] = __builtin_fminf(__builtin_fminf(q[0][p][1], q[1][p][1]), q[2][p][1]);
+        } else {
+            const f2 m = f2{__builtin_fmaxf(__builtin_fabsf(q[0][p][0]), __builtin_fabsf(q[1][p][0])),
+                            __builtin_fmaxf(__builtin_fabsf(q[0][p][1]), __builtin_fabsf(q[1][p][1]))};
+            const f2 zz = q[2][p] - m;
+            z[2 * p] = zz[0]; z[2 * p + 1] = zz[1];
+        }
+    }
+    const float mx = __builtin_fmaxf(__builtin_fmaxf(z[0], z[1]), __builtin_fmaxf(z[2], z[3]));
+    return mx >= R.c[10];
+}
+
 __device__ __forceinline__ void tile_coords(const RenderParams &P, int &x0, int &y, bool &row_ok) {
     const int wave = (int)(blockIdx.x * RT_WAVES_PER_BLOCK + (threadIdx.x >> 6));
     const int lane = (int)(threadIdx.x & 63);
@@ -218,14 +253,14 @@ __device__ __forceinline__ void tile_coords(const RenderParams &P, int &x0, int 
 //   One wave = 32 x 8 pixel tile, 4 pixels per lane.  Apex = the eye (all primary rays pass through
 //   (0, 0, -d)), D = (posX, posY, d).
 
-template <int KIND>
+template <int KIND, bool SHARED_Y>
 __device__ __forceinline__ void primary_loop(const RenderParams &P, const FilterRec *__restrict__ recs,
-                                             const int32_t *__restrict__ gids, int n, const Dir4 &D,
+                                             const int32_t *__restrict__ gids, int n, const Eye4 &D,
                                              const bool act[4], int x0, int y, double bt[4], int bid[4],
                                              unsigned &nexact) {
     for (int i = 0; i < n; ++i) {
         float z[4];
-        if (filter4<KIND, false>(recs[i], D, z)) {
+        if (filter4_eye<KIND, SHARED_Y>(recs[i], D, z)) {
             const int gid = gids[i];
             const LeafD &L = P.leaves[gid];
             const float negm = recs[i].c[10];
@@ -247,11 +282,12 @@ __device__ __forceinline__ void primary_loop(const RenderParams &P, const Filter
     }
 }
 
+template <bool SHARED_Y>
 __global__ void __launch_bounds__(RT_WAVES_PER_BLOCK * 64) k_primary(const RenderParams P) {
     int x0, y; bool row_ok;
     tile_coords(P, x0, y, row_ok);
     bool act[4];
-    Dir4 D;
+    Eye4 D;
     {
         float dx[4], dy[4];
 #pragma unroll
@@ -262,20 +298,19 @@ __global__ void __launch_bounds__(RT_WAVES_PER_BLOCK * 64) k_primary(const Rende
             dx[r] = (float)(P.cam.scaleX * ((double)(x0 + r) + ox) + P.cam.dX);
             dy[r] = (float)(P.cam.scaleY * ((double)y + oy) + P.cam.dY);
         }
-        const float dz = (float)P.cam.d;
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             D.x[p] = f2{dx[2 * p], dx[2 * p + 1]};
             D.y[p] = f2{dy[2 * p], dy[2 * p + 1]};
-            D.z[p] = f2{dz, dz};
         }
+        D.ys = dy[0];
     }
     double bt[4]; int bid[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) { bt[r] = INFINITY; bid[r] = -1; }
     unsigned nexact = 0;
-    primary_loop<LEAF_TRI>(P, P.tri_rec, P.tri_gid, P.ntri, D, act, x0, y, bt, bid, nexact);
-    primary_loop<LEAF_RECT>(P, P.rect_rec, P.rect_gid, P.nrect, D, act, x0, y, bt, bid, nexact);
+    primary_loop<LEAF_TRI, SHARED_Y>(P, P.tri_rec, P.tri_gid, P.ntri, D, act, x0, y, bt, bid, nexact);
+    primary_loop<LEAF_RECT, SHARED_Y>(P, P.rect_rec, P.rect_gid, P.nrect, D, act, x0, y, bt, bid, nexact);
     const long long row = P.out_off + (long long)(y - P.row0) * P.w;
 #pragma unroll
     for (int r = 0; r < 4; ++r)
@@ -688,7 +723,8 @@ int rt_render_device(rt_scene *s, int w, int h, int depth, int spp, uint64_t see
             if (depth == 0) {      // trace 0 = black (Main.hs:542): every pixel misses
                 HIP_TRY(hipMemsetAsync(P.hit_id + P.out_off, 0xff, (size_t)P.qcap * sizeof(int32_t), st));
             } else {
-                hipLaunchKernelGGL(k_primary, dim3(tblocks), dim3(RT_WAVES_PER_BLOCK * 64), 0, st, P);
+                if (spp == 1) hipLaunchKernelGGL(k_primary<true>, dim3(tblocks), dim3(RT_WAVES_PER_BLOCK * 64), 0, st, P);
+                else hipLaunchKernelGGL(k_primary<false>, dim3(tblocks), dim3(RT_WAVES_PER_BLOCK * 64), 0, st, P);
             }
             if ((rc = next_event(*s, st, 1))) return rc;
             if (!d_rgba) continue;

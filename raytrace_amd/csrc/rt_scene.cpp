@@ -155,7 +155,8 @@ static FilterRec always_rec() {  // apex (numerically) in the leaf's plane: let 
     return r;
 }
 
-static FilterRec make_rec(const LeafD &L, const double A[3], const double dmax[3]) {
+// eye_d: 0 for a light apex; the camera's d for the eye apex, whose records are affine in (posX, posY).
+static FilterRec make_rec(const LeafD &L, const double A[3], const double dmax[3], double eye_d = 0.0) {
     const double n[3] = {L.nx, L.ny, L.nz};
     const double e1[3] = {L.e1x, L.e1y, L.e1z}, e2[3] = {L.e2x, L.e2y, L.e2z};
     double g1[3], g2[3], q1A, q2A;   // gradients of the two inside coordinates and their value at A
@@ -193,6 +194,21 @@ static FilterRec make_rec(const LeafD &L, const double A[3], const double dmax[3
     const double mK = std::ldexp(SN + K, -20) + 1e-30;
     if (K <= 4 * mK) return always_rec();
     FilterRec r{};
+    if (eye_d != 0.0) {
+        // Eye apex: D = (posX, posY, d) with d constant, so every form is  f.x*posX + f.y*posY + f.z*d.
+        // Triangles store W = N - U - V instead of N (no clip test for primary rays: a hit between the eye
+        // and the viewport plane is rejected by the exact path, Main.hs:257).
+        double f3[3] = {cn[0], cn[1], cn[2]};
+        if (L.kind == LEAF_TRI) for (int i = 0; i < 3; ++i) f3[i] = cn[i] - c1[i] - c2[i];
+        const double *f[3] = {c1, c2, f3};
+        for (int k = 0; k < 3; ++k) {
+            r.c[3 * k] = (float)f[k][0]; r.c[3 * k + 1] = (float)f[k][1]; r.c[3 * k + 2] = (float)(f[k][2] * eye_d);
+        }
+        r.c[10] = f_down(-m);
+        r.c[9] = 0.0f;
+        for (int i = 0; i < 11; ++i) if (!std::isfinite(r.c[i])) return always_rec();
+        return r;
+    }
     for (int i = 0; i < 3; ++i) { r.c[i] = (float)c1[i]; r.c[3 + i] = (float)c2[i]; r.c[6 + i] = (float)cn[i]; }
     r.c[10] = f_down(-m);
     r.c[9] = f_down((K - mK) - (double)r.c[10]);   // Kq: N - Kq >= -m  <=>  N >= K - mK
@@ -284,9 +300,9 @@ void build_filter_records(rt_scene &s, int w, int h) {
     }
     const CameraD cam = fixed_camera(w, h);
     int apex = 0;
-    auto fill = [&](const double A[3], const double dmax[3]) {
-        for (size_t k = 0; k < ntri; ++k) s.tri_rec[(size_t)apex * ntri + k] = make_rec(s.leaves[s.tri_gid[k]], A, dmax);
-        for (size_t k = 0; k < nrect; ++k) s.rect_rec[(size_t)apex * nrect + k] = make_rec(s.leaves[s.rect_gid[k]], A, dmax);
+    auto fill = [&](const double A[3], const double dmax[3], double eye_d) {
+        for (size_t k = 0; k < ntri; ++k) s.tri_rec[(size_t)apex * ntri + k] = make_rec(s.leaves[s.tri_gid[k]], A, dmax, eye_d);
+        for (size_t k = 0; k < nrect; ++k) s.rect_rec[(size_t)apex * nrect + k] = make_rec(s.leaves[s.rect_gid[k]], A, dmax, eye_d);
         ++apex;
     };
     {   // the eye: every primary ray o = (posX, posY, 0), D = (posX, posY, d) passes through o - D
@@ -294,7 +310,7 @@ void build_filter_records(rt_scene &s, int w, int h) {
         // |posX| <= |dX| (+ half a pixel of jitter), |posY| <= |dY| (+ ...), D.z = d
         const double dmax[3] = {std::fabs(cam.dX) + 2 * std::fabs(cam.scaleX),
                                 std::fabs(cam.dY) + 2 * std::fabs(cam.scaleY), std::fabs(cam.d)};
-        fill(A, dmax);
+        fill(A, dmax, cam.d);
     }
     for (LightD &Lt : s.lights) {
         if (Lt.kind != 0) continue;
@@ -305,7 +321,7 @@ void build_filter_records(rt_scene &s, int w, int h) {
             const double a = std::fabs(lo[i] - A[i]), b = std::fabs(hi[i] - A[i]);
             dmax[i] = (s.leaves.empty() ? 1.0 : std::fmax(a, b)) * 1.001 + 1e-3;
         }
-        fill(A, dmax);
+        fill(A, dmax, 0.0);
     }
     s.rec_w = w; s.rec_h = h;
 }
