@@ -32,6 +32,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from raytrace_amd import api, scenes, _lib  # noqa: E402
+from raytrace_amd.distributed import gather_bands, split_rows  # noqa: E402
 
 FLOPS_TRI, FLOPS_RECT = 52 + 1, 44 + 1
 PEAK_FP32_TFLOPS = 157.3                        # MI355X_MICROARCH.md: peak FP32 (vector), packed FMA
@@ -43,17 +44,11 @@ def balanced_bands(scene, w, h, n, depth):
     if n == 1:
         return [(0, h)]
     sw, sh = max(64, w // 16), max(64, h // 16)
-    _, hit = scene.render(sw, sh, depth=depth, want_rgba=False)
+    _, hit = scene.render(sw, sh, depth=depth, want_rgba=True)
     st = scene.stats()
     shadow_per_hit = st["shadow_rays"] / max(1, int((hit >= 0).sum()))
-    cost = 1.0 + (hit >= 0).mean(axis=1) * shadow_per_hit          # per low-res row
-    cum = np.concatenate([[0.0], np.cumsum(cost)]) / cost.sum()
-    cuts = [0]
-    for k in range(1, n):
-        r = int(np.searchsorted(cum, k / n)) * h // sh
-        cuts.append(min(h, max(cuts[-1] + 8, (r // 8) * 8)))
-    cuts.append(h)
-    return [(cuts[i], cuts[i + 1] - cuts[i]) for i in range(n)]
+    cost = 1.0 + (hit >= 0).mean(axis=1) * shadow_per_hit          # per low-res row, in units of one primary loop
+    return split_rows(cost, h, n)
 
 
 def cpu_baseline(world, lights, w, h, depth, seconds=15.0):
@@ -123,12 +118,7 @@ def main():
     def step():
         scene.render_device(w, h, mine.data_ptr(), hit.data_ptr(), depth=args.depth, row0=row0, nrows=nrows, stream=stream)
         if n > 1:   # row bands -> GPU 0 (ncclSend/ncclRecv in one group: every peer has a direct xGMI link)
-            if rank == 0:
-                ops = [dist.P2POp(dist.irecv, frame[r0:r0 + nr], peer) for peer, (r0, nr) in enumerate(bands) if peer != 0]
-            else:
-                ops = [dist.P2POp(dist.isend, frame, 0)]
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
+            gather_bands(dist, frame, mine, bands, rank)
 
     def sync():
         if n > 1:

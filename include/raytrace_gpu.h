@@ -113,6 +113,14 @@ int  rt_scene_num_leaves(const rt_scene *);
 int  rt_scene_num_lights(const rt_scene *);
 /* out[0..19]: kind(0 rect,1 tri), normal mode, normal xyz, d, p0 xyz, e1 xyz, e2 xyz, c0..c3 */
 int  rt_scene_get_leaf(const rt_scene *, int leaf, double out[20]);
+/* Host-side preparation of everything a w x h render uploads: guard-box chains (fails on an open
+ * bracket) and the FP32 filter records.  Returns the number of guard boxes.  No device needed. */
+int  rt_scene_prepare_host(rt_scene *, int w, int h);
+/* Filter record of `leaf` for apex 0 (the eye) or 1 + k (the k-th point light), after
+ * rt_scene_prepare_host: out[0..11] as laid out in raytrace_amd/csrc/rt_types.h (FilterRec). */
+int  rt_scene_get_filter_record(const rt_scene *, int apex, int leaf, float out[12]);
+/* Guard chain of `leaf`: writes up to cap boxes {x0,y0,z0,x1,y1,z1}, innermost first; returns the count. */
+int  rt_scene_get_guards(const rt_scene *, int leaf, double *out, int cap);
 /* fixedCamera w h: out = {scaleX, scaleY, dX, dY, d}                      Main.hs:506-527 */
 int  rt_camera_params(int w, int h, double out[5]);
 

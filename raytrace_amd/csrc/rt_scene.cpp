@@ -476,6 +476,37 @@ int rt_scene_get_leaf(const rt_scene *s, int leaf, double out[20]) {
     return RT_OK;
 }
 
+int rt_scene_prepare_host(rt_scene *s, int w, int h) {
+    if (!s || w <= 0 || h <= 0) { set_error("rt_scene_prepare_host: bad argument"); return RT_ERR_ARG; }
+    if (!compute_guards(*s)) return RT_ERR_ARG;
+    build_filter_records(*s, w, h);
+    s->dirty = true;    // the device copy (if any) is stale
+    return (int)s->guards.size();
+}
+
+int rt_scene_get_filter_record(const rt_scene *s, int apex, int leaf, float out[12]) {
+    if (!s || !out || leaf < 0 || (size_t)leaf >= s->leaves.size() || apex < 0 || apex > s->npoint || s->rec_w < 0) {
+        set_error("rt_scene_get_filter_record: bad argument (call rt_scene_prepare_host first)"); return RT_ERR_ARG;
+    }
+    const LeafD &L = s->leaves[leaf];
+    const std::vector<FilterRec> &v = L.kind == LEAF_TRI ? s->tri_rec : s->rect_rec;
+    const size_t n = L.kind == LEAF_TRI ? s->tri_gid.size() : s->rect_gid.size();
+    std::memcpy(out, v[(size_t)apex * n + (size_t)L.slot].c, sizeof(float) * 12);
+    return RT_OK;
+}
+
+int rt_scene_get_guards(const rt_scene *s, int leaf, double *out, int cap) {
+    if (!s || leaf < 0 || (size_t)leaf >= s->leaves.size()) { set_error("rt_scene_get_guards: bad argument"); return RT_ERR_ARG; }
+    int n = 0;
+    for (int g = s->leaves[leaf].guard; g >= 0 && (size_t)g < s->guards.size(); g = s->guards[g].parent, ++n)
+        if (out && n < cap) {
+            const GuardD &G = s->guards[g];
+            const double b[6] = {G.x0, G.y0, G.z0, G.x1, G.y1, G.z1};
+            std::memcpy(out + 6 * n, b, sizeof b);
+        }
+    return n;
+}
+
 int rt_camera_params(int w, int h, double out[5]) {
     if (!out || w <= 0 || h <= 0) { set_error("rt_camera_params: bad argument"); return RT_ERR_ARG; }
     const CameraD c = fixed_camera(w, h);

@@ -1,0 +1,72 @@
+"""The N > 1 path on the CPU: two gloo ranks split an image into cost-balanced row bands, each renders its
+band (with the oracle standing in for the GPU), the bands are gathered to rank 0 with the same
+gather_bands() that bench.py uses over RCCL, and rank 0's image equals the single-process render."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from raytrace_amd.distributed import gather_bands, split_rows
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_split_rows_properties():
+    h = 2160
+    for n in (1, 2, 3, 4, 8):
+        cost = np.concatenate([np.ones(40), 5 * np.ones(55), np.ones(40)])
+        bands = split_rows(cost, h, n)
+        assert len(bands) == n and bands[0][0] == 0 and sum(nr for _, nr in bands) == h
+        for i in range(1, n):
+            assert bands[i][0] == bands[i - 1][0] + bands[i - 1][1] and bands[i][0] % 8 == 0 and bands[i][1] >= 8
+        if n > 1:   # balanced: no band costs more than 1.35x the mean
+            per_row = np.repeat(cost, h // len(cost))
+            costs = [per_row[r0:r0 + nr].sum() for r0, nr in bands]
+            assert max(costs) <= 1.35 * np.mean(costs)
+    assert split_rows([0, 0, 0], 64, 2) == [(0, 32), (32, 32)]
+    assert split_rows([1.0], 16, 2) == [(0, 8), (8, 8)]
+    with pytest.raises(ValueError):
+        split_rows([], 10, 2)
+
+
+def _worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_binding as ob
+    from raytrace_amd import scenes
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    w, h = 48, 40
+    wl, lights = scenes.stacked_cubes()
+    osc = ob.OracleScene(wl, lights)
+    # cost estimate from a coarse render, identical on every rank (deterministic)
+    coarse = osc.render(24, 20, nthreads=1)["hit_id"]
+    bands = split_rows(1.0 + 2.0 * (coarse >= 0).mean(axis=1), h, world)
+    r0, nr = bands[rank]
+    mine = torch.from_numpy(osc.render(w, h, row0=r0, nrows=nr, nthreads=1)["rgb"].copy())
+    frame = torch.zeros((h, w, 3), dtype=torch.uint8) if rank == 0 else None
+    if rank == 0:
+        frame[r0:r0 + nr] = mine
+    gather_bands(dist, frame, mine, bands, rank)
+    dist.barrier()
+    if rank == 0:
+        full = osc.render(w, h, nthreads=1)["rgb"]
+        np.save(out_path, np.array([int((frame.numpy() != full).sum()), len(bands)]))
+    dist.destroy_process_group()
+
+
+def test_two_rank_band_render_and_gather(tmp_path):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "res.npy")
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    res = np.load(out)
+    assert res[0] == 0 and res[1] == 2

@@ -1,0 +1,133 @@
+"""The FP32 filter must never reject a (ray, leaf) pair the reference accepts.  Checked on the CPU by
+evaluating the filter records (rt_scene_get_filter_record) in numpy float32, exactly as the kernels do
+(same operation order, fused multiply-adds emulated in float64-then-round), for every primary hit of the
+oracle — and, for the shadow filter, for hit points that the oracle says are occluded."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+from raytrace_amd import _lib, api, scenes
+
+
+def fma32(a, b, c):
+    return (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(np.float32)
+
+
+def records(sc, apex, w, h):
+    L = _lib.lib()
+    assert L.rt_scene_prepare_host(sc.handle, w, h) >= 0
+    out = (C.c_float * 12)()
+    recs = np.zeros((sc.num_leaves, 12), np.float32)
+    for i in range(sc.num_leaves):
+        assert L.rt_scene_get_filter_record(sc.handle, apex, i, out) == 0
+        recs[i] = np.frombuffer(out, np.float32)
+    kinds = np.array([int(sc.leaf(i)[0]) for i in range(sc.num_leaves)])
+    return recs, kinds
+
+
+def eye_z(rec, kind, px, py):
+    """filter4_eye of rt_kernels.hip for one leaf and arrays of pixels."""
+    q = []
+    for k in range(3):
+        b = fma32(np.float32(rec[3 * k + 1]) * np.ones_like(py), py, np.float32(rec[3 * k + 2]) * np.ones_like(py))
+        q.append(fma32(np.float32(rec[3 * k]) * np.ones_like(px), px, b))
+    if kind == 1:
+        return np.minimum(np.minimum(q[0], q[1]), q[2])
+    return (q[2] - np.maximum(np.abs(q[0]), np.abs(q[1]))).astype(np.float32)
+
+
+@pytest.mark.parametrize("name,w,h", [("default", 128, 128), ("stacked_cubes", 96, 96), ("cylinder_axes", 100, 80),
+                                      ("triangle_example", 120, 66), ("spec_test", 64, 64)])
+def test_eye_filter_accepts_every_oracle_hit(name, w, h):
+    world, lights = scenes.REFERENCE_SCENES[name]()
+    sc = api.Scene(world, lights)
+    recs, kinds = records(sc, 0, w, h)
+    cam = (C.c_double * 5)()
+    _lib.lib().rt_camera_params(w, h, cam)
+    hit = ob.OracleScene(world, lights).render(w, h, use_bbox=0)["hit_id"]
+    ys, xs = np.nonzero(hit >= 0)
+    px = (cam[0] * xs.astype(np.float64) + cam[2]).astype(np.float32)
+    py = (cam[1] * ys.astype(np.float64) + cam[3]).astype(np.float32)
+    ids = hit[ys, xs]
+    assert len(ids) > 100
+    for leaf in np.unique(ids):
+        m = ids == leaf
+        z = eye_z(recs[leaf], kinds[leaf], px[m], py[m])
+        assert (z >= recs[leaf][10]).all(), f"{name}: leaf {leaf} rejected by the FP32 filter"
+    sc.close()
+
+
+def test_eye_filter_is_selective():
+    """...and it is a filter: for the default scene far fewer than 1 % of (pixel, leaf) pairs pass."""
+    world, lights = scenes.default_scene()
+    w = h = 64
+    sc = api.Scene(world, lights)
+    recs, kinds = records(sc, 0, w, h)
+    cam = (C.c_double * 5)()
+    _lib.lib().rt_camera_params(w, h, cam)
+    ys, xs = np.mgrid[0:h, 0:w]
+    px = (cam[0] * xs.ravel().astype(np.float64) + cam[2]).astype(np.float32)
+    py = (cam[1] * ys.ravel().astype(np.float64) + cam[3]).astype(np.float32)
+    passed = sum(int((eye_z(recs[i], kinds[i], px, py) >= recs[i][10]).sum()) for i in range(sc.num_leaves))
+    assert passed < 0.01 * w * h * sc.num_leaves
+    sc.close()
+
+
+def test_light_filter_accepts_every_occluder():
+    """Shadow filter (apex = light, clip to the segment): every leaf that the oracle's exact test finds
+    between a hit point and the light must pass, for each such (pixel, light) of stacked_cubes."""
+    world, lights = scenes.stacked_cubes()
+    w = h = 64
+    sc = api.Scene(world, lights)
+    osc = ob.OracleScene(world, lights)
+    o = osc.render(w, h, use_bbox=0, want_t=True)
+    cam = (C.c_double * 5)()
+    _lib.lib().rt_camera_params(w, h, cam)
+    point_lights = [l for l in lights if isinstance(l, api.PointLight)]
+    leaves = [sc.leaf(i) for i in range(sc.num_leaves)]
+    checked = 0
+    for k, lt in enumerate(point_lights):
+        recs, kinds = records(sc, 1 + k, w, h)
+        for y in range(0, h, 3):
+            for x in range(0, w, 3):
+                if o["hit_id"][y, x] < 0:
+                    continue
+                ray = (C.c_double * 9)()
+                ob.lib().orc_camera_ray(w, h, x, y, ray)
+                p = np.array(ray[0:3]) + o["t"][y, x] * np.array(ray[3:6])
+                tl = np.array(lt.pos) - p
+                tl /= np.linalg.norm(tl)
+                org = p + 1e-5 * tl
+                dist = np.linalg.norm(np.array(lt.pos) - org)
+                D = (org - np.array(lt.pos)).astype(np.float32)
+                for i, lf in enumerate(leaves):
+                    if i == o["hit_id"][y, x]:
+                        continue
+                    n, d = np.array(lf[2:5]), lf[5]
+                    den = n @ tl
+                    if abs(den) < 1e-9:
+                        continue
+                    t = -(n @ org + d) / den
+                    if not (1e-7 < t < dist - 1e-7):
+                        continue
+                    q = org + t * tl - np.array(lf[6:9])
+                    e1, e2 = np.array(lf[9:12]), np.array(lf[12:15])
+                    if lf[0] == 0:
+                        a, b = q @ e1 / lf[15], q @ e2 / lf[16]
+                        inside = 1e-6 < a < 1 - 1e-6 and 1e-6 < b < 1 - 1e-6
+                    else:
+                        wv, wu = q @ e2, q @ e1
+                        r, s = (lf[15] * wv - lf[17] * wu) / lf[18], (lf[15] * wu - lf[16] * wv) / lf[18]
+                        inside = r > 1e-6 and s > 1e-6 and r + s < 1 - 1e-6
+                    if not inside:
+                        continue
+                    rec = recs[i]
+                    f = [np.float32(np.float64(rec[3 * j]) * D[0] + np.float64(rec[3 * j + 1]) * D[1] + np.float64(rec[3 * j + 2]) * D[2]) for j in range(3)]
+                    z = min(f[0], f[1], f[2] - f[0] - f[1]) if kinds[i] == 1 else f[2] - max(abs(f[0]), abs(f[1]))
+                    z = min(z, f[2] - rec[9])
+                    assert z >= rec[10], f"light {k} pixel ({x},{y}) leaf {i}: occluder rejected by the shadow filter"
+                    checked += 1
+    assert checked > 200
+    sc.close()

@@ -1,0 +1,161 @@
+"""Host logic of the product library, no GPU: the C ABI exports every declared symbol, the scene builder
+produces the reference's leaf order and constants, guard chains follow the mconcat/mappend tree, errors
+are reported like the reference reports them, and rendering without a GPU fails loudly."""
+import ctypes as C
+import math
+import os
+import re
+
+import numpy as np
+import pytest
+
+from raytrace_amd import _lib, api, scenes
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "raytrace_gpu.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(rt_[a-z_0-9]+)\s*\(", hdr))
+    assert len(declared) >= 25
+    L = _lib.lib()
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in include/raytrace_gpu.h but not exported"
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+
+
+def test_camera_params_match_known_answers():
+    out = (C.c_double * 5)()
+    assert _lib.lib().rt_camera_params(3840, 2160, out) == 0
+    assert list(out) == [0.00026041666666666666, -0.000146484375, -0.5, 0.158203125, math.tan(math.pi / 4) * -0.5]
+
+
+def test_cuboid_is_six_rectangles_in_reference_order_with_outward_normals():
+    sc = api.Scene(api.colorcuboid([api.red, api.green], (1.0, 2.0, -5.0), 2.0, 4.0, 6.0), [])
+    assert sc.num_leaves == 6
+    normals = [tuple(sc.leaf(i)[2:5]) for i in range(6)]
+    # top, bottom, front, back, left(+x), right(-x): Main.hs:308-320
+    assert normals == [(0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1), (1, 0, 0), (-1, 0, 0)]
+    assert [sc.leaf(i)[19] for i in range(6)] == [0, 1, 2, 3, 4, 5]       # one material record per face
+    top = sc.leaf(0)
+    assert top[0] == 0 and top[5] == -4.0                     # kind rect; d = -(point . normal) = -(2+2)
+    assert tuple(top[6:9]) == (0.0, 4.0, -2.0)                # point' = point - w/2 - h/2
+    assert (top[15], top[16]) == (4.0, 36.0)                  # ww, hh
+    sc.close()
+
+
+def test_triangle_constants_follow_the_reference():
+    pa, pb, pc = (0.0, 1.0, -4.0), (-1.0, 0.0, -4.0), (1.0, 0.0, -4.0)
+    sc = api.Scene(api.triangle(api.orange, pa, pb, pc), [])
+    leaf = sc.leaf(0)
+    u, v = np.subtract(pb, pa), np.subtract(pc, pa)
+    uv, uu, vv = float(u @ v), float(u @ u), float(v @ v)
+    assert leaf[0] == 1 and tuple(leaf[15:19]) == (uv, uu, vv, uv * uv - uu * vv)
+    n = np.cross(u, v)
+    assert np.allclose(leaf[2:5], n / np.linalg.norm(n), rtol=0, atol=1e-16)
+    sc.close()
+
+
+def test_cylinder_layout_and_quirks():
+    n = 8
+    sc = api.Scene(api.cylinder(api.blue, api.red, api.green, (0.0, -2.0, -10.0), n, 1.0, 5.0), [])
+    assert sc.num_leaves == 3 * n
+    kinds = [sc.leaf(i)[0] for i in range(3 * n)]
+    assert kinds == [1] * (2 * n) + [0] * n                   # bottom tris, top tris, mantle rects
+    modes = [sc.leaf(i)[1] for i in range(3 * n)]
+    assert modes == [0] * (2 * n) + [1] * n                   # mantle rectangles lerp their normal
+    # botPoint = point - (0, -h/2, 0) = the TOP centre (Main.hs:735): bottom triangles start at y = -1.5
+    assert sc.leaf(0)[7] == -1.5 and sc.leaf(n)[7] == -1.5
+    sc.close()
+
+
+def test_leaf_order_is_depth_first_and_matches_the_oracle_count():
+    import oracle_binding as ob
+    for name, mk in scenes.REFERENCE_SCENES.items():
+        world, lights = mk()
+        sc = api.Scene(world, lights)
+        assert sc.num_leaves == ob.OracleScene(world, lights).num_leaves, name
+        sc.close()
+
+
+def test_guard_chains_follow_the_tree():
+    L = _lib.lib()
+    a = api.rectangle(api.red, (0, 0, -2), (1, 0, 0), (0, 1, 0))
+    b = api.rectangle(api.green, (3, 0, -2), (1, 0, 0), (0, 1, 0))
+    # a single leaf has no mappend node above it
+    sc = api.Scene(a, [])
+    assert L.rt_scene_prepare_host(sc.handle, 64, 64) == 0
+    assert L.rt_scene_get_guards(sc.handle, 0, None, 0) == 0
+    sc.close()
+    # mconcat [a, b]: a sits under box(a u b); b under box(a u b) and box(b)
+    sc = api.Scene(api.mconcat([a, b]), [])
+    assert L.rt_scene_prepare_host(sc.handle, 64, 64) == 2
+    out = (C.c_double * 12)()
+    assert L.rt_scene_get_guards(sc.handle, 0, out, 2) == 1
+    assert list(out)[:6] == [-0.5, -0.5, -2.0, 3.5, 0.5, -2.0]
+    assert L.rt_scene_get_guards(sc.handle, 1, out, 2) == 2
+    assert list(out)[:6] == [2.5, -0.5, -2.0, 3.5, 0.5, -2.0] and list(out)[6:] == [-0.5, -0.5, -2.0, 3.5, 0.5, -2.0]
+    sc.close()
+    # a `mappend` b: one node, both children under the same box
+    sc = api.Scene(a + b, [])
+    assert L.rt_scene_prepare_host(sc.handle, 64, 64) == 1
+    assert L.rt_scene_get_guards(sc.handle, 0, None, 0) == 1 and L.rt_scene_get_guards(sc.handle, 1, None, 0) == 1
+    sc.close()
+
+
+def test_rotated_rectangle_box_uses_two_corners_only():
+    """Main.hs:243-245: the `intersection` scene's floor rectangle gets the too-small box."""
+    L = _lib.lib()
+    world, lights = scenes.intersection()
+    sc = api.Scene(world, lights)
+    L.rt_scene_prepare_host(sc.handle, 64, 64)
+    out = (C.c_double * 6)()
+    assert L.rt_scene_get_guards(sc.handle, sc.num_leaves - 1, out, 1) == 2
+    assert list(out) == [-1.5, -1.0, -3.5, 1.5, -1.0, -2.5]
+    sc.close()
+
+
+def test_errors_are_reported_not_thrown():
+    L = _lib.lib()
+    h = C.c_void_p()
+    assert L.rt_scene_create(C.byref(h)) == 0
+    assert L.rt_add_cuboid(h, (_lib.rt_material * 1)(), 0, _lib.vec3((0, 0, 0)), 1.0, 1.0, 1.0) == -1
+    assert b"list of materials must not be empty" in L.rt_last_error()          # Main.hs:302
+    assert L.rt_add_rectangle(h, None, None, None, None) == -1
+    assert L.rt_end_mconcat(h) == -1
+    assert L.rt_begin_mappend(h) == 0
+    assert L.rt_add_rectangle(h, C.byref(_lib.rt_material()), _lib.vec3((0, 0, -1)), _lib.vec3((1, 0, 0)), _lib.vec3((0, 1, 0))) == 0
+    assert L.rt_end_mappend(h) == -1 and b"exactly two" in L.rt_last_error()
+    assert L.rt_scene_prepare_host(h, 16, 16) == -1 and b"still open" in L.rt_last_error()
+    assert L.rt_set_normal_mode(h, 0, 5, 0, None, 0) == -1
+    assert L.rt_scene_get_leaf(h, 7, (C.c_double * 20)()) == -1
+    L.rt_scene_destroy(h)
+    with pytest.raises(ValueError):
+        api.colorcuboid([], (0, 0, 0), 1, 1, 1)
+
+
+def test_write_bmp(tmp_path):
+    img = np.zeros((3, 5, 3), np.uint8)
+    img[0, 0] = (255, 0, 0)
+    img[2, 4] = (0, 0, 255)
+    p = tmp_path / "t.bmp"
+    api.saveBmpImage(p, img)
+    raw = p.read_bytes()
+    assert raw[:2] == b"BM" and len(raw) == 54 + 16 * 3
+    assert int.from_bytes(raw[18:22], "little") == 5 and int.from_bytes(raw[22:26], "little") == 3
+    assert raw[28] == 24
+    # bottom-up BGR: the last row of the file is image row 0, whose first pixel is red
+    assert raw[54 + 32:54 + 35] == bytes([0, 0, 255])
+    assert raw[54 + 12:54 + 15] == bytes([255, 0, 0])
+
+
+def test_render_without_a_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    world, lights = scenes.planes()
+    sc = api.Scene(world, lights)
+    with pytest.raises(RuntimeError, match="no HIP device|hip"):
+        sc.render(16, 16)
+    sc.close()
