@@ -51,16 +51,17 @@ def balanced_bands(scene, w, h, n, depth):
     return split_rows(cost, h, n)
 
 
-def cpu_baseline(world, lights, w, h, depth, seconds=15.0):
+def cpu_baseline(world, lights, w, h, depth, seconds=18.0):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_binding as ob
     cores = min(16, os.cpu_count() or 1)
     osc = ob.OracleScene(world, lights)
     row0 = h // 2 - 1
+    osc.render(w, h, depth=depth, row0=row0, nrows=1, nthreads=1)       # first call numbers the leaves
     t0 = time.perf_counter()
-    osc.render(w, h, depth=depth, row0=row0, nrows=2, nthreads=cores)
+    osc.render(w, h, depth=depth, row0=row0, nrows=2, nthreads=2)       # calibration: 2 rows on 2 threads
     dt = time.perf_counter() - t0
-    nrows = int(max(2, min(h // 4, 2 * seconds / max(dt, 1e-6))))
+    nrows = int(max(cores, min(h // 2, cores * seconds / max(dt, 1e-6))))
     nrows -= nrows % 2
     row0 = h // 2 - nrows // 2
     t0 = time.perf_counter()

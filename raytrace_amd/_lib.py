@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libraytrace_gpu.so")
+# RT_LIB selects another build of the same library (A/B runs of kernel variants); never a different backend
+LIB_PATH = os.environ.get("RT_LIB") or os.path.join(_HERE, "lib", "libraytrace_gpu.so")
 
 
 class rt_material(C.Structure):

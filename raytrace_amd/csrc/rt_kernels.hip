@@ -28,10 +28,26 @@
 using namespace rt;
 
 typedef float f2 __attribute__((ext_vector_type(2)));
+// Wave-uniform, read-only scene data is addressed through the constant address space, which makes
+// hipcc fetch it with scalar loads (s_load_dwordx8 ...) no matter what else the kernel stores.
+#define RT_CONST __attribute__((address_space(4)))
+typedef const rt::FilterRec RT_CONST *CRecPtr;
+typedef const int32_t RT_CONST *CIntPtr;
 
 #define RT_TILE_W 32
 #define RT_TILE_H 8
 #define RT_WAVES_PER_BLOCK 4
+#ifndef RT_PREFETCH
+#define RT_PREFETCH 1          // double-buffer the leaf records in SGPRs
+#endif
+// occupancy (waves per SIMD) the register allocator must reach for the two brute-force kernels
+#ifndef RT_WAVES_EU_PRIMARY
+#define RT_WAVES_EU_PRIMARY 8
+#endif
+#ifndef RT_WAVES_EU_SHADOW
+#define RT_WAVES_EU_SHADOW 6
+#endif
+#define RT_HOT(n) __attribute__((amdgpu_waves_per_eu(n, 8))) __launch_bounds__(RT_WAVES_PER_BLOCK * 64)
 
 namespace {
 
@@ -167,6 +183,15 @@ __device__ __forceinline__ bool guards_ok(const GuardD *__restrict__ G, int g, c
 // ------------------------------------------------------------------------------------------
 // FP32 filter: 4 rays of one lane against one leaf record (wave-uniform -> SGPR operands)
 
+__device__ __forceinline__ CRecPtr as_const(const FilterRec *p) { return (CRecPtr)(const void *)p; }
+__device__ __forceinline__ CIntPtr as_const(const int32_t *p) { return (CIntPtr)(const void *)p; }
+__device__ __forceinline__ FilterRec load_rec(CRecPtr p) {
+    FilterRec r;
+#pragma unroll
+    for (int k = 0; k < 11; ++k) r.c[k] = p->c[k];
+    r.c[11] = 0.f;
+    return r;
+}
 __device__ __forceinline__ f2 splat(float v) { f2 r = {v, v}; return r; }
 __device__ __forceinline__ f2 pkfma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 
@@ -254,16 +279,26 @@ __device__ __forceinline__ void tile_coords(const RenderParams &P, int &x0, int 
 //   (0, 0, -d)), D = (posX, posY, d).
 
 template <int KIND, bool SHARED_Y>
-__device__ __forceinline__ void primary_loop(const RenderParams &P, const FilterRec *__restrict__ recs,
-                                             const int32_t *__restrict__ gids, int n, const Eye4 &D,
+__device__ __forceinline__ void primary_loop(const RenderParams &P, CRecPtr recs, CIntPtr gids, int n, const Eye4 &D,
                                              const bool act[4], int x0, int y, double bt[4], int bid[4],
                                              unsigned &nexact) {
+    if (n <= 0) return;
+    FilterRec cur = load_rec(recs);
     for (int i = 0; i < n; ++i) {
+#if RT_PREFETCH
+        const FilterRec nxt = load_rec(recs + i + 1);     // scalar loads of the next leaf fly during this one (arrays are padded)
+#else
+        cur = load_rec(recs + i);
+#endif
         float z[4];
-        if (filter4_eye<KIND, SHARED_Y>(recs[i], D, z)) {
+        const bool any = filter4_eye<KIND, SHARED_Y>(cur, D, z);
+        const float negm = cur.c[10];
+#if RT_PREFETCH
+        cur = nxt;
+#endif
+        if (any) {
             const int gid = gids[i];
             const LeafD &L = P.leaves[gid];
-            const float negm = recs[i].c[10];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 if ((z[r] >= negm) & act[r]) {
@@ -283,7 +318,7 @@ __device__ __forceinline__ void primary_loop(const RenderParams &P, const Filter
 }
 
 template <bool SHARED_Y>
-__global__ void __launch_bounds__(RT_WAVES_PER_BLOCK * 64) k_primary(const RenderParams P) {
+__global__ void RT_HOT(RT_WAVES_EU_PRIMARY) k_primary(const RenderParams P) {
     int x0, y; bool row_ok;
     tile_coords(P, x0, y, row_ok);
     bool act[4];
@@ -309,8 +344,8 @@ __global__ void __launch_bounds__(RT_WAVES_PER_BLOCK * 64) k_primary(const Rende
 #pragma unroll
     for (int r = 0; r < 4; ++r) { bt[r] = INFINITY; bid[r] = -1; }
     unsigned nexact = 0;
-    primary_loop<LEAF_TRI, SHARED_Y>(P, P.tri_rec, P.tri_gid, P.ntri, D, act, x0, y, bt, bid, nexact);
-    primary_loop<LEAF_RECT, SHARED_Y>(P, P.rect_rec, P.rect_gid, P.nrect, D, act, x0, y, bt, bid, nexact);
+    primary_loop<LEAF_TRI, SHARED_Y>(P, as_const(P.tri_rec), as_const(P.tri_gid), P.ntri, D, act, x0, y, bt, bid, nexact);
+    primary_loop<LEAF_RECT, SHARED_Y>(P, as_const(P.rect_rec), as_const(P.rect_gid), P.nrect, D, act, x0, y, bt, bid, nexact);
     const long long row = P.out_off + (long long)(y - P.row0) * P.w;
 #pragma unroll
     for (int r = 0; r < 4; ++r)
@@ -399,15 +434,25 @@ __global__ void __launch_bounds__(256) k_setup(const RenderParams P) {
 //   Apex = the light, D = shadow-ray origin - light; the filter's clip keeps leaves between them.
 
 template <int KIND>
-__device__ __forceinline__ void shadow_loop(const RenderParams &P, const FilterRec *__restrict__ recs,
-                                            const int32_t *__restrict__ gids, int n, const Dir4 &D,
+__device__ __forceinline__ void shadow_loop(const RenderParams &P, CRecPtr recs, CIntPtr gids, int n, const Dir4 &D,
                                             const uint32_t pix[4], const LightD &Lt, bool need[4], unsigned &nexact) {
+    if (n <= 0) return;
+    FilterRec cur = load_rec(recs);
     for (int i = 0; i < n; ++i) {
+#if RT_PREFETCH
+        const FilterRec nxt = load_rec(recs + i + 1);     // scalar loads of the next leaf fly during this one (arrays are padded)
+#else
+        cur = load_rec(recs + i);
+#endif
         float z[4];
-        if (filter4<KIND, true>(recs[i], D, z)) {
+        const bool any = filter4<KIND, true>(cur, D, z);
+        const float negm = cur.c[10];
+#if RT_PREFETCH
+        cur = nxt;
+#endif
+        if (any) {
             const int gid = gids[i];
             const LeafD &L = P.leaves[gid];
-            const float negm = recs[i].c[10];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 if ((z[r] >= negm) & need[r]) {
@@ -433,7 +478,7 @@ __device__ __forceinline__ void shadow_loop(const RenderParams &P, const FilterR
     }
 }
 
-__global__ void __launch_bounds__(RT_WAVES_PER_BLOCK * 64) k_shadow(const RenderParams P) {
+__global__ void RT_HOT(RT_WAVES_EU_SHADOW) k_shadow(const RenderParams P) {
     const int pl = (int)blockIdx.y;
     const unsigned count = P.qcount[pl];
     const unsigned wave = blockIdx.x * RT_WAVES_PER_BLOCK + (threadIdx.x >> 6);
@@ -469,9 +514,10 @@ __global__ void __launch_bounds__(RT_WAVES_PER_BLOCK * 64) k_shadow(const Render
         D.z[p] = f2{ddz[2 * p], ddz[2 * p + 1]};
     }
     unsigned nexact = 0;
-    const size_t ro = (size_t)Lt.rec_offset;
-    shadow_loop<LEAF_TRI>(P, P.tri_rec + ro * (size_t)P.ntri, P.tri_gid, P.ntri, D, pix, Lt, need, nexact);
-    shadow_loop<LEAF_RECT>(P, P.rect_rec + ro * (size_t)P.nrect, P.rect_gid, P.nrect, D, pix, Lt, need, nexact);
+    // wave-uniform by construction; say so, or the record loads become per-lane vector loads
+    const size_t ro = (size_t)__builtin_amdgcn_readfirstlane(Lt.rec_offset);
+    shadow_loop<LEAF_TRI>(P, as_const(P.tri_rec + ro * (size_t)P.ntri), as_const(P.tri_gid), P.ntri, D, pix, Lt, need, nexact);
+    shadow_loop<LEAF_RECT>(P, as_const(P.rect_rec + ro * (size_t)P.nrect), as_const(P.rect_gid), P.nrect, D, pix, Lt, need, nexact);
 #pragma unroll
     for (int r = 0; r < 4; ++r)
         if (need[r]) atomicOr(&P.lit[pix[r]], 1u << pl);

@@ -283,8 +283,9 @@ bool compute_guards(rt_scene &s) {
 void build_filter_records(rt_scene &s, int w, int h) {
     const size_t ntri = s.tri_gid.size(), nrect = s.rect_gid.size();
     const int napex = 1 + s.npoint;
-    s.tri_rec.assign(ntri * (size_t)napex, FilterRec{});
-    s.rect_rec.assign(nrect * (size_t)napex, FilterRec{});
+    // one record of padding: the kernels prefetch record i + 1 while testing record i
+    s.tri_rec.assign(ntri * (size_t)napex + 1, never_rec());
+    s.rect_rec.assign(nrect * (size_t)napex + 1, never_rec());
     // scene extent (leaf corners), for the per-light bound on |D| = |hit - light|
     double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
     for (const LeafD &L : s.leaves) {

@@ -17,9 +17,9 @@ def main(path):
     for name, n, tot, avg, mn, mx in rows:
         print(f"{name[:60]:60s} {n:6d} {tot / 1e6:10.3f} {avg / 1e6:10.4f} {mn / 1e6:10.4f} {mx / 1e6:10.4f} {100 * tot / total:6.2f}")
     try:
-        pm = list(c.execute("select k.name, p.counter_name, count(*), sum(p.value) from pmc_events p "
-                            "join kernels k on k.dispatch_id = p.dispatch_id group by k.name, p.counter_name "
-                            "order by k.name, p.counter_name"))
+        # one row per (dispatch, counter, dimension instance): sum the instances, then average over dispatches
+        pm = list(c.execute("select kernel_name, counter_name, count(distinct dispatch_id), sum(value) "
+                            "from counters_collection group by kernel_name, counter_name order by kernel_name, counter_name"))
     except sqlite3.Error as e:
         pm = []
         print(f"# (no counters: {e})")
