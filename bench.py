@@ -36,6 +36,11 @@ from raytrace_amd.distributed import gather_bands, split_rows  # noqa: E402
 
 FLOPS_TRI, FLOPS_RECT = 52 + 1, 44 + 1
 PEAK_FP32_TFLOPS = 157.3                        # MI355X_MICROARCH.md: peak FP32 (vector), packed FMA
+# HBM bytes of one k_shadow launch on the default N = 1 workload, from the PMC passes committed under
+# profiles/ (r01_pmc_rd / r01_pmc_wr: FETCH_SIZE and WRITE_SIZE are in KiB and are summed as reported;
+# the guide's x2 correction applies to 16-B-per-lane streaming reads only, which this kernel has none of).
+# The counters cannot be read from inside this process; for any other workload traffic is null.
+K_SHADOW_TRAFFIC_BYTES_DEFAULT = (329533 + 24400) * 1024
 
 
 def balanced_bands(scene, w, h, n, depth):
@@ -84,6 +89,9 @@ def main():
     ap.add_argument("--ncuboid", type=int, default=1000)
     ap.add_argument("--depth", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the measured path) or gloo (rehearsal on one GPU)")
+    ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank renders on GPU 0 (gloo only)")
+    ap.add_argument("--verify", action="store_true", help="rank 0 re-renders the whole frame alone and compares it with the gathered one")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -94,12 +102,20 @@ def main():
         raise SystemExit(f"--gpus {n} but WORLD_SIZE={world_size}: launch with torch.distributed.run --nproc-per-node {n}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the render path has no CPU fallback")
+    if args.same_device:
+        if args.dist_backend != "gloo":
+            raise SystemExit("--same-device is a rehearsal mode and needs --dist-backend gloo (RCCL refuses two ranks on one GPU)")
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if n > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)           # RCCL
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)       # RCCL over xGMI
+        else:
+            dist.init_process_group("gloo")
+    staged = n > 1 and args.dist_backend != "nccl"               # gloo rehearsal: bands travel through host memory
     _lib.check(_lib.lib().rt_init(local_rank), "rt_init")
 
     w = args.width or (3840 if n == 1 else 16384)
@@ -118,10 +134,19 @@ def main():
 
     def step():
         scene.render_device(w, h, mine.data_ptr(), hit.data_ptr(), depth=args.depth, row0=row0, nrows=nrows, stream=stream)
-        if n > 1:   # row bands -> GPU 0 (ncclSend/ncclRecv in one group: every peer has a direct xGMI link)
+        if n > 1 and not staged:   # row bands -> GPU 0 (ncclSend/ncclRecv in one group: every peer has a direct xGMI link)
             gather_bands(dist, frame, mine, bands, rank)
+        elif staged:
+            torch.cuda.synchronize()
+            host_band = mine.cpu()
+            host_frame = torch.empty((h, w, 4), dtype=torch.uint8) if rank == 0 else None
+            gather_bands(dist, host_frame, host_band, bands, rank)
+            if rank == 0:
+                host_frame[row0:row0 + nrows] = host_band
+                frame.copy_(host_frame)
 
     def sync():
+        torch.cuda.synchronize()
         if n > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -140,14 +165,24 @@ def main():
     dt = time.perf_counter() - t0
     if n > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        if staged:
+            tmax = tmax.cpu()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     stats = scene.stats()
     counts = torch.tensor([stats["primary_rays"], stats["shadow_rays"], stats["exact_evals"]], dtype=torch.float64, device=dev)
     shade_t = torch.tensor([stats["ms_shadow"], stats["ms_primary"]], dtype=torch.float64, device=dev)
     if n > 1:
+        if staged:
+            counts, shade_t = counts.cpu(), shade_t.cpu()
         dist.all_reduce(counts)
         dist.all_reduce(shade_t, op=dist.ReduceOp.MAX)
+    verified = None
+    if args.verify and rank == 0:
+        alone = torch.empty((h, w, 4), dtype=torch.uint8, device=dev)
+        scene.render_device(w, h, alone.data_ptr(), None, depth=args.depth, stream=stream)
+        torch.cuda.synchronize()
+        verified = bool(torch.equal(alone, frame))
     if rank == 0:
         primary, shadow, exact = (float(c) for c in counts.tolist())
         ms_step = dt / args.steps * 1e3
@@ -164,14 +199,16 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"synthetic {ntri} triangles + {args.ncuboid} cuboids ({ntri + nrect} leaves), 4 point lights + ambient, "
                                    f"{w}x{h}, depth {args.depth}, spp 1, brute force"
-                                   + (f", {n} cost-balanced row bands gathered to GPU 0 over RCCL" if n > 1 else ""),
+                                   + (f", {n} cost-balanced row bands gathered to GPU 0 over " + ("RCCL" if not staged else "gloo via host memory (rehearsal)") if n > 1 else ""),
                        "width": w, "height": h, "leaves": ntri + nrect, "lights": 4,
-                       "bands": bands if n > 1 else None,
+                       "bands": bands if n > 1 else None, "gathered_frame_equals_single_render": verified,
                        "shadow_rays_per_frame": shadow, "exact_fp64_evals_per_frame": exact,
                        "whole_frame_algorithmic_tflops": (primary + shadow) * per_test / (dt / args.steps) / 1e12,
                        "kernel_ms": {"k_primary": ms_prim, "k_setup": stats["ms_setup"], "k_shadow": ms_shade, "k_final": stats["ms_final"]}},
             "roofline": {"bound": "valu_fp32", "kernel": "k_shadow", "achieved": achieved, "peak": PEAK_FP32_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS, "traffic": None,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS,
+                         "traffic": K_SHADOW_TRAFFIC_BYTES_DEFAULT if (n == 1 and (w, h, ntri, nrect) == (3840, 2160, 10000, 6000)) else None,
+                         "traffic_unit": "bytes per launch (rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE, profiles/r01_pmc_*)",
                          "note": "algorithmic flops (53/45 per ray x triangle/rectangle test) x shadow rays cast x leaves, per launch"},
         }
         if n == 1 and not args.no_cpu_baseline:
