@@ -70,6 +70,15 @@ struct RenderParams {
     uint32_t *queue;                // npoint blocks of qcap shadow jobs (chunk pixel indices)
     unsigned *qcount;               // shadow jobs per point light
     uint32_t *lit;                  // per chunk pixel: bit l set = point light l reaches it
+    // bounce levels (reflective scenes, trace depth > 1; Main.hs:546-556).  A "slot" is a pixel of the chunk at
+    // level 0 and an entry of the level's ray list above it.
+    const RayRec *rays;             // this level's rays (nullptr at level 0: camera rays)
+    const unsigned *count_ptr;      // number of slots of this level (nullptr at level 0: qcap)
+    RayRec *next_rays;              // where k_final appends the reflected rays (nullptr: none)
+    unsigned *next_count;
+    uint32_t *colour;               // per-slot colour of this level (nullptr: write RGBA8 / accum directly)
+    const GenRec *gen_tri;          // general-ray filter records
+    const GenRec *gen_rect;
     CameraD cam;
     double eps;
     int ntri, nrect, nlights, nleaves, npoint;
@@ -128,6 +137,21 @@ __device__ __forceinline__ RayD camera_ray(const RenderParams &P, int x, int y) 
     const double posY = P.cam.scaleY * ((double)y + oy) + P.cam.dY;
     const double n = sqrt(posX * posX + posY * posY + P.cam.d * P.cam.d);
     return mkray(posX, posY, 0.0, posX / n, posY / n, P.cam.d / n, P.eps);
+}
+
+__device__ __forceinline__ unsigned num_slots(const RenderParams &P) {
+    if (!P.count_ptr) return (unsigned)P.qcap;
+    const unsigned c = *P.count_ptr;
+    return c < (unsigned)P.qcap ? c : (unsigned)P.qcap;
+}
+// the ray of a slot: `cast camera x y` at level 0, `mkray (ipos + 1e-5 rdir) rdir` (Main.hs:552) above
+__device__ __forceinline__ RayD slot_ray(const RenderParams &P, int slot) {
+    if (P.rays) {
+        const RayRec R = P.rays[slot];
+        return mkray(R.ox, R.oy, R.oz, R.dx, R.dy, R.dz, P.eps);
+    }
+    const int ly = slot / P.w;
+    return camera_ray(P, slot - ly * P.w, P.row0 + ly);
 }
 
 // planeRayIsect + the inside test of rectangle (Main.hs:234-242) / triangle (Main.hs:374-383).
@@ -368,13 +392,12 @@ __device__ __forceinline__ void to_light(const LightD &Lt, double hx, double hy,
 
 __global__ void __launch_bounds__(256) k_setup(const RenderParams P) {
     const int pix = (int)(blockIdx.x * 256 + threadIdx.x);
-    const bool act = pix < P.qcap;
-    const int ly = act ? pix / P.w : 0, x = act ? pix - ly * P.w : 0, y = P.row0 + ly;
+    const bool act = (unsigned)pix < num_slots(P);
     const int id = act ? P.hit_id[P.out_off + pix] : -1;
     HitRec H = {0, 0, 0, 0, 0, 0};
     if (id >= 0) {
         const LeafD L = P.leaves[id];
-        const RayD ray = camera_ray(P, x, y);
+        const RayD ray = slot_ray(P, pix);
         double ix = 0, iy = 0, iz = 0, t;
         if (L.kind == LEAF_RECT) leaf_isect<LEAF_RECT>(L, ray, ix, iy, iz, t);
         else leaf_isect<LEAF_TRI>(L, ray, ix, iy, iz, t);
@@ -539,14 +562,16 @@ __device__ __forceinline__ double hs_max0(double v) { return 0.0 <= v ? v : 0.0;
 
 __global__ void __launch_bounds__(256) k_final(const RenderParams P) {
     const int pix = (int)(blockIdx.x * 256 + threadIdx.x);
-    if (pix >= P.qcap) return;
-    const int ly = pix / P.w, x = pix - ly * P.w, y = P.row0 + ly;
-    const int id = P.hit_id[P.out_off + pix];
+    const bool act = (unsigned)pix < num_slots(P);
+    const int id = act ? P.hit_id[P.out_off + pix] : -1;
     int cr = 0, cg = 0, cb = 0;
+    bool spawn = false;
+    RayRec child = {0, 0, 0, 0, 0, 0, 0, 0u, 0u};
     if (id >= 0) {
         const MaterialD M = P.mats[P.leaves[id].mat];
         const HitRec H = P.hitrec[pix];
         const uint32_t lit = P.lit[pix];
+        const RayD ray = slot_ray(P, pix);
         int pl = 0;
         for (int li = 0; li < P.nlights; ++li) {
             const LightD &Lt = P.lights[li];
@@ -557,7 +582,6 @@ __global__ void __launch_bounds__(256) k_final(const RenderParams P) {
                 continue;
             }
             if ((lit >> pl) & 1u) {                                                    // lit: Main.hs:476-487
-                const RayD ray = camera_ray(P, x, y);
                 double tx, ty, tz;
                 to_light(Lt, H.px, H.py, H.pz, tx, ty, tz);
                 const double lndot = tx * H.nx + ty * H.ny + tz * H.nz;
@@ -572,13 +596,167 @@ __global__ void __launch_bounds__(256) k_final(const RenderParams P) {
             }
             ++pl;
         }
+        if (P.next_rays) {                                                             // reflection, Main.hs:546-556
+            const double r = H.nx * ray.dx + H.ny * ray.dy + H.nz * ray.dz;            // :549
+            if (M.reflectivity > 0 && r < 0) {                                         // :553
+                const double k2 = 2 * r;
+                const double qx = ray.dx - k2 * H.nx, qy = ray.dy - k2 * H.ny, qz = ray.dz - k2 * H.nz;   // rdir, :550
+                child.ox = H.px + 0.00001 * qx; child.oy = H.py + 0.00001 * qy; child.oz = H.pz + 0.00001 * qz;   // :552
+                child.dx = qx; child.dy = qy; child.dz = qz;
+                child.rho = M.reflectivity; child.parent = (uint32_t)pix;
+                spawn = true;
+            }
+        }
     }
-    if (P.rgba) {
-        reinterpret_cast<uint32_t *>(P.rgba)[P.out_off + pix] =
-            (uint32_t)cr | ((uint32_t)cg << 8) | ((uint32_t)cb << 16) | 0xff000000u;   // 256 B per wave, coalesced
+    if (P.next_rays) {          // append the reflected rays, one atomic per wave
+        const int lane = (int)(threadIdx.x & 63);
+        const unsigned long long m = __ballot(spawn);
+        if (m) {
+            const int leader = __ffsll((long long)m) - 1;
+            unsigned base = 0;
+            if (lane == leader) base = atomicAdd(P.next_count, (unsigned)__popcll(m));
+            base = __shfl(base, leader);
+            if (spawn) P.next_rays[base + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = child;
+        }
+    }
+    if (!act) return;
+    const uint32_t rgb = (uint32_t)cr | ((uint32_t)cg << 8) | ((uint32_t)cb << 16);
+    if (P.colour) {
+        P.colour[pix] = rgb;
+    } else if (P.rgba) {
+        reinterpret_cast<uint32_t *>(P.rgba)[P.out_off + pix] = rgb | 0xff000000u;     // 256 B per wave, coalesced
     } else {
         uint32_t *a = P.accum + 3 * (P.out_off + pix);
         a[0] += (uint32_t)cr; a[1] += (uint32_t)cg; a[2] += (uint32_t)cb;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Reflected rays (bounce levels >= 1): nearest hit of rays with arbitrary origins.
+//   replaces `intersect world reflected` inside trace (n-1) (Main.hs:543, 552-554).
+
+typedef const rt::GenRec RT_CONST *CGenPtr;
+__device__ __forceinline__ CGenPtr as_const(const GenRec *p) { return (CGenPtr)(const void *)p; }
+struct Ray4 { f2 ox[2], oy[2], oz[2], dx[2], dy[2], dz[2]; };
+
+// z[r] >= negm  <=>  ray r may hit the leaf.  q_k*a = e_k*a - b*f_k and t*a = -b must all carry the sign of a.
+template <int KIND>
+__device__ __forceinline__ bool filter4_gen(CGenPtr R, const Ray4 &G, float z[4]) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const f2 a = pkfma(splat(R->c[0]), G.dx[p], pkfma(splat(R->c[1]), G.dy[p], splat(R->c[2]) * G.dz[p]));
+        const f2 b = pkfma(splat(R->c[0]), G.ox[p], pkfma(splat(R->c[1]), G.oy[p], pkfma(splat(R->c[2]), G.oz[p], splat(R->c[3]))));
+        const f2 e1 = pkfma(splat(R->c[4]), G.ox[p], pkfma(splat(R->c[5]), G.oy[p], pkfma(splat(R->c[6]), G.oz[p], splat(R->c[7]))));
+        const f2 f1 = pkfma(splat(R->c[4]), G.dx[p], pkfma(splat(R->c[5]), G.dy[p], splat(R->c[6]) * G.dz[p]));
+        const f2 e2 = pkfma(splat(R->c[8]), G.ox[p], pkfma(splat(R->c[9]), G.oy[p], pkfma(splat(R->c[10]), G.oz[p], splat(R->c[11]))));
+        const f2 f2_ = pkfma(splat(R->c[8]), G.dx[p], pkfma(splat(R->c[9]), G.dy[p], splat(R->c[10]) * G.dz[p]));
+        const f2 u = pkfma(e1, a, -(b * f1));
+        const f2 v = pkfma(e2, a, -(b * f2_));
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (KIND == LEAF_TRI) {
+                const float w = a[k] - u[k] - v[k], t = -b[k];
+                const float lo = __builtin_fminf(__builtin_fminf(__builtin_fminf(u[k], v[k]), w), t);
+                const float hi = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(u[k], v[k]), w), t);
+                z[2 * p + k] = __builtin_fmaxf(lo, -hi);
+            } else {
+                const float q = __builtin_fabsf(a[k]) - __builtin_fmaxf(__builtin_fabsf(u[k]), __builtin_fabsf(v[k]));
+                z[2 * p + k] = __builtin_fminf(q, -(b[k] * a[k]));
+            }
+        }
+    }
+    const float mx = __builtin_fmaxf(__builtin_fmaxf(z[0], z[1]), __builtin_fmaxf(z[2], z[3]));
+    return mx >= R->c[12];
+}
+
+template <int KIND>
+__device__ __forceinline__ void general_loop(const RenderParams &P, CGenPtr recs, CIntPtr gids, int n, const Ray4 &G,
+                                             const bool act[4], const uint32_t slot[4], double bt[4], int bid[4], unsigned &nexact) {
+    for (int i = 0; i < n; ++i) {
+        float z[4];
+        if (filter4_gen<KIND>(recs + i, G, z)) {
+            const int gid = gids[i];
+            const LeafD &L = P.leaves[gid];
+            const float negm = recs[i].c[12];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if ((z[r] >= negm) & act[r]) {
+                    uint32_t sr = slot[r];
+                    asm volatile("" : "+v"(sr));
+                    const RayD ray = slot_ray(P, (int)sr);
+                    double ix, iy, iz, t;
+                    ++nexact;
+                    if (leaf_isect<KIND>(L, ray, ix, iy, iz, t) && guards_ok(P.guards, L.guard, ray)) {
+                        if (t < bt[r] || (t == bt[r] && gid < bid[r]) || bid[r] < 0) { bt[r] = t; bid[r] = gid; }
+                    }
+                }
+            }
+        }
+    }
+}
+
+__global__ void RT_HOT(4) k_general(const RenderParams P) {
+    const unsigned count = num_slots(P);
+    const unsigned wave = blockIdx.x * RT_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (wave * 256u >= count) return;
+    const int lane = (int)(threadIdx.x & 63);
+    uint32_t slot[4]; bool act[4];
+    float o[3][4], d[3][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        slot[r] = wave * 256u + (unsigned)(r * 64 + lane);
+        act[r] = slot[r] < count;
+        if (!act[r]) slot[r] = 0u;
+        const RayD ray = slot_ray(P, (int)slot[r]);
+        o[0][r] = (float)ray.px; o[1][r] = (float)ray.py; o[2][r] = (float)ray.pz;
+        d[0][r] = (float)ray.dx; d[1][r] = (float)ray.dy; d[2][r] = (float)ray.dz;
+    }
+    Ray4 G;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        G.ox[p] = f2{o[0][2 * p], o[0][2 * p + 1]}; G.oy[p] = f2{o[1][2 * p], o[1][2 * p + 1]}; G.oz[p] = f2{o[2][2 * p], o[2][2 * p + 1]};
+        G.dx[p] = f2{d[0][2 * p], d[0][2 * p + 1]}; G.dy[p] = f2{d[1][2 * p], d[1][2 * p + 1]}; G.dz[p] = f2{d[2][2 * p], d[2][2 * p + 1]};
+    }
+    double bt[4]; int bid[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { bt[r] = INFINITY; bid[r] = -1; }
+    unsigned nexact = 0;
+    general_loop<LEAF_TRI>(P, as_const(P.gen_tri), as_const(P.tri_gid), P.ntri, G, act, slot, bt, bid, nexact);
+    general_loop<LEAF_RECT>(P, as_const(P.gen_rect), as_const(P.rect_gid), P.nrect, G, act, slot, bt, bid, nexact);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (act[r]) P.hit_id[P.out_off + slot[r]] = bid[r];
+    for (int o2 = 32; o2 > 0; o2 >>= 1) nexact += __shfl_down(nexact, o2);
+    if (lane == 0 && nexact) atomicAdd(&P.counters[1], (unsigned long long)nexact);
+}
+
+// colour of a level folded into the level below: addPixelRGB8 direct (scalePixelRGB8 reflectivity sub), Main.hs:545, 554
+__global__ void __launch_bounds__(256) k_combine(const RayRec *__restrict__ rays, const uint32_t *__restrict__ col,
+                                                 const unsigned *__restrict__ count, unsigned cap, uint32_t *__restrict__ parent_col) {
+    const unsigned i = blockIdx.x * 256 + threadIdx.x;
+    const unsigned n = *count < cap ? *count : cap;
+    if (i >= n) return;
+    const RayRec R = rays[i];
+    const uint32_t c = col[i], pc = parent_col[R.parent];
+    uint32_t out = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int sub = round8(R.rho * (double)((c >> (8 * k)) & 255u));
+        const int sum = (int)((pc >> (8 * k)) & 255u) + sub;
+        out |= (uint32_t)(sum > 255 ? 255 : sum) << (8 * k);
+    }
+    parent_col[R.parent] = out;
+}
+
+// level-0 colours -> RGBA8 (spp == 1) or the sample accumulator
+__global__ void __launch_bounds__(256) k_store(const RenderParams P) {
+    const int pix = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (pix >= P.qcap) return;
+    const uint32_t rgb = P.colour[pix];
+    if (P.rgba) reinterpret_cast<uint32_t *>(P.rgba)[P.out_off + pix] = rgb | 0xff000000u;
+    else {
+        uint32_t *a = P.accum + 3 * (P.out_off + pix);
+        a[0] += rgb & 255u; a[1] += (rgb >> 8) & 255u; a[2] += (rgb >> 16) & 255u;
     }
 }
 
@@ -638,6 +816,10 @@ int prepare(rt_scene &s, int w, int h) {
         if ((rc = upload(s.dev.lights, s.lights))) return rc;
         if ((rc = upload(s.dev.tri_rec, s.tri_rec))) return rc;
         if ((rc = upload(s.dev.rect_rec, s.rect_rec))) return rc;
+        if (s.reflective) {
+            if ((rc = upload(s.dev.gen_tri, s.gen_tri))) return rc;
+            if ((rc = upload(s.dev.gen_rect, s.gen_rect))) return rc;
+        }
         if ((rc = upload(s.dev.tri_gid, s.tri_gid))) return rc;
         if ((rc = upload(s.dev.rect_gid, s.rect_gid))) return rc;
         if (!s.dev.counters) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s.dev.counters), 8 * sizeof(unsigned long long)));
@@ -686,8 +868,13 @@ void rt_scene_destroy(rt_scene *s) {
     if (!s) return;
     DeviceScene &d = s->dev;
     void *ptrs[] = {d.leaves, d.aux, d.guards, d.mats, d.lights, d.tri_rec, d.rect_rec, d.tri_gid, d.rect_gid,
-                    d.counters, d.qcount, d.hit_id, d.accum, d.rgba, d.hitrec, d.queue, d.lit};
+                    d.counters, d.qcount, d.hit_id, d.accum, d.rgba, d.hit_out, d.hitrec, d.queue, d.lit, d.gen_tri, d.gen_rect};
     for (void *p : ptrs) if (p) (void)hipFree(p);
+    for (int k = 0; k < 8; ++k) {
+        if (d.lvl_rays[k]) (void)hipFree(d.lvl_rays[k]);
+        if (d.lvl_hit[k]) (void)hipFree(d.lvl_hit[k]);
+        if (d.lvl_col[k]) (void)hipFree(d.lvl_col[k]);
+    }
     for (void *e : s->evpool) if (e) (void)hipEventDestroy((hipEvent_t)e);
     delete s;
 }
@@ -700,12 +887,6 @@ int rt_render_device(rt_scene *s, int w, int h, int depth, int spp, uint64_t see
     }
     if (depth < 0) { set_error("rt_render: depth must be >= 0"); return RT_ERR_ARG; }
     if (s->npoint > 32) { set_error("rt_render: more than 32 point lights are not supported yet"); return RT_ERR_UNSUPPORTED; }
-    if (depth > 1)
-        for (const MaterialD &m : s->mats)
-            if (m.reflectivity > 0) {
-                set_error("rt_render: reflective materials (trace depth > 1, Main.hs:546-556) are not built yet");
-                return RT_ERR_UNSUPPORTED;
-            }
     int rc;
     if ((rc = ensure_init())) return rc;
     if ((rc = prepare(*s, w, h))) return rc;
@@ -715,8 +896,12 @@ int rt_render_device(rt_scene *s, int w, int h, int depth, int spp, uint64_t see
     s->ev_used = 0;
     s->stats_pending = false;
     if (npix == 0) return RT_OK;
+    // bounce levels: trace n reflects at most n - 1 times (trace 0 = black, Main.hs:542); only scenes with a
+    // reflective material ever spawn a reflected ray (Main.hs:553)
+    const int levels = (s->reflective && depth > 1) ? (depth < 8 ? depth : 8) : 1;
+    if (s->reflective && depth > 8) { set_error("rt_render: trace depth > 8 with reflective materials is not supported"); return RT_ERR_UNSUPPORTED; }
     // rows per chunk: a multiple of the tile height
-    size_t crow = RT_CHUNK_PIXELS / (size_t)w;
+    size_t crow = (levels > 1 ? RT_CHUNK_PIXELS / 4 : RT_CHUNK_PIXELS) / (size_t)w;
     crow = crow < RT_TILE_H ? RT_TILE_H : crow - crow % RT_TILE_H;
     if (crow > (size_t)nrows) crow = (size_t)nrows;
     const size_t cpix = crow * (size_t)w;
@@ -730,6 +915,14 @@ int rt_render_device(rt_scene *s, int w, int h, int depth, int spp, uint64_t see
         if ((rc = ensure(s->dev.lit, s->dev.lit_cap, cpix))) return rc;
         if ((rc = ensure(s->dev.queue, s->dev.queue_cap, cpix * (size_t)(s->npoint > 0 ? s->npoint : 1)))) return rc;
     }
+    if (d_rgba && levels > 1) {
+        if ((rc = ensure(s->dev.lvl_col[0], s->dev.lvl_col_cap[0], cpix))) return rc;
+        for (int k = 1; k < levels; ++k) {
+            if ((rc = ensure(s->dev.lvl_rays[k], s->dev.lvl_rays_cap[k], cpix))) return rc;
+            if ((rc = ensure(s->dev.lvl_hit[k], s->dev.lvl_hit_cap[k], cpix))) return rc;
+            if ((rc = ensure(s->dev.lvl_col[k], s->dev.lvl_col_cap[k], cpix))) return rc;
+        }
+    }
     if (spp > 1 && d_rgba) {
         if ((rc = ensure(s->dev.accum, s->dev.accum_cap, 3 * npix))) return rc;
         HIP_TRY(hipMemsetAsync(s->dev.accum, 0, 3 * npix * sizeof(uint32_t), st));
@@ -742,6 +935,7 @@ int rt_render_device(rt_scene *s, int w, int h, int depth, int spp, uint64_t see
     P.tri_gid = s->dev.tri_gid; P.rect_gid = s->dev.rect_gid;
     P.counters = s->dev.counters;
     P.hitrec = reinterpret_cast<HitRec *>(s->dev.hitrec); P.queue = s->dev.queue; P.qcount = s->dev.qcount; P.lit = s->dev.lit;
+    P.gen_tri = s->dev.gen_tri; P.gen_rect = s->dev.gen_rect;
     P.cam = fixed_camera(w, h);
     P.eps = ray_eps();
     P.ntri = (int)s->tri_gid.size(); P.nrect = (int)s->rect_gid.size();
@@ -774,16 +968,42 @@ int rt_render_device(rt_scene *s, int w, int h, int depth, int spp, uint64_t see
             }
             if ((rc = next_event(*s, st, 1))) return rc;
             if (!d_rgba) continue;
+            const unsigned sblocks = (unsigned)(((size_t)P.qcap + 256 * RT_WAVES_PER_BLOCK - 1) / (256 * RT_WAVES_PER_BLOCK));
+            int32_t *const hit0 = P.hit_id;
+            const long long off0 = P.out_off;
+            uint8_t *const rgba0 = P.rgba;
+            uint32_t *const accum0 = P.accum;
+            unsigned *const lvl_count = s->dev.qcount + 32;
             HIP_TRY(hipMemsetAsync(s->dev.qcount, 0, 64 * sizeof(unsigned), st));
-            hipLaunchKernelGGL(k_setup, dim3(pblocks), dim3(256), 0, st, P);
-            if ((rc = next_event(*s, st, 2))) return rc;
-            if (s->npoint > 0) {
-                const unsigned sblocks = (unsigned)(((size_t)P.qcap + 256 * RT_WAVES_PER_BLOCK - 1) / (256 * RT_WAVES_PER_BLOCK));
-                hipLaunchKernelGGL(k_shadow, dim3(sblocks, (unsigned)s->npoint), dim3(RT_WAVES_PER_BLOCK * 64), 0, st, P);
+            for (int lvl = 0; lvl < levels; ++lvl) {
+                if (lvl > 0) {      // trace (n-1) lights world reflected, Main.hs:554
+                    HIP_TRY(hipMemsetAsync(s->dev.qcount, 0, 32 * sizeof(unsigned), st));
+                    P.rays = s->dev.lvl_rays[lvl]; P.count_ptr = lvl_count + lvl;
+                    P.hit_id = s->dev.lvl_hit[lvl]; P.out_off = 0;
+                    hipLaunchKernelGGL(k_general, dim3(sblocks), dim3(RT_WAVES_PER_BLOCK * 64), 0, st, P);
+                    if ((rc = next_event(*s, st, 1))) return rc;
+                }
+                P.next_rays = (lvl + 1 < levels) ? s->dev.lvl_rays[lvl + 1] : nullptr;
+                P.next_count = lvl_count + lvl + 1;
+                P.colour = (levels > 1) ? s->dev.lvl_col[lvl] : nullptr;
+                hipLaunchKernelGGL(k_setup, dim3(pblocks), dim3(256), 0, st, P);
+                if ((rc = next_event(*s, st, 2))) return rc;
+                if (s->npoint > 0)
+                    hipLaunchKernelGGL(k_shadow, dim3(sblocks, (unsigned)s->npoint), dim3(RT_WAVES_PER_BLOCK * 64), 0, st, P);
+                if ((rc = next_event(*s, st, 3))) return rc;
+                hipLaunchKernelGGL(k_final, dim3(pblocks), dim3(256), 0, st, P);
+                if ((rc = next_event(*s, st, 4))) return rc;
             }
-            if ((rc = next_event(*s, st, 3))) return rc;
-            hipLaunchKernelGGL(k_final, dim3(pblocks), dim3(256), 0, st, P);
-            if ((rc = next_event(*s, st, 4))) return rc;
+            P.rays = nullptr; P.count_ptr = nullptr; P.next_rays = nullptr; P.hit_id = hit0; P.out_off = off0;
+            if (levels > 1) {       // fold the levels back: direct `addPixelRGB8` scaled reflection, deepest first
+                for (int lvl = levels - 1; lvl >= 1; --lvl)
+                    hipLaunchKernelGGL(k_combine, dim3(pblocks), dim3(256), 0, st, s->dev.lvl_rays[lvl], s->dev.lvl_col[lvl],
+                                       lvl_count + lvl, (unsigned)P.qcap, s->dev.lvl_col[lvl - 1]);
+                P.colour = s->dev.lvl_col[0]; P.rgba = rgba0; P.accum = accum0;
+                hipLaunchKernelGGL(k_store, dim3(pblocks), dim3(256), 0, st, P);
+                P.colour = nullptr;
+                if ((rc = next_event(*s, st, 4))) return rc;
+            }
         }
     }
     if (d_rgba && spp > 1) {

@@ -280,6 +280,43 @@ bool compute_guards(rt_scene &s) {
     return true;
 }
 
+// General-ray record (reflected rays have no common apex).  With a = n.d, b = n.o + dpl, e_k = g_k.o + c_k,
+// f_k = g_k.d the hit distance is t = -b/a and the inside coordinates are q_k = e_k + t f_k, so
+// q_k * a = e_k a - b f_k and t * a = -b: the ray hits iff those all have the sign of a.
+static GenRec make_gen_rec(const LeafD &L, const double omax[3]) {
+    GenRec r{};
+    const double n[3] = {L.nx, L.ny, L.nz};
+    const double e1[3] = {L.e1x, L.e1y, L.e1z}, e2[3] = {L.e2x, L.e2y, L.e2z};
+    double g1[3], g2[3], ref[3];
+    if (L.kind == LEAF_TRI) {
+        for (int i = 0; i < 3; ++i) {
+            g1[i] = (L.c0 * e2[i] - L.c2 * e1[i]) / L.c3;
+            g2[i] = (L.c0 * e1[i] - L.c1 * e2[i]) / L.c3;
+        }
+        ref[0] = L.p0x; ref[1] = L.p0y; ref[2] = L.p0z;
+    } else {
+        for (int i = 0; i < 3; ++i) { g1[i] = 2.0 * e1[i] / L.c0; g2[i] = 2.0 * e2[i] / L.c1; }
+        ref[0] = L.p0x + 0.5 * e1[0] + 0.5 * e2[0]; ref[1] = L.p0y + 0.5 * e1[1] + 0.5 * e2[1]; ref[2] = L.p0z + 0.5 * e1[2] + 0.5 * e2[2];
+    }
+    const double c1 = -(g1[0] * ref[0] + g1[1] * ref[1] + g1[2] * ref[2]);
+    const double c2 = -(g2[0] * ref[0] + g2[1] * ref[1] + g2[2] * ref[2]);
+    double An = 0, Bn = std::fabs(L.d), E1 = std::fabs(c1), E2 = std::fabs(c2), F1 = 0, F2 = 0;
+    for (int i = 0; i < 3; ++i) {
+        An += std::fabs(n[i]); Bn += std::fabs(n[i]) * omax[i];
+        E1 += std::fabs(g1[i]) * omax[i]; E2 += std::fabs(g2[i]) * omax[i];
+        F1 += std::fabs(g1[i]); F2 += std::fabs(g2[i]);
+    }
+    const double m = std::ldexp(E1 * An + Bn * F1 + E2 * An + Bn * F2 + An + Bn * An + Bn, -19) + 1e-30;
+    r.c[12] = 1.0f;                                        // never passes (z <= 0 for all-zero coefficients)
+    if (!std::isfinite(m)) return r;
+    for (int i = 0; i < 3; ++i) { r.c[i] = (float)n[i]; r.c[4 + i] = (float)g1[i]; r.c[8 + i] = (float)g2[i]; }
+    r.c[3] = (float)L.d; r.c[7] = (float)c1; r.c[11] = (float)c2;
+    r.c[12] = f_down(-m);
+    for (int i = 0; i < 13; ++i)
+        if (!std::isfinite(r.c[i])) { GenRec a{}; a.c[12] = -1.0f; return a; }   // overflow: always pass, exact path decides
+    return r;
+}
+
 void build_filter_records(rt_scene &s, int w, int h) {
     const size_t ntri = s.tri_gid.size(), nrect = s.rect_gid.size();
     const int napex = 1 + s.npoint;
@@ -323,6 +360,17 @@ void build_filter_records(rt_scene &s, int w, int h) {
             dmax[i] = (s.leaves.empty() ? 1.0 : std::fmax(a, b)) * 1.001 + 1e-3;
         }
         fill(A, dmax, 0.0);
+    }
+    s.reflective = false;
+    for (const MaterialD &m : s.mats) if (m.reflectivity > 0) s.reflective = true;
+    s.gen_tri.clear(); s.gen_rect.clear();
+    if (s.reflective) {
+        double omax[3];
+        for (int i = 0; i < 3; ++i) omax[i] = (s.leaves.empty() ? 1.0 : std::fmax(std::fabs(lo[i]), std::fabs(hi[i]))) * 1.001 + 1e-3;
+        GenRec never{}; never.c[12] = 1.0f;
+        s.gen_tri.assign(ntri + 1, never); s.gen_rect.assign(nrect + 1, never);
+        for (size_t k = 0; k < ntri; ++k) s.gen_tri[k] = make_gen_rec(s.leaves[s.tri_gid[k]], omax);
+        for (size_t k = 0; k < nrect; ++k) s.gen_rect[k] = make_gen_rec(s.leaves[s.rect_gid[k]], omax);
     }
     s.rec_w = w; s.rec_h = h;
 }

@@ -32,7 +32,12 @@ struct DeviceScene {          // device copies (HBM), owned by the scene
     char *hitrec = nullptr;     size_t hitrec_cap = 0;     // per chunk pixel: 48-byte HitRec (capacity in bytes)
     uint32_t *queue = nullptr;  size_t queue_cap = 0;      // shadow-job queues, npoint x chunk pixels
     uint32_t *lit = nullptr;    size_t lit_cap = 0;        // per chunk pixel: lit-by-light bit mask
-    unsigned *qcount = nullptr;                            // shadow jobs per point light
+    unsigned *qcount = nullptr;                            // shadow jobs per point light; [32..39] rays per bounce level
+    GenRec *gen_tri = nullptr, *gen_rect = nullptr;        // general-ray filter records (reflective scenes only)
+    // bounce levels 1..7 (reflective scenes only): rays, hit ids and colours per slot; [0] = colour of level 0
+    RayRec *lvl_rays[8] = {};   size_t lvl_rays_cap[8] = {};
+    int32_t *lvl_hit[8] = {};   size_t lvl_hit_cap[8] = {};
+    uint32_t *lvl_col[8] = {};  size_t lvl_col_cap[8] = {};
     int device = -1;
 };
 
@@ -58,6 +63,8 @@ struct rt_scene {
 
     // filter records, rebuilt when the camera (w, h) or the scene changes
     std::vector<rt::FilterRec> tri_rec, rect_rec;
+    std::vector<rt::GenRec> gen_tri, gen_rect;   // only filled when a material reflects
+    bool reflective = false;
     int rec_w = -1, rec_h = -1;
     bool dirty = true;                    // host scene changed since the last upload
     rt::DeviceScene dev;

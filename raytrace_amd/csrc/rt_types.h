@@ -56,6 +56,17 @@ struct LightD {                // kind 0: pointLight (Main.hs:467), kind 1: ambi
 // (negm = -margin; Kq = K - mK + margin, so that the clip test N >= K - mK reads N - Kq >= negm)
 struct FilterRec { float c[12]; };
 
+// 16 floats per leaf for rays with arbitrary origins (reflected rays, Main.hs:549-552):
+//   n xyz, dpl, g1 xyz, c1, g2 xyz, c2, negm, 0, 0, 0     with q_k(p) = g_k . p + c_k the two inside coordinates
+struct GenRec { float c[16]; };
+
+// A reflected ray waiting to be traced: the arguments of `mkray` (Main.hs:552), the reflectivity that
+// scales what it returns (Main.hs:554) and the slot of the ray that spawned it.
+struct RayRec {
+    double ox, oy, oz, dx, dy, dz, rho;
+    uint32_t parent, _pad;
+};
+
 struct CameraD {               // fixedCamera, Main.hs:506-527
     double scaleX, scaleY, dX, dY, d;
 };

@@ -103,10 +103,26 @@ def talk_main2():                                    # Talk.hs:263-273 geometry,
     return world, mconcat_lights([ambient(0.1), pointLight(0.3, 0.0, (0, 0, 0)), pointLight(0.6, 0.0, (-1, 3, -3))])
 
 
+def mirror_room():
+    """The planar part of `spheres` (Main.hs:670-690): mirror floor strip and walls, lights of that scene.
+    (The spheres themselves are a "next" primitive.)  Exercises trace's reflection recursion, Main.hs:546-556."""
+    mirror = black.replace(reflectivity=0.9, specular=(255, 255, 255), specularity=100)
+    world = mconcat([
+        colorcube([red, green, blue], (-2, -3.5, -7), 2.0),
+        triangle(yellow.replace(reflectivity=0.4), (2, -4.5, -6), (4, -4.5, -8), (3, -1.5, -7)),
+        rectangle(orange, (0, -5, -10), (0, 0, 20), (20, 0, 0)),
+        rectangle(green, (0, 5, -15), (20, 0, 0), (0, 20, 0)),
+        rectangle(mirror, (0, 4, -10), (20, 0, 0), (0, 0, 20)),
+        rectangle(white, (10, 4, -10), (0, 0, 20), (0, 1, 0)),
+        rectangle(mirror, (-9, 0, -10), (0, 0, 20), (0, 10, 0))])
+    lights = mconcat_lights([pointLight(0.8, 0.1, (0, 3, -10)), pointLight(0.8, 0.8, (0, 3, 0)), ambient(0.2)])
+    return world, lights
+
+
 REFERENCE_SCENES = {
     "default": default_scene, "planes": planes, "axes": axes, "cubes": cubes, "stacked_cubes": stacked_cubes,
     "triangle_example": triangle_example, "spec_test": spec_test, "intersection": intersection,
-    "cylinder_axes": cylinder_axes, "talk_main2": talk_main2,
+    "cylinder_axes": cylinder_axes, "talk_main2": talk_main2, "mirror_room": mirror_room,
 }
 
 

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 SIZES = {"default": (256, 256), "planes": (160, 120), "axes": (200, 200), "cubes": (256, 144),
          "stacked_cubes": (256, 256), "triangle_example": (250, 130), "spec_test": (192, 192),
-         "intersection": (256, 256), "cylinder_axes": (200, 160), "talk_main2": (128, 128)}
+         "intersection": (256, 256), "cylinder_axes": (200, 160), "talk_main2": (128, 128), "mirror_room": (256, 192)}
 
 
 def compare(world, lights, w, h, depth=4, label=""):
@@ -166,3 +166,24 @@ def test_synthetic_4k_rows_against_oracle(gpu_lib):
         assert (hit[r0] == ref["hit_id"][0]).all(), f"row {r0}"
         assert (rgba[r0, :, :3] == ref["rgb"][0]).all(), f"row {r0}"
     assert 0.3 < (hit >= 0).mean() < 0.95
+
+
+def test_reflection_depths(gpu_lib):
+    """trace n (Main.hs:541-557): n = 1 has no reflection, n = 2..5 add one bounce each; all must match the oracle."""
+    world, lights = scenes.mirror_room()
+    osc = ob.OracleScene(world, lights)
+    sc = api.Scene(world, lights)
+    prev = None
+    for depth in (1, 2, 3, 5):
+        ref = osc.render(160, 120, depth=depth)
+        rgba, hit = sc.render(160, 120, depth=depth)
+        assert (hit == ref["hit_id"]).all()
+        assert (rgba[:, :, :3] == ref["rgb"]).all(), f"depth {depth}"
+        if depth == 2:
+            assert (rgba != prev).any()          # the first bounce is visible in this scene
+        prev = rgba
+    # supersampled + reflective
+    ref = osc.render(96, 72, depth=4, spp=4, seed=11)
+    rgba, hit = sc.render(96, 72, depth=4, spp=4, seed=11)
+    assert (rgba[:, :, :3] == ref["rgb"]).all() and (hit == ref["hit_id"]).all()
+    sc.close()
