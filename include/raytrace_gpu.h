@@ -80,6 +80,8 @@ int  rt_add_rectangle(rt_scene *, const rt_material *, const double point[3],
 /* triangle material pa pb pc                                              Main.hs:363-385 */
 int  rt_add_triangle(rt_scene *, const rt_material *, const double pa[3],
                      const double pb[3], const double pc[3]);
+/* sphere material center radius                                           Main.hs:392-415 */
+int  rt_add_sphere(rt_scene *, const rt_material *, const double center[3], double radius);
 /* colorcuboid materials point l h d (cube/colorcube/cuboid are special cases) Main.hs:286-320 */
 int  rt_add_cuboid(rt_scene *, const rt_material *mats, int nmats, const double point[3],
                    double l, double h, double d);
@@ -111,7 +113,7 @@ int  rt_add_ambient(rt_scene *, double f);
 /* ---- introspection (host logic tests; no device needed) --------------------------------- */
 int  rt_scene_num_leaves(const rt_scene *);
 int  rt_scene_num_lights(const rt_scene *);
-/* out[0..19]: kind(0 rect,1 tri), normal mode, normal xyz, d, p0 xyz, e1 xyz, e2 xyz, c0..c3 */
+/* out[0..19]: kind(0 rect,1 tri,2 sphere), normal mode, normal xyz, d, p0 xyz, e1 xyz, e2 xyz, c0..c3 */
 int  rt_scene_get_leaf(const rt_scene *, int leaf, double out[20]);
 /* Host-side preparation of everything a w x h render uploads: guard-box chains (fails on an open
  * bracket) and the FP32 filter records.  Returns the number of guard boxes.  No device needed. */

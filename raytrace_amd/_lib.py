@@ -33,6 +33,7 @@ SYMBOLS = {
     "rt_scene_destroy": (None, [C.c_void_p]),
     "rt_add_rectangle": (C.c_int, [C.c_void_p, _MAT, _D3, _D3, _D3]),
     "rt_add_triangle": (C.c_int, [C.c_void_p, _MAT, _D3, _D3, _D3]),
+    "rt_add_sphere": (C.c_int, [C.c_void_p, _MAT, _D3, C.c_double]),
     "rt_add_cuboid": (C.c_int, [C.c_void_p, _MAT, C.c_int, _D3, C.c_double, C.c_double, C.c_double]),
     "rt_add_cylinder": (C.c_int, [C.c_void_p, _MAT, _MAT, _MAT, _D3, C.c_int, C.c_double, C.c_double]),
     "rt_begin_mconcat": (C.c_int, [C.c_void_p]),

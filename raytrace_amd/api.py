@@ -7,6 +7,7 @@ Names, argument order and meaning follow the reference:
 
     rectangle material point width height            Main.hs:226
     triangle material pa pb pc                       Main.hs:363
+    sphere material center radius                    Main.hs:392
     cube / colorcube / cuboid / colorcuboid          Main.hs:286-320
     cylinder topM botM mantleM point n h r           Main.hs:725
     pointLight diffuse specular lpos, ambient f      Main.hs:467, 490   (world is bound at render time)
@@ -93,6 +94,13 @@ class Triangle(Shape):
 
 
 @dataclass
+class Sphere(Shape):
+    material: Material
+    center: Vec
+    radius: float
+
+
+@dataclass
 class Cuboid(Shape):
     materials: Sequence[Material]
     point: Vec
@@ -148,6 +156,10 @@ def rectangle(material, point, width, height) -> Shape:
 
 def triangle(material, pa, pb, pc) -> Shape:
     return Triangle(material, tuple(pa), tuple(pb), tuple(pc))
+
+
+def sphere(material, center, radius) -> Shape:          # Main.hs:392
+    return Sphere(material, tuple(center), radius)
 
 
 def colorcuboid(materials, point, l, h, d) -> Shape:
@@ -297,6 +309,8 @@ class Scene:
             _lib.check(L.rt_add_rectangle(h, C.byref(_cmat(s.material)), _lib.vec3(s.point), _lib.vec3(s.width), _lib.vec3(s.height)))
         elif isinstance(s, Triangle):
             _lib.check(L.rt_add_triangle(h, C.byref(_cmat(s.material)), _lib.vec3(s.pa), _lib.vec3(s.pb), _lib.vec3(s.pc)))
+        elif isinstance(s, Sphere):
+            _lib.check(L.rt_add_sphere(h, C.byref(_cmat(s.material)), _lib.vec3(s.center), s.radius))
         elif isinstance(s, Cuboid):
             arr = (_lib.rt_material * len(s.materials))(*[_cmat(m) for m in s.materials])
             _lib.check(L.rt_add_cuboid(h, arr, len(s.materials), _lib.vec3(s.point), s.l, s.h, s.d))

@@ -62,6 +62,9 @@ struct RenderParams {
     const FilterRec *rect_rec;
     const int32_t *tri_gid;
     const int32_t *rect_gid;
+    const FilterRec *sph_rec;
+    const GenRec *gen_sph;
+    const int32_t *sph_gid;
     unsigned long long *counters;   // [0] shadow rays cast, [1] exact evals (primary), [2] exact evals (shadow)
     int32_t *hit_id;                // band-local output, indexed out_off + pix
     uint8_t *rgba;                  // band-local output (spp == 1) or nullptr
@@ -81,7 +84,7 @@ struct RenderParams {
     const GenRec *gen_rect;
     CameraD cam;
     double eps;
-    int ntri, nrect, nlights, nleaves, npoint;
+    int ntri, nrect, nsph, nlights, nleaves, npoint;
     int w, h;
     int row0, nrows;                // this chunk: first absolute image row, rows
     long long out_off;              // index of the chunk's first pixel inside the band-local outputs
@@ -158,6 +161,24 @@ __device__ __forceinline__ RayD slot_ray(const RenderParams &P, int slot) {
 // KIND is the leaf type; L is wave-uniform in the filter loops (scalar loads).
 template <int KIND>
 __device__ __forceinline__ bool leaf_isect(const LeafD &L, const RayD &r, double &ix, double &iy, double &iz, double &t) {
+    if (KIND == LEAF_SPHERE) {                                                         // sphere, Main.hs:395-411
+        const double ox = r.px - L.p0x, oy = r.py - L.p0y, oz = r.pz - L.p0z;          // :396
+        const double sb = 2 * (r.dx * ox + r.dy * oy + r.dz * oz);                     // :398
+        const double sc = (ox * ox + oy * oy + oz * oz) - L.c0 * L.c0;                 // :399
+        const double delta = sb * sb - 4 * sc;                                         // :400
+        if (!(delta >= 0)) return false;                                               // :401
+        double ts;
+        if (delta > 0) {
+            const double sq = sqrt(delta);
+            const double t1 = (-sb + sq) / 2, t2 = (-sb - sq) / 2;                     // :404-405
+            const double m1 = t1 <= 0 ? 0.0 : t1, m2 = t2 <= 0 ? 0.0 : t2;             // max t 0
+            ts = m1 <= m2 ? m1 : m2;                                                   // min, :406
+        } else ts = -sb / 2;                                                           // :407
+        if (!(ts > 0)) return false;                                                   // :408
+        t = ts;
+        ix = r.px + ts * r.dx; iy = r.py + ts * r.dy; iz = r.pz + ts * r.dz;           // :409
+        return true;
+    }
     const double a = L.nx, b = L.ny, c = L.nz;
     const double frac = (a * r.dx + b * r.dy + c * r.dz) / r.dz;                       // Main.hs:269
     const double z = (-L.d - a * r.px - b * r.py + (frac - c) * r.pz) / frac;          // :270
@@ -251,6 +272,22 @@ __device__ __forceinline__ bool filter4(const FilterRec &R, const Dir4 &D, float
     return mx >= R.c[10];
 }
 
+// Sphere, apex form: z = (D.oc)^2 - |D|^2 cs; dd = |D|^2 of the lane's rays.
+__device__ __forceinline__ bool filter4_sphere(const FilterRec &R, const Dir4 &D, const f2 dd[2], float z[4]) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const f2 b = pkfma(splat(R.c[0]), D.x[p], pkfma(splat(R.c[1]), D.y[p], splat(R.c[2]) * D.z[p]));
+        const f2 zz = pkfma(b, b, -(dd[p] * splat(R.c[3])));
+        z[2 * p] = zz[0]; z[2 * p + 1] = zz[1];
+    }
+    const float mx = __builtin_fmaxf(__builtin_fmaxf(z[0], z[1]), __builtin_fmaxf(z[2], z[3]));
+    return mx >= R.c[10];
+}
+__device__ __forceinline__ void dir_norms(const Dir4 &D, f2 dd[2]) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) dd[p] = pkfma(D.x[p], D.x[p], pkfma(D.y[p], D.y[p], D.z[p] * D.z[p]));
+}
+
 // Eye-apex variant: the forms are affine in the pixel's viewport position (posX, posY); the lane's 4
 // pixels share posY (SHARED_Y, spp == 1), so the posY part of a form is computed once per lane.
 //   triangle : z = min(U, V, W)          rectangle: z = N - max(|A|, |B|)
@@ -341,6 +378,40 @@ __device__ __forceinline__ void primary_loop(const RenderParams &P, CRecPtr recs
     }
 }
 
+// spheres seen from the eye (few per scene: plain loop, generic apex form)
+__device__ __noinline__ void primary_sphere_loop(const RenderParams &P, const Eye4 &E, const bool act[4], int x0, int y,
+                                                 double bt[4], int bid[4], unsigned &nexact) {
+    Dir4 D;
+    const float dz = (float)P.cam.d;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) { D.x[p] = E.x[p]; D.y[p] = E.y[p]; D.z[p] = f2{dz, dz}; }
+    f2 dd[2];
+    dir_norms(D, dd);
+    CRecPtr recs = as_const(P.sph_rec);
+    CIntPtr gids = as_const(P.sph_gid);
+    for (int i = 0; i < P.nsph; ++i) {
+        const FilterRec cur = load_rec(recs + i);
+        float z[4];
+        if (filter4_sphere(cur, D, dd, z)) {
+            const int gid = gids[i];
+            const LeafD &L = P.leaves[gid];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if ((z[r] >= cur.c[10]) & act[r]) {
+                    int xr = x0 + r;
+                    asm volatile("" : "+v"(xr));
+                    const RayD ray = camera_ray(P, xr, y);
+                    double ix, iy, iz, t;
+                    ++nexact;
+                    if (leaf_isect<LEAF_SPHERE>(L, ray, ix, iy, iz, t) && guards_ok(P.guards, L.guard, ray)) {
+                        if (t < bt[r] || (t == bt[r] && gid < bid[r]) || bid[r] < 0) { bt[r] = t; bid[r] = gid; }
+                    }
+                }
+            }
+        }
+    }
+}
+
 template <bool SHARED_Y>
 __global__ void RT_HOT(RT_WAVES_EU_PRIMARY) k_primary(const RenderParams P) {
     int x0, y; bool row_ok;
@@ -370,6 +441,7 @@ __global__ void RT_HOT(RT_WAVES_EU_PRIMARY) k_primary(const RenderParams P) {
     unsigned nexact = 0;
     primary_loop<LEAF_TRI, SHARED_Y>(P, as_const(P.tri_rec), as_const(P.tri_gid), P.ntri, D, act, x0, y, bt, bid, nexact);
     primary_loop<LEAF_RECT, SHARED_Y>(P, as_const(P.rect_rec), as_const(P.rect_gid), P.nrect, D, act, x0, y, bt, bid, nexact);
+    if (P.nsph > 0) primary_sphere_loop(P, D, act, x0, y, bt, bid, nexact);
     const long long row = P.out_off + (long long)(y - P.row0) * P.w;
 #pragma unroll
     for (int r = 0; r < 4; ++r)
@@ -400,8 +472,13 @@ __global__ void __launch_bounds__(256) k_setup(const RenderParams P) {
         const RayD ray = slot_ray(P, pix);
         double ix = 0, iy = 0, iz = 0, t;
         if (L.kind == LEAF_RECT) leaf_isect<LEAF_RECT>(L, ray, ix, iy, iz, t);
-        else leaf_isect<LEAF_TRI>(L, ray, ix, iy, iz, t);
+        else if (L.kind == LEAF_TRI) leaf_isect<LEAF_TRI>(L, ray, ix, iy, iz, t);
+        else leaf_isect<LEAF_SPHERE>(L, ray, ix, iy, iz, t);
         double nx = L.nx, ny = L.ny, nz = L.nz;
+        if (L.kind == LEAF_SPHERE) {                                                   // scalar (recip radius) (isect - center), :410
+            const double rr = 1.0 / L.c0;
+            nx = rr * (ix - L.p0x); ny = rr * (iy - L.p0y); nz = rr * (iz - L.p0z);
+        }
         if (L.nmode == RT_NORMAL_MANTLE) {                                             // Main.hs:769-771
             const AuxD A = P.aux[L.aux];
             nx = A.a[0] + (ix - A.a[3]) * A.a[6];
@@ -501,6 +578,39 @@ __device__ __forceinline__ void shadow_loop(const RenderParams &P, CRecPtr recs,
     }
 }
 
+// spheres between a light and the shadow-ray origins (no own-leaf exclusion: a sphere is not planar)
+__device__ __noinline__ void shadow_sphere_loop(const RenderParams &P, CRecPtr recs, const Dir4 &D, const uint32_t pix[4],
+                                                const LightD &Lt, bool need[4], unsigned &nexact) {
+    f2 dd[2];
+    dir_norms(D, dd);
+    CIntPtr gids = as_const(P.sph_gid);
+    for (int i = 0; i < P.nsph; ++i) {
+        const FilterRec cur = load_rec(recs + i);
+        float z[4];
+        if (filter4_sphere(cur, D, dd, z)) {
+            const int gid = gids[i];
+            const LeafD &L = P.leaves[gid];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if ((z[r] >= cur.c[10]) & need[r]) {
+                    uint32_t pr = pix[r];
+                    asm volatile("" : "+v"(pr));
+                    const HitRec H = P.hitrec[pr];
+                    double tx, ty, tz;
+                    to_light(Lt, H.px, H.py, H.pz, tx, ty, tz);
+                    const RayD ray = mkray(H.px + 0.00001 * tx, H.py + 0.00001 * ty, H.pz + 0.00001 * tz, tx, ty, tz, P.eps);
+                    double ix, iy, iz, t;
+                    ++nexact;
+                    if (leaf_isect<LEAF_SPHERE>(L, ray, ix, iy, iz, t) && guards_ok(P.guards, L.guard, ray)) {
+                        const double tl = (Lt.pz - ray.pz) * ray.rz;
+                        if (t <= tl) need[r] = false;
+                    }
+                }
+            }
+        }
+    }
+}
+
 __global__ void RT_HOT(RT_WAVES_EU_SHADOW) k_shadow(const RenderParams P) {
     const int pl = (int)blockIdx.y;
     const unsigned count = P.qcount[pl];
@@ -541,6 +651,7 @@ __global__ void RT_HOT(RT_WAVES_EU_SHADOW) k_shadow(const RenderParams P) {
     const size_t ro = (size_t)__builtin_amdgcn_readfirstlane(Lt.rec_offset);
     shadow_loop<LEAF_TRI>(P, as_const(P.tri_rec + ro * (size_t)P.ntri), as_const(P.tri_gid), P.ntri, D, pix, Lt, need, nexact);
     shadow_loop<LEAF_RECT>(P, as_const(P.rect_rec + ro * (size_t)P.nrect), as_const(P.rect_gid), P.nrect, D, pix, Lt, need, nexact);
+    if (P.nsph > 0) shadow_sphere_loop(P, as_const(P.sph_rec + ro * (size_t)P.nsph), D, pix, Lt, need, nexact);
 #pragma unroll
     for (int r = 0; r < 4; ++r)
         if (need[r]) atomicOr(&P.lit[pix[r]], 1u << pl);
@@ -695,6 +806,42 @@ __device__ __forceinline__ void general_loop(const RenderParams &P, CGenPtr recs
     }
 }
 
+__device__ __noinline__ void general_sphere_loop(const RenderParams &P, const Ray4 &G, const bool act[4], const uint32_t slot[4],
+                                                 double bt[4], int bid[4], unsigned &nexact) {
+    CGenPtr recs = as_const(P.gen_sph);
+    CIntPtr gids = as_const(P.sph_gid);
+    for (int i = 0; i < P.nsph; ++i) {
+        CGenPtr R = recs + i;
+        float z[4];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {           // delta/4 = (d.o)^2 - (o.o - r^2) with o = origin - centre, Main.hs:396-400
+            const f2 ox = G.ox[p] - splat(R->c[0]), oy = G.oy[p] - splat(R->c[1]), oz = G.oz[p] - splat(R->c[2]);
+            const f2 b = pkfma(G.dx[p], ox, pkfma(G.dy[p], oy, G.dz[p] * oz));
+            const f2 c = pkfma(ox, ox, pkfma(oy, oy, pkfma(oz, oz, -splat(R->c[3]))));
+            const f2 zz = pkfma(b, b, -c);
+            z[2 * p] = zz[0]; z[2 * p + 1] = zz[1];
+        }
+        const float negm = R->c[12];
+        if (__builtin_fmaxf(__builtin_fmaxf(z[0], z[1]), __builtin_fmaxf(z[2], z[3])) >= negm) {
+            const int gid = gids[i];
+            const LeafD &L = P.leaves[gid];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if ((z[r] >= negm) & act[r]) {
+                    uint32_t sr = slot[r];
+                    asm volatile("" : "+v"(sr));
+                    const RayD ray = slot_ray(P, (int)sr);
+                    double ix, iy, iz, t;
+                    ++nexact;
+                    if (leaf_isect<LEAF_SPHERE>(L, ray, ix, iy, iz, t) && guards_ok(P.guards, L.guard, ray)) {
+                        if (t < bt[r] || (t == bt[r] && gid < bid[r]) || bid[r] < 0) { bt[r] = t; bid[r] = gid; }
+                    }
+                }
+            }
+        }
+    }
+}
+
 __global__ void RT_HOT(4) k_general(const RenderParams P) {
     const unsigned count = num_slots(P);
     const unsigned wave = blockIdx.x * RT_WAVES_PER_BLOCK + (threadIdx.x >> 6);
@@ -723,6 +870,7 @@ __global__ void RT_HOT(4) k_general(const RenderParams P) {
     unsigned nexact = 0;
     general_loop<LEAF_TRI>(P, as_const(P.gen_tri), as_const(P.tri_gid), P.ntri, G, act, slot, bt, bid, nexact);
     general_loop<LEAF_RECT>(P, as_const(P.gen_rect), as_const(P.rect_gid), P.nrect, G, act, slot, bt, bid, nexact);
+    if (P.nsph > 0) general_sphere_loop(P, G, act, slot, bt, bid, nexact);
 #pragma unroll
     for (int r = 0; r < 4; ++r)
         if (act[r]) P.hit_id[P.out_off + slot[r]] = bid[r];
@@ -816,7 +964,10 @@ int prepare(rt_scene &s, int w, int h) {
         if ((rc = upload(s.dev.lights, s.lights))) return rc;
         if ((rc = upload(s.dev.tri_rec, s.tri_rec))) return rc;
         if ((rc = upload(s.dev.rect_rec, s.rect_rec))) return rc;
+        if ((rc = upload(s.dev.sph_rec, s.sph_rec))) return rc;
+        if ((rc = upload(s.dev.sph_gid, s.sph_gid))) return rc;
         if (s.reflective) {
+            if ((rc = upload(s.dev.gen_sph, s.gen_sph))) return rc;
             if ((rc = upload(s.dev.gen_tri, s.gen_tri))) return rc;
             if ((rc = upload(s.dev.gen_rect, s.gen_rect))) return rc;
         }
@@ -868,7 +1019,7 @@ void rt_scene_destroy(rt_scene *s) {
     if (!s) return;
     DeviceScene &d = s->dev;
     void *ptrs[] = {d.leaves, d.aux, d.guards, d.mats, d.lights, d.tri_rec, d.rect_rec, d.tri_gid, d.rect_gid,
-                    d.counters, d.qcount, d.hit_id, d.accum, d.rgba, d.hit_out, d.hitrec, d.queue, d.lit, d.gen_tri, d.gen_rect};
+                    d.counters, d.qcount, d.hit_id, d.accum, d.rgba, d.hit_out, d.hitrec, d.queue, d.lit, d.gen_tri, d.gen_rect, d.sph_rec, d.gen_sph, d.sph_gid};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (int k = 0; k < 8; ++k) {
         if (d.lvl_rays[k]) (void)hipFree(d.lvl_rays[k]);
@@ -936,6 +1087,7 @@ int rt_render_device(rt_scene *s, int w, int h, int depth, int spp, uint64_t see
     P.counters = s->dev.counters;
     P.hitrec = reinterpret_cast<HitRec *>(s->dev.hitrec); P.queue = s->dev.queue; P.qcount = s->dev.qcount; P.lit = s->dev.lit;
     P.gen_tri = s->dev.gen_tri; P.gen_rect = s->dev.gen_rect;
+    P.sph_rec = s->dev.sph_rec; P.gen_sph = s->dev.gen_sph; P.sph_gid = s->dev.sph_gid; P.nsph = (int)s->sph_gid.size();
     P.cam = fixed_camera(w, h);
     P.eps = ray_eps();
     P.ntri = (int)s->tri_gid.size(); P.nrect = (int)s->rect_gid.size();

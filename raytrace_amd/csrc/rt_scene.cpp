@@ -80,6 +80,7 @@ static int push_leaf(rt_scene &s, LeafD &L, const Box &bb) {
     L.aux = -1;
     L.nmode = RT_NORMAL_GEOMETRIC;
     if (L.kind == LEAF_TRI) { L.slot = (int)s.tri_gid.size(); s.tri_gid.push_back((int)s.leaves.size()); }
+    else if (L.kind == LEAF_SPHERE) { L.slot = (int)s.sph_gid.size(); s.sph_gid.push_back((int)s.leaves.size()); }
     else { L.slot = (int)s.rect_gid.size(); s.rect_gid.push_back((int)s.leaves.size()); }
     s.leaves.push_back(L);
     s.dirty = true;
@@ -124,6 +125,49 @@ static int add_tri(rt_scene &s, const rt_material &m, D3 pa, D3 pb, D3 pc) {
     Box bb = {{hmin(pa.x, hmin(pb.x, pc.x)), hmin(pa.y, hmin(pb.y, pc.y)), hmin(pa.z, hmin(pb.z, pc.z))},   // :384
               {hmax(pa.x, hmax(pb.x, pc.x)), hmax(pa.y, hmax(pb.y, pc.y)), hmax(pa.z, hmax(pb.z, pc.z))}};
     return push_leaf(s, L, bb);
+}
+
+// sphere material center radius — Main.hs:392-415 (boundingBox :412-414)
+static int add_sphere(rt_scene &s, const rt_material &m, D3 c, double radius) {
+    LeafD L{};
+    L.kind = LEAF_SPHERE;
+    L.mat = add_material(s, m);
+    L.p0x = c.x; L.p0y = c.y; L.p0z = c.z;
+    L.c0 = radius;
+    Box bb = {{c.x - radius, c.y - radius, c.z - radius}, {c.x + radius, c.y + radius, c.z + radius}};
+    return push_leaf(s, L, bb);
+}
+
+static inline float f_down(double v);
+
+// Sphere filter records.  The reference solves t^2 + b t + c = 0 assuming a unit direction (Main.hs:396-400):
+// delta = (2 d.o)^2 - 4 (o.o - r^2) >= 0, i.e. the LINE of the ray passes within r of the centre; that does not
+// depend on where on the line o lies, so it can be tested from the apex: (D.oc)^2 - |D|^2 (|oc|^2 - r^2) >= 0.
+static FilterRec make_sphere_rec(const LeafD &L, const double A[3], const double dmax[3]) {
+    FilterRec r{};
+    const double oc[3] = {A[0] - L.p0x, A[1] - L.p0y, A[2] - L.p0z};
+    const double oo = oc[0] * oc[0] + oc[1] * oc[1] + oc[2] * oc[2], cs = oo - L.c0 * L.c0;
+    double B = 0, DD = 0;
+    for (int i = 0; i < 3; ++i) { B += std::fabs(oc[i]) * dmax[i]; DD += dmax[i] * dmax[i]; }
+    const double m = std::ldexp(B * B + DD * (oo + L.c0 * L.c0), -19) + 1e-30;
+    r.c[10] = 1.0f;
+    if (!std::isfinite(m)) { r.c[10] = -1.0f; return r; }      // all-zero forms, negm = -1: always passes
+    for (int i = 0; i < 3; ++i) r.c[i] = (float)oc[i];
+    r.c[3] = (float)cs;
+    r.c[10] = f_down(-m);
+    return r;
+}
+static GenRec make_sphere_gen_rec(const LeafD &L, const double omax[3]) {
+    GenRec r{};
+    double O = 0;
+    const double c[3] = {L.p0x, L.p0y, L.p0z};
+    for (int i = 0; i < 3; ++i) O += (omax[i] + std::fabs(c[i])) * (omax[i] + std::fabs(c[i]));
+    // reflected directions are unit vectors only up to rounding (and not at all after a mantle normal): |d| <= 4 is ample
+    const double m = std::ldexp(16.0 * O + O + L.c0 * L.c0, -18) + 1e-30;
+    for (int i = 0; i < 3; ++i) r.c[i] = (float)c[i];
+    r.c[3] = (float)(L.c0 * L.c0);
+    r.c[12] = std::isfinite(m) ? f_down(-m) : -INFINITY;
+    return r;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -318,8 +362,9 @@ static GenRec make_gen_rec(const LeafD &L, const double omax[3]) {
 }
 
 void build_filter_records(rt_scene &s, int w, int h) {
-    const size_t ntri = s.tri_gid.size(), nrect = s.rect_gid.size();
+    const size_t ntri = s.tri_gid.size(), nrect = s.rect_gid.size(), nsph = s.sph_gid.size();
     const int napex = 1 + s.npoint;
+    s.sph_rec.assign(nsph * (size_t)napex + 1, never_rec());
     // one record of padding: the kernels prefetch record i + 1 while testing record i
     s.tri_rec.assign(ntri * (size_t)napex + 1, never_rec());
     s.rect_rec.assign(nrect * (size_t)napex + 1, never_rec());
@@ -331,6 +376,13 @@ void build_filter_records(rt_scene &s, int w, int h) {
             {L.p0x + L.e1x, L.p0y + L.e1y, L.p0z + L.e1z},
             {L.p0x + L.e2x, L.p0y + L.e2y, L.p0z + L.e2z},
             {L.p0x + L.e1x + L.e2x, L.p0y + L.e1y + L.e2y, L.p0z + L.e1z + L.e2z}};
+        if (L.kind == LEAF_SPHERE) {
+            for (int i = 0; i < 3; ++i) {
+                const double c = i == 0 ? L.p0x : (i == 1 ? L.p0y : L.p0z);
+                if (std::isfinite(c) && std::isfinite(L.c0)) { lo[i] = std::fmin(lo[i], c - std::fabs(L.c0)); hi[i] = std::fmax(hi[i], c + std::fabs(L.c0)); }
+            }
+            continue;
+        }
         const int np = L.kind == LEAF_TRI ? 3 : 4;
         for (int k = 0; k < np; ++k)
             for (int i = 0; i < 3; ++i)
@@ -341,6 +393,7 @@ void build_filter_records(rt_scene &s, int w, int h) {
     auto fill = [&](const double A[3], const double dmax[3], double eye_d) {
         for (size_t k = 0; k < ntri; ++k) s.tri_rec[(size_t)apex * ntri + k] = make_rec(s.leaves[s.tri_gid[k]], A, dmax, eye_d);
         for (size_t k = 0; k < nrect; ++k) s.rect_rec[(size_t)apex * nrect + k] = make_rec(s.leaves[s.rect_gid[k]], A, dmax, eye_d);
+        for (size_t k = 0; k < nsph; ++k) s.sph_rec[(size_t)apex * nsph + k] = make_sphere_rec(s.leaves[s.sph_gid[k]], A, dmax);
         ++apex;
     };
     {   // the eye: every primary ray o = (posX, posY, 0), D = (posX, posY, d) passes through o - D
@@ -363,7 +416,7 @@ void build_filter_records(rt_scene &s, int w, int h) {
     }
     s.reflective = false;
     for (const MaterialD &m : s.mats) if (m.reflectivity > 0) s.reflective = true;
-    s.gen_tri.clear(); s.gen_rect.clear();
+    s.gen_tri.clear(); s.gen_rect.clear(); s.gen_sph.clear();
     if (s.reflective) {
         double omax[3];
         for (int i = 0; i < 3; ++i) omax[i] = (s.leaves.empty() ? 1.0 : std::fmax(std::fabs(lo[i]), std::fabs(hi[i]))) * 1.001 + 1e-3;
@@ -371,6 +424,8 @@ void build_filter_records(rt_scene &s, int w, int h) {
         s.gen_tri.assign(ntri + 1, never); s.gen_rect.assign(nrect + 1, never);
         for (size_t k = 0; k < ntri; ++k) s.gen_tri[k] = make_gen_rec(s.leaves[s.tri_gid[k]], omax);
         for (size_t k = 0; k < nrect; ++k) s.gen_rect[k] = make_gen_rec(s.leaves[s.rect_gid[k]], omax);
+        s.gen_sph.assign(nsph + 1, never);
+        for (size_t k = 0; k < nsph; ++k) s.gen_sph[k] = make_sphere_gen_rec(s.leaves[s.sph_gid[k]], omax);
     }
     s.rec_w = w; s.rec_h = h;
 }
@@ -404,6 +459,11 @@ int rt_add_triangle(rt_scene *s, const rt_material *m, const double pa[3], const
                     const double pc[3]) {
     if (!s || !m || !pa || !pb || !pc) { set_error("rt_add_triangle: NULL argument"); return RT_ERR_ARG; }
     return add_tri(*s, *m, from(pa), from(pb), from(pc));
+}
+
+int rt_add_sphere(rt_scene *s, const rt_material *m, const double center[3], double radius) {
+    if (!s || !m || !center) { set_error("rt_add_sphere: NULL argument"); return RT_ERR_ARG; }
+    return add_sphere(*s, *m, from(center), radius);
 }
 
 // colorcuboid materials point l h d — Main.hs:301-320: six rectangles in the order
@@ -538,8 +598,8 @@ int rt_scene_get_filter_record(const rt_scene *s, int apex, int leaf, float out[
         set_error("rt_scene_get_filter_record: bad argument (call rt_scene_prepare_host first)"); return RT_ERR_ARG;
     }
     const LeafD &L = s->leaves[leaf];
-    const std::vector<FilterRec> &v = L.kind == LEAF_TRI ? s->tri_rec : s->rect_rec;
-    const size_t n = L.kind == LEAF_TRI ? s->tri_gid.size() : s->rect_gid.size();
+    const std::vector<FilterRec> &v = L.kind == LEAF_TRI ? s->tri_rec : (L.kind == LEAF_SPHERE ? s->sph_rec : s->rect_rec);
+    const size_t n = L.kind == LEAF_TRI ? s->tri_gid.size() : (L.kind == LEAF_SPHERE ? s->sph_gid.size() : s->rect_gid.size());
     std::memcpy(out, v[(size_t)apex * n + (size_t)L.slot].c, sizeof(float) * 12);
     return RT_OK;
 }

@@ -23,6 +23,9 @@ struct DeviceScene {          // device copies (HBM), owned by the scene
     FilterRec *rect_rec = nullptr;   // (1 + npoint) blocks of nrect records
     int32_t *tri_gid = nullptr;      // per-type slot -> leaf index
     int32_t *rect_gid = nullptr;
+    FilterRec *sph_rec = nullptr;    // (1 + npoint) blocks of nsph sphere records
+    GenRec *gen_sph = nullptr;
+    int32_t *sph_gid = nullptr;
     unsigned long long *counters = nullptr;  // 8 x u64
     // work buffers, grown on demand
     int32_t *hit_id = nullptr;  size_t hit_id_cap = 0;     // per band pixel
@@ -58,12 +61,12 @@ struct rt_scene {
     std::vector<rt::GuardD> guards;       // guard-box chains, rebuilt by compute_guards
     std::vector<rt::MaterialD> mats;
     std::vector<rt::LightD> lights;
-    std::vector<int32_t> tri_gid, rect_gid;
+    std::vector<int32_t> tri_gid, rect_gid, sph_gid;
     int npoint = 0;                       // number of point lights
 
     // filter records, rebuilt when the camera (w, h) or the scene changes
-    std::vector<rt::FilterRec> tri_rec, rect_rec;
-    std::vector<rt::GenRec> gen_tri, gen_rect;   // only filled when a material reflects
+    std::vector<rt::FilterRec> tri_rec, rect_rec, sph_rec;
+    std::vector<rt::GenRec> gen_tri, gen_rect, gen_sph;   // only filled when a material reflects
     bool reflective = false;
     int rec_w = -1, rec_h = -1;
     bool dirty = true;                    // host scene changed since the last upload

@@ -13,15 +13,15 @@
 
 namespace rt {
 
-enum : int32_t { LEAF_RECT = 0, LEAF_TRI = 1 };
+enum : int32_t { LEAF_RECT = 0, LEAF_TRI = 1, LEAF_SPHERE = 2 };
 
 struct LeafD {                 // 176 bytes
     double nx, ny, nz, d;      // unit normal, plane offset (normal . p + d = 0)
     double p0x, p0y, p0z;      // rect: point' (corner, Main.hs:231); tri: pa
     double e1x, e1y, e1z;      // rect: width;  tri: u = pb - pa
     double e2x, e2y, e2z;      // rect: height; tri: v = pc - pa
-    double c0, c1, c2, c3;     // rect: ww, hh, 0, 0;  tri: uv, uu, vv, n
-    int32_t kind;              // LEAF_RECT / LEAF_TRI
+    double c0, c1, c2, c3;     // rect: ww, hh, 0, 0;  tri: uv, uu, vv, n;  sphere: radius (p0 = centre)
+    int32_t kind;              // LEAF_RECT / LEAF_TRI / LEAF_SPHERE
     int32_t nmode;             // rt_normal_mode
     int32_t mat;               // material index
     int32_t aux;               // index into AuxD (mantle / gaussian parameters), -1 if none
@@ -55,6 +55,8 @@ struct LightD {                // kind 0: pointLight (Main.hs:467), kind 1: ambi
 // 12 floats.  Triangle: U xyz, V xyz, N xyz, Kq, negm, 0.  Rectangle: A xyz, B xyz, N xyz, Kq, negm, 0.
 // (negm = -margin; Kq = K - mK + margin, so that the clip test N >= K - mK reads N - Kq >= negm)
 struct FilterRec { float c[12]; };
+// Sphere, apex form: oc xyz (apex - centre), cs = |oc|^2 - r^2, ..., c[10] = negm: the line A + u D meets the
+// sphere iff (D.oc)^2 - |D|^2 cs >= 0.  Sphere, general form (GenRec): centre xyz, r^2, ..., c[12] = negm.
 
 // 16 floats per leaf for rays with arbitrary origins (reflected rays, Main.hs:549-552):
 //   n xyz, dpl, g1 xyz, c1, g2 xyz, c2, negm, 0, 0, 0     with q_k(p) = g_k . p + c_k the two inside coordinates

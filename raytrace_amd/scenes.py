@@ -8,7 +8,7 @@ import numpy as np
 
 from .api import (GAUSSIAN_FNORM, COLOURS, ambient, aquamarine, black, blue, colorcube, colorcuboid, cube, cyan,
                   cylinder, gaussian, green, linearInterpolation, magenta, mconcat, mconcat_lights, orange, orchid,
-                  pointLight, rectangle, red, triangle, white, yellow)
+                  pointLight, rectangle, red, sphere, triangle, white, yellow)
 
 
 def main_lights():                                   # Main.hs:607-609
@@ -103,6 +103,20 @@ def talk_main2():                                    # Talk.hs:263-273 geometry,
     return world, mconcat_lights([ambient(0.1), pointLight(0.3, 0.0, (0, 0, 0)), pointLight(0.6, 0.0, (-1, 3, -3))])
 
 
+def spheres():                                       # Main.hs:670-690
+    mirror = black.replace(reflectivity=0.9, specular=(255, 255, 255), specularity=100)
+    world = mconcat([
+        sphere(mirror, (-2, 1, -4), 1),
+        sphere(red, (0, 1, -7), 1),
+        sphere(blue, (2, 1, -5), 1),
+        rectangle(orange, (0, -5, -10), (0, 0, 20), (20, 0, 0)),
+        rectangle(green, (0, 5, -15), (20, 0, 0), (0, 20, 0)),
+        rectangle(mirror, (0, 4, -10), (20, 0, 0), (0, 0, 20)),
+        rectangle(white, (10, 4, -10), (0, 0, 20), (0, 1, 0))])
+    lights = mconcat_lights([pointLight(0.8, 0.1, (0, 3, -10)), pointLight(0.8, 0.8, (0, 3, 0)), ambient(0.2)])
+    return world, lights
+
+
 def mirror_room():
     """The planar part of `spheres` (Main.hs:670-690): mirror floor strip and walls, lights of that scene.
     (The spheres themselves are a "next" primitive.)  Exercises trace's reflection recursion, Main.hs:546-556."""
@@ -122,7 +136,7 @@ def mirror_room():
 REFERENCE_SCENES = {
     "default": default_scene, "planes": planes, "axes": axes, "cubes": cubes, "stacked_cubes": stacked_cubes,
     "triangle_example": triangle_example, "spec_test": spec_test, "intersection": intersection,
-    "cylinder_axes": cylinder_axes, "talk_main2": talk_main2, "mirror_room": mirror_room,
+    "cylinder_axes": cylinder_axes, "talk_main2": talk_main2, "mirror_room": mirror_room, "spheres": spheres,
 }
 
 

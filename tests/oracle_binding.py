@@ -87,6 +87,8 @@ class OracleScene:
             return L.orc_rectangle(h, C.byref(_m(s.material)), _v(s.point), _v(s.width), _v(s.height))
         if isinstance(s, api.Triangle):
             return L.orc_triangle(h, C.byref(_m(s.material)), _v(s.pa), _v(s.pb), _v(s.pc))
+        if isinstance(s, api.Sphere):
+            return L.orc_sphere(h, C.byref(_m(s.material)), _v(s.center), s.radius)
         if isinstance(s, api.Cuboid):
             arr = (orc_material * len(s.materials))(*[_m(m) for m in s.materials])
             return L.orc_colorcuboid(h, arr, len(s.materials), _v(s.point), s.l, s.h, s.d)
