@@ -379,7 +379,7 @@ __device__ __forceinline__ void primary_loop(const RenderParams &P, CRecPtr recs
 }
 
 // spheres seen from the eye (few per scene: plain loop, generic apex form)
-__device__ __noinline__ void primary_sphere_loop(const RenderParams &P, const Eye4 &E, const bool act[4], int x0, int y,
+__device__ __forceinline__ void primary_sphere_loop(const RenderParams &P, const Eye4 &E, const bool act[4], int x0, int y,
                                                  double bt[4], int bid[4], unsigned &nexact) {
     Dir4 D;
     const float dz = (float)P.cam.d;
@@ -579,7 +579,7 @@ __device__ __forceinline__ void shadow_loop(const RenderParams &P, CRecPtr recs,
 }
 
 // spheres between a light and the shadow-ray origins (no own-leaf exclusion: a sphere is not planar)
-__device__ __noinline__ void shadow_sphere_loop(const RenderParams &P, CRecPtr recs, const Dir4 &D, const uint32_t pix[4],
+__device__ __forceinline__ void shadow_sphere_loop(const RenderParams &P, CRecPtr recs, const Dir4 &D, const uint32_t pix[4],
                                                 const LightD &Lt, bool need[4], unsigned &nexact) {
     f2 dd[2];
     dir_norms(D, dd);
@@ -806,7 +806,7 @@ __device__ __forceinline__ void general_loop(const RenderParams &P, CGenPtr recs
     }
 }
 
-__device__ __noinline__ void general_sphere_loop(const RenderParams &P, const Ray4 &G, const bool act[4], const uint32_t slot[4],
+__device__ __forceinline__ void general_sphere_loop(const RenderParams &P, const Ray4 &G, const bool act[4], const uint32_t slot[4],
                                                  double bt[4], int bid[4], unsigned &nexact) {
     CGenPtr recs = as_const(P.gen_sph);
     CIntPtr gids = as_const(P.sph_gid);
