@@ -88,6 +88,10 @@ def main():
     ap.add_argument("--ntri", type=int, default=10000)
     ap.add_argument("--ncuboid", type=int, default=1000)
     ap.add_argument("--depth", type=int, default=4)
+    ap.add_argument("--workload", default="synthetic", choices=["synthetic", "cylinders", "default"],
+                    help="synthetic = configs[2]/[3] (the metric's workload); cylinders = configs[4] (specular cylinders + cuboids, "
+                         "use with --spp 16 --width 7680 --height 4320); default = the Main.hs scene (configs[0]/[1])")
+    ap.add_argument("--spp", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the measured path) or gloo (rehearsal on one GPU)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank renders on GPU 0 (gloo only)")
@@ -120,9 +124,20 @@ def main():
 
     w = args.width or (3840 if n == 1 else 16384)
     h = args.height or (2160 if n == 1 else 16384)
-    world, lights = scenes.synthetic(ntri=args.ntri, ncuboid=args.ncuboid)
+    if args.workload == "synthetic":
+        world, lights = scenes.synthetic(ntri=args.ntri, ncuboid=args.ncuboid)
+        ntri, nrect, nlt = args.ntri, 6 * args.ncuboid, 4
+        wname = f"synthetic {ntri} triangles + {args.ncuboid} cuboids"
+    elif args.workload == "cylinders":
+        world, lights = scenes.synthetic_cylinders()
+        ntri, nrect, nlt = 200 * 32, 200 * 16 + 500 * 6, 4
+        wname = "200 upright cylinders (n=16) + 500 cuboids, specularity 100/400"
+    else:
+        world, lights = scenes.default_scene()
+        ntri, nrect, nlt = 200, 1, 1
+        wname = "Main.hs default scene (gaussian height field, linearInterpolation)"
     scene = api.Scene(world, lights)
-    ntri, nrect = args.ntri, 6 * args.ncuboid
+    assert scene.num_leaves == ntri + nrect
 
     bands = balanced_bands(scene, w, h, n, args.depth)
     row0, nrows = bands[rank]
@@ -133,7 +148,8 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
-        scene.render_device(w, h, mine.data_ptr(), hit.data_ptr(), depth=args.depth, row0=row0, nrows=nrows, stream=stream)
+        scene.render_device(w, h, mine.data_ptr(), hit.data_ptr(), depth=args.depth, spp=args.spp, seed=20260355,
+                            row0=row0, nrows=nrows, stream=stream)
         if n > 1 and not staged:   # row bands -> GPU 0 (ncclSend/ncclRecv in one group: every peer has a direct xGMI link)
             gather_bands(dist, frame, mine, bands, rank)
         elif staged:
@@ -180,7 +196,7 @@ def main():
     verified = None
     if args.verify and rank == 0:
         alone = torch.empty((h, w, 4), dtype=torch.uint8, device=dev)
-        scene.render_device(w, h, alone.data_ptr(), None, depth=args.depth, stream=stream)
+        scene.render_device(w, h, alone.data_ptr(), None, depth=args.depth, spp=args.spp, seed=20260355, stream=stream)
         torch.cuda.synchronize()
         verified = bool(torch.equal(alone, frame))
     if rank == 0:
@@ -197,17 +213,17 @@ def main():
             "n_gpus": n, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "strong" if n > 1 else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"synthetic {ntri} triangles + {args.ncuboid} cuboids ({ntri + nrect} leaves), 4 point lights + ambient, "
-                                   f"{w}x{h}, depth {args.depth}, spp 1, brute force"
+            "config": {"workload": f"{wname} ({ntri + nrect} leaves), {nlt} point light(s) + ambient, "
+                                   f"{w}x{h}, depth {args.depth}, spp {args.spp}, brute force"
                                    + (f", {n} cost-balanced row bands gathered to GPU 0 over " + ("RCCL" if not staged else "gloo via host memory (rehearsal)") if n > 1 else ""),
-                       "width": w, "height": h, "leaves": ntri + nrect, "lights": 4,
+                       "width": w, "height": h, "leaves": ntri + nrect, "lights": nlt, "spp": args.spp,
                        "bands": bands if n > 1 else None, "gathered_frame_equals_single_render": verified,
                        "shadow_rays_per_frame": shadow, "exact_fp64_evals_per_frame": exact,
                        "whole_frame_algorithmic_tflops": (primary + shadow) * per_test / (dt / args.steps) / 1e12,
                        "kernel_ms": {"k_primary": ms_prim, "k_setup": stats["ms_setup"], "k_shadow": ms_shade, "k_final": stats["ms_final"]}},
             "roofline": {"bound": "valu_fp32", "kernel": "k_shadow", "achieved": achieved, "peak": PEAK_FP32_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS,
-                         "traffic": K_SHADOW_TRAFFIC_BYTES_DEFAULT if (n == 1 and (w, h, ntri, nrect) == (3840, 2160, 10000, 6000)) else None,
+                         "traffic": K_SHADOW_TRAFFIC_BYTES_DEFAULT if (n == 1 and args.spp == 1 and args.workload == "synthetic" and (w, h, ntri, nrect) == (3840, 2160, 10000, 6000)) else None,
                          "traffic_unit": "bytes per launch (rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE, profiles/r01_pmc_*)",
                          "note": "algorithmic flops (53/45 per ray x triangle/rectangle test) x shadow rays cast x leaves, per launch"},
         }

@@ -187,3 +187,21 @@ def test_reflection_depths(gpu_lib):
     rgba, hit = sc.render(96, 72, depth=4, spp=4, seed=11)
     assert (rgba[:, :, :3] == ref["rgb"]).all() and (hit == ref["hit_id"]).all()
     sc.close()
+
+
+def test_cpp_main_matches_oracle(gpu_lib, tmp_path):
+    """examples/main (C++ mirror of the reference's main, Main.hs:569-621): BMP pixels and hit IDs vs the oracle."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "main")
+    w, h = 200, 120
+    bmp, ids = tmp_path / "trace.bmp", tmp_path / "ids.bin"
+    r = subprocess.run([exe, str(w), str(h), str(bmp), str(ids)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    raw = bmp.read_bytes()
+    row = (3 * w + 3) & ~3
+    px = np.frombuffer(raw, np.uint8, offset=54).reshape(h, row)[:, :3 * w].reshape(h, w, 3)[::-1, :, ::-1]
+    world, lights = scenes.default_scene()
+    ref = ob.OracleScene(world, lights).render(w, h)
+    assert (px == ref["rgb"]).all()
+    assert (np.fromfile(ids, np.int32).reshape(h, w) == ref["hit_id"]).all()

@@ -159,3 +159,16 @@ def test_render_without_a_gpu_fails_loudly():
     with pytest.raises(RuntimeError, match="no HIP device|hip"):
         sc.render(16, 16)
     sc.close()
+
+
+def test_cpp_host_mirror_builds_and_fails_loudly_without_gpu(tmp_path):
+    """include/raytrace.hpp + examples/main.cpp (the reference's `main`) compile against the C ABI."""
+    import subprocess
+    import torch
+    subprocess.run(["make", "-C", os.path.join(ROOT, "examples")], check=True, capture_output=True)
+    exe = os.path.join(ROOT, "examples", "main")
+    assert os.path.exists(exe)
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the GPU test runs the binary")
+    r = subprocess.run([exe, "32", "32", str(tmp_path / "t.bmp")], capture_output=True, text=True)
+    assert r.returncode == 1 and "no HIP device" in r.stderr
