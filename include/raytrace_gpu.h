@@ -119,8 +119,8 @@ int  rt_scene_get_leaf(const rt_scene *, int leaf, double out[20]);
  * bracket) and the FP32 filter records.  Returns the number of guard boxes.  No device needed. */
 int  rt_scene_prepare_host(rt_scene *, int w, int h);
 /* Filter record of `leaf` for apex 0 (the eye) or 1 + k (the k-th point light), after
- * rt_scene_prepare_host: out[0..11] as laid out in raytrace_amd/csrc/rt_types.h (FilterRec). */
-int  rt_scene_get_filter_record(const rt_scene *, int apex, int leaf, float out[12]);
+ * rt_scene_prepare_host: out[0..15] as laid out in raytrace_amd/csrc/rt_types.h (FilterRec). */
+int  rt_scene_get_filter_record(const rt_scene *, int apex, int leaf, float out[16]);
 /* Guard chain of `leaf`: writes up to cap boxes {x0,y0,z0,x1,y1,z1}, innermost first; returns the count. */
 int  rt_scene_get_guards(const rt_scene *, int leaf, double *out, int cap);
 /* fixedCamera w h: out = {scaleX, scaleY, dX, dY, d}                      Main.hs:506-527 */

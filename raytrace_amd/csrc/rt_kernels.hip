@@ -37,6 +37,9 @@ typedef const int32_t RT_CONST *CIntPtr;
 #define RT_TILE_W 32
 #define RT_TILE_H 8
 #define RT_WAVES_PER_BLOCK 4
+#ifndef RT_SHADOW_CLIP
+#define RT_SHADOW_CLIP 0       // 1: shadow filter tests "not beyond the ray origin" per leaf (6 more VALU per 4 rays)
+#endif
 #ifndef RT_PREFETCH
 #define RT_PREFETCH 1          // double-buffer the leaf records in SGPRs
 #endif
@@ -230,11 +233,11 @@ __device__ __forceinline__ bool guards_ok(const GuardD *__restrict__ G, int g, c
 
 __device__ __forceinline__ CRecPtr as_const(const FilterRec *p) { return (CRecPtr)(const void *)p; }
 __device__ __forceinline__ CIntPtr as_const(const int32_t *p) { return (CIntPtr)(const void *)p; }
+template <int N = 11>
 __device__ __forceinline__ FilterRec load_rec(CRecPtr p) {
     FilterRec r;
 #pragma unroll
-    for (int k = 0; k < 11; ++k) r.c[k] = p->c[k];
-    r.c[11] = 0.f;
+    for (int k = 0; k < 16; ++k) r.c[k] = k < N ? p->c[k] : 0.f;
     return r;
 }
 __device__ __forceinline__ f2 splat(float v) { f2 r = {v, v}; return r; }
@@ -255,7 +258,7 @@ __device__ __forceinline__ bool filter4(const FilterRec &R, const Dir4 &D, float
         const f2 n = pkfma(splat(R.c[6]), D.x[p], pkfma(splat(R.c[7]), D.y[p], splat(R.c[8]) * D.z[p]));
         f2 zz;
         if (KIND == LEAF_TRI) {
-            const f2 w = n - q1 - q2;
+            const f2 w = CLIP ? n - q1 - q2 : n;      // without the clip the third form already is W
             zz = f2{__builtin_fminf(__builtin_fminf(q1[0], q2[0]), w[0]), __builtin_fminf(__builtin_fminf(q1[1], q2[1]), w[1])};
         } else {
             const f2 m = f2{__builtin_fmaxf(__builtin_fabsf(q1[0]), __builtin_fabsf(q2[0])),
@@ -535,31 +538,48 @@ __global__ void __launch_bounds__(256) k_setup(const RenderParams P) {
 
 template <int KIND>
 __device__ __forceinline__ void shadow_loop(const RenderParams &P, CRecPtr recs, CIntPtr gids, int n, const Dir4 &D,
-                                            const uint32_t pix[4], const LightD &Lt, bool need[4], unsigned &nexact) {
+                                            const uint32_t pix[4], const int own[4], const LightD &Lt, bool need[4],
+                                            unsigned &nexact) {
+    constexpr int NLOAD = RT_SHADOW_CLIP ? 11 : 14;
     if (n <= 0) return;
-    FilterRec cur = load_rec(recs);
+    FilterRec cur = load_rec<NLOAD>(recs);
     for (int i = 0; i < n; ++i) {
 #if RT_PREFETCH
-        const FilterRec nxt = load_rec(recs + i + 1);     // scalar loads of the next leaf fly during this one (arrays are padded)
+        const FilterRec nxt = load_rec<NLOAD>(recs + i + 1);   // scalar loads of the next leaf fly during this one (arrays are padded)
 #else
-        cur = load_rec(recs + i);
+        cur = load_rec<NLOAD>(recs + i);
 #endif
         float z[4];
-        const bool any = filter4<KIND, true>(cur, D, z);
-        const float negm = cur.c[10];
-#if RT_PREFETCH
-        cur = nxt;
+        if (filter4<KIND, RT_SHADOW_CLIP != 0>(cur, D, z)) {
+            const float negm = cur.c[10];
+#ifdef RT_COUNT_EVENTS
+            if ((threadIdx.x & 63) == __builtin_amdgcn_readfirstlane(threadIdx.x & 63)) atomicAdd(&P.counters[3], 1ull);
 #endif
-        if (any) {
-            const int gid = gids[i];
-            const LeafD &L = P.leaves[gid];
+            bool cand[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if ((z[r] >= negm) & need[r]) {
-                    uint32_t pr = pix[r];
-                    asm volatile("" : "+v"(pr));   // keep the exact-path ray set-up inside this rare branch
+            for (int r = 0; r < 4; ++r) cand[r] = (z[r] >= negm) & need[r];
+#if !RT_SHADOW_CLIP
+            // The fast filter tests the whole line from the light through the shadow-ray origin.  Keep only the
+            // rays whose SEGMENT light..origin can meet the plane: N.D >= K (Main.hs:474 needs t <= distance).
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const f2 nd = pkfma(splat(cur.c[11]), D.x[p], pkfma(splat(cur.c[12]), D.y[p], splat(cur.c[13]) * D.z[p]));
+                cand[2 * p] &= nd[0] >= cur.c[9];
+                cand[2 * p + 1] &= nd[1] >= cur.c[9];
+            }
+#endif
+            if (cand[0] | cand[1] | cand[2] | cand[3]) {
+                const int gid = gids[i];
+                const LeafD &L = P.leaves[gid];
+#ifdef RT_COUNT_EVENTS
+                if ((threadIdx.x & 63) == __builtin_amdgcn_readfirstlane(threadIdx.x & 63)) atomicAdd(&P.counters[4], 1ull);
+#endif
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
                     // the hit leaf itself lies 1e-5 behind the shadow-ray origin (Main.hs:472): t < 0
-                    if (P.hit_id[P.out_off + pr] != gid) {
+                    if (cand[r] & (own[r] != gid)) {
+                        uint32_t pr = pix[r];
+                        asm volatile("" : "+v"(pr));   // keep the exact-path ray set-up inside this rare branch
                         const HitRec H = P.hitrec[pr];
                         double tx, ty, tz;
                         to_light(Lt, H.px, H.py, H.pz, tx, ty, tz);
@@ -575,6 +595,9 @@ __device__ __forceinline__ void shadow_loop(const RenderParams &P, CRecPtr recs,
                 }
             }
         }
+#if RT_PREFETCH
+        cur = nxt;
+#endif
     }
 }
 
@@ -622,13 +645,14 @@ __global__ void RT_HOT(RT_WAVES_EU_SHADOW) k_shadow(const RenderParams P) {
     for (int k = -1; li < P.nlights; ++li) if (P.lights[li].kind == 0 && ++k == pl) break;
     const LightD &Lt = P.lights[li];
     const uint32_t *q = P.queue + (size_t)pl * (size_t)P.qcap;
-    uint32_t pix[4]; bool need[4];
+    uint32_t pix[4]; bool need[4]; int own[4];
     float ddx[4], ddy[4], ddz[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const unsigned j = wave * 256u + (unsigned)(r * 64 + lane);
         need[r] = j < count;
         pix[r] = need[r] ? q[j] : 0u;
+        own[r] = need[r] ? P.hit_id[P.out_off + pix[r]] : -1;
         ddx[r] = ddy[r] = ddz[r] = 0.f;
         if (need[r]) {
             const HitRec H = P.hitrec[pix[r]];
@@ -649,8 +673,8 @@ __global__ void RT_HOT(RT_WAVES_EU_SHADOW) k_shadow(const RenderParams P) {
     unsigned nexact = 0;
     // wave-uniform by construction; say so, or the record loads become per-lane vector loads
     const size_t ro = (size_t)__builtin_amdgcn_readfirstlane(Lt.rec_offset);
-    shadow_loop<LEAF_TRI>(P, as_const(P.tri_rec + ro * (size_t)P.ntri), as_const(P.tri_gid), P.ntri, D, pix, Lt, need, nexact);
-    shadow_loop<LEAF_RECT>(P, as_const(P.rect_rec + ro * (size_t)P.nrect), as_const(P.rect_gid), P.nrect, D, pix, Lt, need, nexact);
+    shadow_loop<LEAF_TRI>(P, as_const(P.tri_rec + ro * (size_t)P.ntri), as_const(P.tri_gid), P.ntri, D, pix, own, Lt, need, nexact);
+    shadow_loop<LEAF_RECT>(P, as_const(P.rect_rec + ro * (size_t)P.nrect), as_const(P.rect_gid), P.nrect, D, pix, own, Lt, need, nexact);
     if (P.nsph > 0) shadow_sphere_loop(P, as_const(P.sph_rec + ro * (size_t)P.nsph), D, pix, Lt, need, nexact);
 #pragma unroll
     for (int r = 0; r < 4; ++r)
@@ -1213,6 +1237,9 @@ int rt_get_stats(rt_scene *s, rt_stats *out) {
         st.tri_tests = (st.primary_rays + st.shadow_rays) * (uint64_t)s->tri_gid.size();
         st.rect_tests = (st.primary_rays + st.shadow_rays) * (uint64_t)s->rect_gid.size();
         st.exact_evals = c[1] + c[2];
+#ifdef RT_COUNT_EVENTS
+        fprintf(stderr, "[rt] shadow filter events (wave x leaf) %llu, with a segment candidate %llu, exact evals primary %llu shadow %llu\n", c[3], c[4], c[1], c[2]);
+#endif
         st.ms_primary = ms[1]; st.ms_setup = ms[2]; st.ms_shadow = ms[3]; st.ms_final = ms[4]; st.ms_total = tot;
         s->stats = st;
         s->stats_pending = false;

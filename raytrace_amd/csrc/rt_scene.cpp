@@ -6,6 +6,10 @@
 // -ffp-contract=off), because the kernels' exact path must reproduce the reference bit for bit.
 #include "rt_scene.h"
 
+#ifndef RT_SHADOW_CLIP
+#define RT_SHADOW_CLIP 0      // must match rt_kernels.hip
+#endif
+
 #include <cmath>
 #include <cstring>
 #include <limits>
@@ -253,11 +257,24 @@ static FilterRec make_rec(const LeafD &L, const double A[3], const double dmax[3
         for (int i = 0; i < 11; ++i) if (!std::isfinite(r.c[i])) return always_rec();
         return r;
     }
+#if RT_SHADOW_CLIP
     for (int i = 0; i < 3; ++i) { r.c[i] = (float)c1[i]; r.c[3 + i] = (float)c2[i]; r.c[6 + i] = (float)cn[i]; }
+#else
+    // Light apex without the clip form: a triangle stores W = N - U - V, like the eye apex.  Leaves beyond the
+    // shadow-ray origin then pass the filter too; k_shadow drops them with a plane-side test before the exact path.
+    for (int i = 0; i < 3; ++i) {
+        r.c[i] = (float)c1[i]; r.c[3 + i] = (float)c2[i];
+        r.c[6 + i] = (float)(L.kind == LEAF_TRI ? cn[i] - c1[i] - c2[i] : cn[i]);
+    }
+#endif
     r.c[10] = f_down(-m);
+#if RT_SHADOW_CLIP
     r.c[9] = f_down((K - mK) - (double)r.c[10]);   // Kq: N - Kq >= -m  <=>  N >= K - mK
-    r.c[11] = 0.0f;
-    for (int i = 0; i < 11; ++i) if (!std::isfinite(r.c[i])) return always_rec();   // FP32 overflow
+#else
+    r.c[9] = f_down(K - mK);                       // candidate path: N.D >= Kq, N in c[11..13]
+#endif
+    for (int i = 0; i < 3; ++i) r.c[11 + i] = (float)cn[i];
+    for (int i = 0; i < 14; ++i) if (!std::isfinite(r.c[i])) return always_rec();   // FP32 overflow
     return r;
 }
 
@@ -593,14 +610,14 @@ int rt_scene_prepare_host(rt_scene *s, int w, int h) {
     return (int)s->guards.size();
 }
 
-int rt_scene_get_filter_record(const rt_scene *s, int apex, int leaf, float out[12]) {
+int rt_scene_get_filter_record(const rt_scene *s, int apex, int leaf, float out[16]) {
     if (!s || !out || leaf < 0 || (size_t)leaf >= s->leaves.size() || apex < 0 || apex > s->npoint || s->rec_w < 0) {
         set_error("rt_scene_get_filter_record: bad argument (call rt_scene_prepare_host first)"); return RT_ERR_ARG;
     }
     const LeafD &L = s->leaves[leaf];
     const std::vector<FilterRec> &v = L.kind == LEAF_TRI ? s->tri_rec : (L.kind == LEAF_SPHERE ? s->sph_rec : s->rect_rec);
     const size_t n = L.kind == LEAF_TRI ? s->tri_gid.size() : (L.kind == LEAF_SPHERE ? s->sph_gid.size() : s->rect_gid.size());
-    std::memcpy(out, v[(size_t)apex * n + (size_t)L.slot].c, sizeof(float) * 12);
+    std::memcpy(out, v[(size_t)apex * n + (size_t)L.slot].c, sizeof(float) * 16);
     return RT_OK;
 }
 

@@ -52,9 +52,11 @@ struct LightD {                // kind 0: pointLight (Main.hs:467), kind 1: ambi
     int32_t rec_offset;        // index of this light's filter records block (point lights)
 };
 
-// 12 floats.  Triangle: U xyz, V xyz, N xyz, Kq, negm, 0.  Rectangle: A xyz, B xyz, N xyz, Kq, negm, 0.
-// (negm = -margin; Kq = K - mK + margin, so that the clip test N >= K - mK reads N - Kq >= negm)
-struct FilterRec { float c[12]; };
+// 16 floats (one 64-byte line).  c[0..8]: three linear forms of the ray direction D from the apex —
+// triangle U, V, W (= N - U - V); rectangle A, B, N.  c[9] = Kq, c[10] = negm (= -margin), c[11..13] = N xyz
+// (the sign-normalised plane normal: N.D >= Kq  <=>  the plane is met between the apex and A + D; only the
+// shadow kernel's candidate path reads it), c[14..15] spare.
+struct FilterRec { float c[16]; };
 // Sphere, apex form: oc xyz (apex - centre), cs = |oc|^2 - r^2, ..., c[10] = negm: the line A + u D meets the
 // sphere iff (D.oc)^2 - |D|^2 cs >= 0.  Sphere, general form (GenRec): centre xyz, r^2, ..., c[12] = negm.
 

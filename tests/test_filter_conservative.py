@@ -18,8 +18,8 @@ def fma32(a, b, c):
 def records(sc, apex, w, h):
     L = _lib.lib()
     assert L.rt_scene_prepare_host(sc.handle, w, h) >= 0
-    out = (C.c_float * 12)()
-    recs = np.zeros((sc.num_leaves, 12), np.float32)
+    out = (C.c_float * 16)()
+    recs = np.zeros((sc.num_leaves, 16), np.float32)
     for i in range(sc.num_leaves):
         assert L.rt_scene_get_filter_record(sc.handle, apex, i, out) == 0
         recs[i] = np.frombuffer(out, np.float32)
@@ -76,7 +76,7 @@ def test_eye_filter_is_selective():
 
 
 def test_light_filter_accepts_every_occluder():
-    """Shadow filter (apex = light, clip to the segment): every leaf that the oracle's exact test finds
+    """Shadow filter (apex = light): every leaf that the oracle's exact test finds
     between a hit point and the light must pass, for each such (pixel, light) of stacked_cubes."""
     world, lights = scenes.stacked_cubes()
     w = h = 64
@@ -125,9 +125,12 @@ def test_light_filter_accepts_every_occluder():
                         continue
                     rec = recs[i]
                     f = [np.float32(np.float64(rec[3 * j]) * D[0] + np.float64(rec[3 * j + 1]) * D[1] + np.float64(rec[3 * j + 2]) * D[2]) for j in range(3)]
-                    z = min(f[0], f[1], f[2] - f[0] - f[1]) if kinds[i] == 1 else f[2] - max(abs(f[0]), abs(f[1]))
-                    z = min(z, f[2] - rec[9])
+                    # third form: W for triangles, N for rectangles (rt_scene.cpp: make_rec, light apex)
+                    z = min(f[0], f[1], f[2]) if kinds[i] == 1 else f[2] - max(abs(f[0]), abs(f[1]))
                     assert z >= rec[10], f"light {k} pixel ({x},{y}) leaf {i}: occluder rejected by the shadow filter"
+                    # candidate path of k_shadow: the segment light..origin must be kept (N.D >= Kq)
+                    nd = np.float32(np.float64(rec[11]) * D[0] + np.float64(rec[12]) * D[1] + np.float64(rec[13]) * D[2])
+                    assert nd >= rec[9], f"light {k} pixel ({x},{y}) leaf {i}: occluder dropped by the segment clip"
                     checked += 1
     assert checked > 200
     sc.close()
