@@ -233,19 +233,24 @@ __device__ __forceinline__ bool guards_ok(const GuardD *__restrict__ G, int g, c
 
 __device__ __forceinline__ CRecPtr as_const(const FilterRec *p) { return (CRecPtr)(const void *)p; }
 __device__ __forceinline__ CIntPtr as_const(const int32_t *p) { return (CIntPtr)(const void *)p; }
-template <int N = 11>
+template <int N = 10>
 __device__ __forceinline__ FilterRec load_rec(CRecPtr p) {
     FilterRec r;
 #pragma unroll
     for (int k = 0; k < 16; ++k) r.c[k] = k < N ? p->c[k] : 0.f;
     return r;
 }
+// p, but not before record r has arrived: orders a prefetch after the wait for the record in use
+__device__ __forceinline__ CRecPtr after(CRecPtr p, const FilterRec &r) {
+    asm volatile("" : "+s"(p) : "s"(r.c[0]));
+    return p;
+}
 __device__ __forceinline__ f2 splat(float v) { f2 r = {v, v}; return r; }
 __device__ __forceinline__ f2 pkfma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 
 struct Dir4 { f2 x[2], y[2], z[2]; };   // directions of the lane's 4 rays from the apex
 
-// Returns z[r] for the lane's 4 rays: ray r passes the filter iff z[r] >= R.c[10] (= -margin).
+// Returns z[r] for the lane's 4 rays: ray r passes the filter iff z[r] >= R.c[9] (= -margin).
 //   triangle : z = min(q1*N, q2*N, (1-q1-q2)*N [, N - Kq])      q1, q2 = barycentrics r, s
 //   rectangle: z = min(N - max(|a'N|, |b'N|)     [, N - Kq])     a', b' in [-1, 1]
 // CLIP adds the "not beyond the ray origin" test u* = K/N <= 1 used by shadow rays.
@@ -266,13 +271,13 @@ __device__ __forceinline__ bool filter4(const FilterRec &R, const Dir4 &D, float
             zz = n - m;
         }
         if (CLIP) {
-            const f2 c = n - splat(R.c[9]);
+            const f2 c = n - splat(R.c[10]);
             zz = f2{__builtin_fminf(zz[0], c[0]), __builtin_fminf(zz[1], c[1])};
         }
         z[2 * p] = zz[0]; z[2 * p + 1] = zz[1];
     }
     const float mx = __builtin_fmaxf(__builtin_fmaxf(z[0], z[1]), __builtin_fmaxf(z[2], z[3]));
-    return mx >= R.c[10];
+    return mx >= R.c[9];
 }
 
 // Sphere, apex form: z = (D.oc)^2 - |D|^2 cs; dd = |D|^2 of the lane's rays.
@@ -284,7 +289,7 @@ __device__ __forceinline__ bool filter4_sphere(const FilterRec &R, const Dir4 &D
         z[2 * p] = zz[0]; z[2 * p + 1] = zz[1];
     }
     const float mx = __builtin_fmaxf(__builtin_fmaxf(z[0], z[1]), __builtin_fmaxf(z[2], z[3]));
-    return mx >= R.c[10];
+    return mx >= R.c[9];
 }
 __device__ __forceinline__ void dir_norms(const Dir4 &D, f2 dd[2]) {
 #pragma unroll
@@ -323,7 +328,7 @@ __device__ __forceinline__ bool filter4_eye(const FilterRec &R, const Eye4 &E, f
         }
     }
     const float mx = __builtin_fmaxf(__builtin_fmaxf(z[0], z[1]), __builtin_fmaxf(z[2], z[3]));
-    return mx >= R.c[10];
+    return mx >= R.c[9];
 }
 
 __device__ __forceinline__ void tile_coords(const RenderParams &P, int &x0, int &y, bool &row_ok) {
@@ -347,20 +352,10 @@ __device__ __forceinline__ void primary_loop(const RenderParams &P, CRecPtr recs
                                              const bool act[4], int x0, int y, double bt[4], int bid[4],
                                              unsigned &nexact) {
     if (n <= 0) return;
-    FilterRec cur = load_rec(recs);
-    for (int i = 0; i < n; ++i) {
-#if RT_PREFETCH
-        const FilterRec nxt = load_rec(recs + i + 1);     // scalar loads of the next leaf fly during this one (arrays are padded)
-#else
-        cur = load_rec(recs + i);
-#endif
+    auto body = [&](const FilterRec &cur, int i) {
         float z[4];
-        const bool any = filter4_eye<KIND, SHARED_Y>(cur, D, z);
-        const float negm = cur.c[10];
-#if RT_PREFETCH
-        cur = nxt;
-#endif
-        if (any) {
+        if (filter4_eye<KIND, SHARED_Y>(cur, D, z)) {
+            const float negm = cur.c[9];
             const int gid = gids[i];
             const LeafD &L = P.leaves[gid];
 #pragma unroll
@@ -378,7 +373,23 @@ __device__ __forceinline__ void primary_loop(const RenderParams &P, CRecPtr recs
                 }
             }
         }
+    };
+#if RT_PREFETCH
+    // Two record buffers in SGPRs, used in turn (no copies).  Scalar loads return out of order, so the only wait
+    // there is waits for ALL of them: the load of record i + 1 is issued right after the wait for record i (the
+    // asm ties its address to a register of record i) and has the whole test of record i to arrive.
+    FilterRec a = load_rec(recs);
+    int i = 0;
+    for (; i + 1 < n; i += 2) {
+        const FilterRec b = load_rec(after(recs + i + 1, a));
+        body(a, i);
+        a = load_rec(after(recs + i + 2, b));             // arrays are padded: i + 2 may be one past the end
+        body(b, i + 1);
     }
+    if (i < n) body(a, i);
+#else
+    for (int i = 0; i < n; ++i) body(load_rec(recs + i), i);
+#endif
 }
 
 // spheres seen from the eye (few per scene: plain loop, generic apex form)
@@ -400,7 +411,7 @@ __device__ __forceinline__ void primary_sphere_loop(const RenderParams &P, const
             const LeafD &L = P.leaves[gid];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                if ((z[r] >= cur.c[10]) & act[r]) {
+                if ((z[r] >= cur.c[9]) & act[r]) {
                     int xr = x0 + r;
                     asm volatile("" : "+v"(xr));
                     const RayD ray = camera_ray(P, xr, y);
@@ -540,18 +551,12 @@ template <int KIND>
 __device__ __forceinline__ void shadow_loop(const RenderParams &P, CRecPtr recs, CIntPtr gids, int n, const Dir4 &D,
                                             const uint32_t pix[4], const int own[4], const LightD &Lt, bool need[4],
                                             unsigned &nexact) {
-    constexpr int NLOAD = RT_SHADOW_CLIP ? 11 : 14;
+    constexpr int NLOAD = RT_SHADOW_CLIP ? 11 : 10;   // the hot test reads c[0..9]; Kq and N stay in memory
     if (n <= 0) return;
-    FilterRec cur = load_rec<NLOAD>(recs);
-    for (int i = 0; i < n; ++i) {
-#if RT_PREFETCH
-        const FilterRec nxt = load_rec<NLOAD>(recs + i + 1);   // scalar loads of the next leaf fly during this one (arrays are padded)
-#else
-        cur = load_rec<NLOAD>(recs + i);
-#endif
+    auto body = [&](const FilterRec &cur, int i) {
         float z[4];
         if (filter4<KIND, RT_SHADOW_CLIP != 0>(cur, D, z)) {
-            const float negm = cur.c[10];
+            const float negm = cur.c[9];
 #ifdef RT_COUNT_EVENTS
             if ((threadIdx.x & 63) == __builtin_amdgcn_readfirstlane(threadIdx.x & 63)) atomicAdd(&P.counters[3], 1ull);
 #endif
@@ -560,12 +565,14 @@ __device__ __forceinline__ void shadow_loop(const RenderParams &P, CRecPtr recs,
             for (int r = 0; r < 4; ++r) cand[r] = (z[r] >= negm) & need[r];
 #if !RT_SHADOW_CLIP
             // The fast filter tests the whole line from the light through the shadow-ray origin.  Keep only the
-            // rays whose SEGMENT light..origin can meet the plane: N.D >= K (Main.hs:474 needs t <= distance).
+            // rays whose SEGMENT light..origin can meet the plane: N.D >= Kq (Main.hs:474 needs t <= distance).
+            // Kq and N are fetched here, on the rare path, so the loop carries 10 SGPRs per record, not 14.
+            const float kq = recs[i].c[10], nx = recs[i].c[11], ny = recs[i].c[12], nz = recs[i].c[13];
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
-                const f2 nd = pkfma(splat(cur.c[11]), D.x[p], pkfma(splat(cur.c[12]), D.y[p], splat(cur.c[13]) * D.z[p]));
-                cand[2 * p] &= nd[0] >= cur.c[9];
-                cand[2 * p + 1] &= nd[1] >= cur.c[9];
+                const f2 nd = pkfma(splat(nx), D.x[p], pkfma(splat(ny), D.y[p], splat(nz) * D.z[p]));
+                cand[2 * p] &= nd[0] >= kq;
+                cand[2 * p + 1] &= nd[1] >= kq;
             }
 #endif
             if (cand[0] | cand[1] | cand[2] | cand[3]) {
@@ -595,10 +602,20 @@ __device__ __forceinline__ void shadow_loop(const RenderParams &P, CRecPtr recs,
                 }
             }
         }
+    };
 #if RT_PREFETCH
-        cur = nxt;
-#endif
+    FilterRec a = load_rec<NLOAD>(recs);                   // two SGPR buffers used in turn, see primary_loop
+    int i = 0;
+    for (; i + 1 < n; i += 2) {
+        const FilterRec b = load_rec<NLOAD>(after(recs + i + 1, a));
+        body(a, i);
+        a = load_rec<NLOAD>(after(recs + i + 2, b));
+        body(b, i + 1);
     }
+    if (i < n) body(a, i);
+#else
+    for (int i = 0; i < n; ++i) body(load_rec<NLOAD>(recs + i), i);
+#endif
 }
 
 // spheres between a light and the shadow-ray origins (no own-leaf exclusion: a sphere is not planar)
@@ -615,7 +632,7 @@ __device__ __forceinline__ void shadow_sphere_loop(const RenderParams &P, CRecPt
             const LeafD &L = P.leaves[gid];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                if ((z[r] >= cur.c[10]) & need[r]) {
+                if ((z[r] >= cur.c[9]) & need[r]) {
                     uint32_t pr = pix[r];
                     asm volatile("" : "+v"(pr));
                     const HitRec H = P.hitrec[pr];

@@ -154,11 +154,11 @@ static FilterRec make_sphere_rec(const LeafD &L, const double A[3], const double
     double B = 0, DD = 0;
     for (int i = 0; i < 3; ++i) { B += std::fabs(oc[i]) * dmax[i]; DD += dmax[i] * dmax[i]; }
     const double m = std::ldexp(B * B + DD * (oo + L.c0 * L.c0), -19) + 1e-30;
-    r.c[10] = 1.0f;
-    if (!std::isfinite(m)) { r.c[10] = -1.0f; return r; }      // all-zero forms, negm = -1: always passes
+    r.c[9] = 1.0f;
+    if (!std::isfinite(m)) { r.c[9] = -1.0f; return r; }      // all-zero forms, negm = -1: always passes
     for (int i = 0; i < 3; ++i) r.c[i] = (float)oc[i];
     r.c[3] = (float)cs;
-    r.c[10] = f_down(-m);
+    r.c[9] = f_down(-m);
     return r;
 }
 static GenRec make_sphere_gen_rec(const LeafD &L, const double omax[3]) {
@@ -192,14 +192,14 @@ static inline float f_down(double v) {
 
 static FilterRec never_rec() {   // degenerate leaf (NaN normal): the reference never hits it
     FilterRec r{};
-    r.c[9] = 0.0f;
-    r.c[10] = 1.0f;     // z <= 0 < 1: never passes
+    r.c[10] = 0.0f;
+    r.c[9] = 1.0f;     // z <= 0 < 1: never passes
     return r;
 }
 static FilterRec always_rec() {  // apex (numerically) in the leaf's plane: let the exact path decide
     FilterRec r{};
-    r.c[9] = -1.0f;
     r.c[10] = -1.0f;
+    r.c[9] = -1.0f;
     return r;
 }
 
@@ -252,8 +252,8 @@ static FilterRec make_rec(const LeafD &L, const double A[3], const double dmax[3
         for (int k = 0; k < 3; ++k) {
             r.c[3 * k] = (float)f[k][0]; r.c[3 * k + 1] = (float)f[k][1]; r.c[3 * k + 2] = (float)(f[k][2] * eye_d);
         }
-        r.c[10] = f_down(-m);
-        r.c[9] = 0.0f;
+        r.c[9] = f_down(-m);
+        r.c[10] = 0.0f;
         for (int i = 0; i < 11; ++i) if (!std::isfinite(r.c[i])) return always_rec();
         return r;
     }
@@ -267,11 +267,11 @@ static FilterRec make_rec(const LeafD &L, const double A[3], const double dmax[3
         r.c[6 + i] = (float)(L.kind == LEAF_TRI ? cn[i] - c1[i] - c2[i] : cn[i]);
     }
 #endif
-    r.c[10] = f_down(-m);
+    r.c[9] = f_down(-m);
 #if RT_SHADOW_CLIP
-    r.c[9] = f_down((K - mK) - (double)r.c[10]);   // Kq: N - Kq >= -m  <=>  N >= K - mK
+    r.c[10] = f_down((K - mK) - (double)r.c[9]);   // Kq: N - Kq >= -m  <=>  N >= K - mK
 #else
-    r.c[9] = f_down(K - mK);                       // candidate path: N.D >= Kq, N in c[11..13]
+    r.c[10] = f_down(K - mK);                       // candidate path: N.D >= Kq, N in c[11..13]
 #endif
     for (int i = 0; i < 3; ++i) r.c[11 + i] = (float)cn[i];
     for (int i = 0; i < 14; ++i) if (!std::isfinite(r.c[i])) return always_rec();   // FP32 overflow
@@ -381,10 +381,10 @@ static GenRec make_gen_rec(const LeafD &L, const double omax[3]) {
 void build_filter_records(rt_scene &s, int w, int h) {
     const size_t ntri = s.tri_gid.size(), nrect = s.rect_gid.size(), nsph = s.sph_gid.size();
     const int napex = 1 + s.npoint;
-    s.sph_rec.assign(nsph * (size_t)napex + 1, never_rec());
-    // one record of padding: the kernels prefetch record i + 1 while testing record i
-    s.tri_rec.assign(ntri * (size_t)napex + 1, never_rec());
-    s.rect_rec.assign(nrect * (size_t)napex + 1, never_rec());
+    s.sph_rec.assign(nsph * (size_t)napex + 4, never_rec());
+    // four records of padding: the kernels prefetch up to record i + 2 while testing record i
+    s.tri_rec.assign(ntri * (size_t)napex + 4, never_rec());
+    s.rect_rec.assign(nrect * (size_t)napex + 4, never_rec());
     // scene extent (leaf corners), for the per-light bound on |D| = |hit - light|
     double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
     for (const LeafD &L : s.leaves) {

@@ -5,7 +5,7 @@
 //              constructors (rectangle Main.hs:228-232, triangle Main.hs:365-372).  Only the few
 //              candidate (ray, leaf) pairs that survive the FP32 filter are evaluated on it, with
 //              the reference's own expression order, so hit IDs and colours agree bit for bit.
-//   * FilterRec — 12 floats per (apex, leaf): linear forms of the ray direction D from a common
+//   * FilterRec — 16 floats per (apex, leaf): linear forms of the ray direction D from a common
 //              apex (the eye for primary rays, a light for shadow rays).  This is what the
 //              brute-force O(rays x leaves) loops read, as wave-uniform scalar operands.
 #pragma once
@@ -53,11 +53,11 @@ struct LightD {                // kind 0: pointLight (Main.hs:467), kind 1: ambi
 };
 
 // 16 floats (one 64-byte line).  c[0..8]: three linear forms of the ray direction D from the apex —
-// triangle U, V, W (= N - U - V); rectangle A, B, N.  c[9] = Kq, c[10] = negm (= -margin), c[11..13] = N xyz
-// (the sign-normalised plane normal: N.D >= Kq  <=>  the plane is met between the apex and A + D; only the
-// shadow kernel's candidate path reads it), c[14..15] spare.
+// triangle U, V, W (= N - U - V); rectangle A, B, N.  c[9] = negm (= -margin): the loops keep c[0..9] in SGPRs.
+// c[10] = Kq, c[11..13] = N xyz (the sign-normalised plane normal: N.D >= Kq  <=>  the plane is met between the
+// apex and A + D): read from memory by the shadow kernel's candidate path only.  c[14..15] spare.
 struct FilterRec { float c[16]; };
-// Sphere, apex form: oc xyz (apex - centre), cs = |oc|^2 - r^2, ..., c[10] = negm: the line A + u D meets the
+// Sphere, apex form: oc xyz (apex - centre), cs = |oc|^2 - r^2, ..., c[9] = negm: the line A + u D meets the
 // sphere iff (D.oc)^2 - |D|^2 cs >= 0.  Sphere, general form (GenRec): centre xyz, r^2, ..., c[12] = negm.
 
 // 16 floats per leaf for rays with arbitrary origins (reflected rays, Main.hs:549-552):

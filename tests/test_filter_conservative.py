@@ -55,7 +55,7 @@ def test_eye_filter_accepts_every_oracle_hit(name, w, h):
     for leaf in np.unique(ids):
         m = ids == leaf
         z = eye_z(recs[leaf], kinds[leaf], px[m], py[m])
-        assert (z >= recs[leaf][10]).all(), f"{name}: leaf {leaf} rejected by the FP32 filter"
+        assert (z >= recs[leaf][9]).all(), f"{name}: leaf {leaf} rejected by the FP32 filter"
     sc.close()
 
 
@@ -70,7 +70,7 @@ def test_eye_filter_is_selective():
     ys, xs = np.mgrid[0:h, 0:w]
     px = (cam[0] * xs.ravel().astype(np.float64) + cam[2]).astype(np.float32)
     py = (cam[1] * ys.ravel().astype(np.float64) + cam[3]).astype(np.float32)
-    passed = sum(int((eye_z(recs[i], kinds[i], px, py) >= recs[i][10]).sum()) for i in range(sc.num_leaves))
+    passed = sum(int((eye_z(recs[i], kinds[i], px, py) >= recs[i][9]).sum()) for i in range(sc.num_leaves))
     assert passed < 0.01 * w * h * sc.num_leaves
     sc.close()
 
@@ -127,10 +127,10 @@ def test_light_filter_accepts_every_occluder():
                     f = [np.float32(np.float64(rec[3 * j]) * D[0] + np.float64(rec[3 * j + 1]) * D[1] + np.float64(rec[3 * j + 2]) * D[2]) for j in range(3)]
                     # third form: W for triangles, N for rectangles (rt_scene.cpp: make_rec, light apex)
                     z = min(f[0], f[1], f[2]) if kinds[i] == 1 else f[2] - max(abs(f[0]), abs(f[1]))
-                    assert z >= rec[10], f"light {k} pixel ({x},{y}) leaf {i}: occluder rejected by the shadow filter"
+                    assert z >= rec[9], f"light {k} pixel ({x},{y}) leaf {i}: occluder rejected by the shadow filter"
                     # candidate path of k_shadow: the segment light..origin must be kept (N.D >= Kq)
                     nd = np.float32(np.float64(rec[11]) * D[0] + np.float64(rec[12]) * D[1] + np.float64(rec[13]) * D[2])
-                    assert nd >= rec[9], f"light {k} pixel ({x},{y}) leaf {i}: occluder dropped by the segment clip"
+                    assert nd >= rec[10], f"light {k} pixel ({x},{y}) leaf {i}: occluder dropped by the segment clip"
                     checked += 1
     assert checked > 200
     sc.close()
