@@ -68,6 +68,8 @@ struct RenderParams {
     const FilterRec *sph_rec;
     const GenRec *gen_sph;
     const int32_t *sph_gid;
+    const uint16_t *mf_rows;        // MFMA row blocks, per apex (rt_types.h)
+    const int32_t *mf_gid;          // MFMA stream position -> leaf index
     unsigned long long *counters;   // [0] shadow rays cast, [1] exact evals (primary), [2] exact evals (shadow)
     int32_t *hit_id;                // band-local output, indexed out_off + pix
     uint8_t *rgba;                  // band-local output (spp == 1) or nullptr
@@ -88,6 +90,7 @@ struct RenderParams {
     CameraD cam;
     double eps;
     int ntri, nrect, nsph, nlights, nleaves, npoint;
+    int mf_groups;                  // blocks of MF_LEAVES planar leaves per apex (+ 2 of padding)
     int w, h;
     int row0, nrows;                // this chunk: first absolute image row, rows
     long long out_off;              // index of the chunk's first pixel inside the band-local outputs
@@ -701,6 +704,316 @@ __global__ void RT_HOT(RT_WAVES_EU_SHADOW) k_shadow(const RenderParams P) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Matrix-core versions of kernels 1 and 3.
+//
+// The filter's linear forms are a matrix product: (leaves x 3 forms) x (D components) x (rays).  Here it runs on
+// v_mfma_f32_32x32x16_bf16: the A operand is one block of 32 rows = 10 leaves x 3 forms (rt_scene.cpp builds them,
+// coefficients as bf16 hi + mid pairs), the B operand is 32 rays (D = x, y, z, 1 split the same way; lanes 0-31 hold
+// the hi parts, lanes 32-63 the mid parts), the K = 16 products of a row and a column are exactly
+// (c_hi + c_mid) (D_hi + D_mid) over the four components, summed in FP32.  A lane then owns one ray (column) and 16
+// forms (registers) = 5 leaves: z = min3 of a leaf's three forms, max over the 5 leaves, one compare — 8 VALU
+// instructions per 32 rays x 10 leaves, beside a 32-cycle MFMA, instead of 25 per 256 rays x 1 leaf.
+// A wave carries 8 B operands (256 rays).  Pairs that pass are queued in two bit masks per lane and handled after
+// the 8 MFMAs of the block: FP32 record test (exact shape, segment clip), then the exact FP64 path as before.
+
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
+typedef __attribute__((__vector_size__(16 * sizeof(float)))) float f32x16;
+typedef __attribute__((__vector_size__(4 * sizeof(int)))) int i32x4;
+
+__device__ __forceinline__ uint32_t bf16_bits(float f) {        // round to nearest even; f finite
+    const uint32_t u = __float_as_uint(f);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+// B fragment of one ray for lane half h: h = 0 -> (x_hi, x_hi, y_hi, y_hi, z_hi, z_hi, w, w), h = 1 -> the mid parts
+// and w = 0.  An inactive ray is all zero: every form is then 0, which is not > 0.
+__device__ __forceinline__ bf16x8 ray_fragment(float x, float y, float z, bool active, int h) {
+    uint32_t px = bf16_bits(x), py = bf16_bits(y), pz = bf16_bits(z), pw = 0x3f80u;
+    if (h) {
+        px = bf16_bits(x - __uint_as_float(px << 16));
+        py = bf16_bits(y - __uint_as_float(py << 16));
+        pz = bf16_bits(z - __uint_as_float(pz << 16));
+        pw = 0u;
+    }
+    if (!active) px = py = pz = pw = 0u;
+    i32x4 v = {(int)(px | (px << 16)), (int)(py | (py << 16)), (int)(pz | (pz << 16)), (int)(pw | (pw << 16))};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+// One MFMA step: 32 rays (B) against the 10 leaves of block A.  Returns the lane's 5-bit pass mask (0 almost always).
+__device__ __forceinline__ unsigned mfma_step(const bf16x8 A, const bf16x8 B) {
+    f32x16 acc = {0};
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, acc, 0, 0, 0);
+    const float z0 = __builtin_fminf(__builtin_fminf(acc[0], acc[1]), acc[2]);
+    const float z1 = __builtin_fminf(__builtin_fminf(acc[3], acc[4]), acc[5]);
+    const float z2 = __builtin_fminf(__builtin_fminf(acc[6], acc[7]), acc[8]);
+    const float z3 = __builtin_fminf(__builtin_fminf(acc[9], acc[10]), acc[11]);
+    const float z4 = __builtin_fminf(__builtin_fminf(acc[12], acc[13]), acc[14]);
+    const float mx = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(z0, z1), z2), __builtin_fmaxf(z3, z4));
+    unsigned bits = 0;
+    if (mx > 0.f) {
+        asm volatile("" ::: "memory");      // a real branch: the block below runs for a few percent of the steps
+        bits = (z0 > 0.f ? 1u : 0u) | (z1 > 0.f ? 2u : 0u) | (z2 > 0.f ? 4u : 0u) | (z3 > 0.f ? 8u : 0u) | (z4 > 0.f ? 16u : 0u);
+    }
+    return bits;
+}
+
+// FP32 record test of ONE ray (the second stage, rare path): the exact shape of the leaf, same margins as filter4.
+__device__ __forceinline__ bool record_test(const FilterRec *R, int kind, float x, float y, float z) {
+    const float q1 = __builtin_fmaf(R->c[0], x, __builtin_fmaf(R->c[1], y, R->c[2] * z));
+    const float q2 = __builtin_fmaf(R->c[3], x, __builtin_fmaf(R->c[4], y, R->c[5] * z));
+    const float n = __builtin_fmaf(R->c[6], x, __builtin_fmaf(R->c[7], y, R->c[8] * z));
+    const float zz = kind == LEAF_TRI ? __builtin_fminf(__builtin_fminf(q1, q2), n)
+                                      : n - __builtin_fmaxf(__builtin_fabsf(q1), __builtin_fabsf(q2));
+    return zz >= R->c[9];
+}
+
+#ifndef RT_WAVES_EU_MFMA
+#define RT_WAVES_EU_MFMA 4
+#endif
+
+// Kernel 3 on the matrix cores.  Lane (c = lane & 31, h = lane >> 5): ray column c of each of the wave's 8 ray
+// blocks, leaves 5h .. 5h + 4 of each leaf block.
+__global__ void RT_HOT(RT_WAVES_EU_MFMA) k_shadow_mfma(const RenderParams P) {
+    const int pl = (int)blockIdx.y;
+    const unsigned count = P.qcount[pl];
+    const unsigned wave = blockIdx.x * RT_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (wave * 256u >= count) return;
+    const int lane = (int)(threadIdx.x & 63), c = lane & 31, h = lane >> 5;
+    int li = 0;
+    for (int k = -1; li < P.nlights; ++li) if (P.lights[li].kind == 0 && ++k == pl) break;
+    const LightD &Lt = P.lights[li];
+    const uint32_t *q = P.queue + (size_t)pl * (size_t)P.qcap;
+    bf16x8 B[8];
+    unsigned need = 0;                       // bit b: ray (b, c) exists and no occluder found by this lane yet
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        const unsigned j = wave * 256u + (unsigned)(b * 32 + c);
+        const bool ok = j < count;
+        float dx = 0.f, dy = 0.f, dz = 0.f;
+        if (ok) {
+            const HitRec H = P.hitrec[q[j]];
+            double tx, ty, tz;
+            to_light(Lt, H.px, H.py, H.pz, tx, ty, tz);
+            dx = (float)((H.px + 0.00001 * tx) - Lt.px);
+            dy = (float)((H.py + 0.00001 * ty) - Lt.py);
+            dz = (float)((H.pz + 0.00001 * tz) - Lt.pz);
+            need |= 1u << b;
+        }
+        B[b] = ray_fragment(dx, dy, dz, ok, h);
+    }
+    const size_t ro = (size_t)__builtin_amdgcn_readfirstlane(Lt.rec_offset);
+    const i32x4 *blocks = reinterpret_cast<const i32x4 *>(P.mf_rows) + ro * (size_t)(P.mf_groups + 2) * 32 + c;
+    unsigned nexact = 0;
+    i32x4 a_next = blocks[0];
+    for (int g = 0; g < P.mf_groups; ++g) {
+        const bf16x8 A = __builtin_bit_cast(bf16x8, a_next);
+        a_next = blocks[(size_t)(g + 1) * 32];             // two blocks of padding follow the last one
+        unsigned pend0 = 0, pend1 = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) pend0 |= mfma_step(A, B[b]) << (5 * b);
+#pragma unroll
+        for (int b = 4; b < 8; ++b) pend1 |= mfma_step(A, B[b]) << (5 * (b - 4));
+        if (pend0 | pend1) {
+            unsigned long long bits = (unsigned long long)pend0 | ((unsigned long long)pend1 << 20);
+            while (bits) {
+                const int k = __ffsll((long long)bits) - 1;
+                bits &= bits - 1;
+                const int b = k / 5, t = k - 5 * b;
+                if (!((need >> b) & 1u)) continue;
+                const int gid = P.mf_gid[g * MF_LEAVES + 5 * h + t];
+                if (gid < 0) continue;
+                const uint32_t pix = q[wave * 256u + (unsigned)(b * 32 + c)];
+                // the hit leaf itself lies 1e-5 behind the shadow-ray origin (Main.hs:472): t < 0
+                if (P.hit_id[P.out_off + pix] == gid) continue;
+                const LeafD &L = P.leaves[gid];
+                const int kind = L.kind;
+                const HitRec H = P.hitrec[pix];
+                double tx, ty, tz;
+                to_light(Lt, H.px, H.py, H.pz, tx, ty, tz);
+                const double ox = H.px + 0.00001 * tx, oy = H.py + 0.00001 * ty, oz = H.pz + 0.00001 * tz;
+                const float dx = (float)(ox - Lt.px), dy = (float)(oy - Lt.py), dz = (float)(oz - Lt.pz);
+                const FilterRec *R = (kind == LEAF_TRI ? P.tri_rec + ro * (size_t)P.ntri : P.rect_rec + ro * (size_t)P.nrect) + L.slot;
+                if (!record_test(R, kind, dx, dy, dz)) continue;
+                // only leaves between the light and the origin: N.D >= Kq (Main.hs:474 needs t <= distance)
+                if (!(__builtin_fmaf(R->c[11], dx, __builtin_fmaf(R->c[12], dy, R->c[13] * dz)) >= R->c[10])) continue;
+                const RayD ray = mkray(ox, oy, oz, tx, ty, tz, P.eps);                 // Main.hs:472
+                double ix, iy, iz, tt;
+                ++nexact;
+                const bool hit = kind == LEAF_TRI ? leaf_isect<LEAF_TRI>(L, ray, ix, iy, iz, tt) : leaf_isect<LEAF_RECT>(L, ray, ix, iy, iz, tt);
+                if (hit && guards_ok(P.guards, L.guard, ray)) {
+                    const double tl = (Lt.pz - ray.pz) * ray.rz;                       // rayDistance ray lpos
+                    if (tt <= tl) need &= ~(1u << b);                                  // Main.hs:474 -> black
+                }
+            }
+        }
+    }
+    // spheres: lane (c, h) takes the rays (4h + r, c) with the scalar-record loop
+    if (P.nsph > 0) {
+        uint32_t pix[4]; bool nd[4]; float ddx[4], ddy[4], ddz[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int b = 4 * h + r;
+            const unsigned j = wave * 256u + (unsigned)(b * 32 + c);
+            nd[r] = j < count;
+            pix[r] = nd[r] ? q[j] : 0u;
+            ddx[r] = ddy[r] = ddz[r] = 0.f;
+            if (nd[r]) {
+                const HitRec H = P.hitrec[pix[r]];
+                double tx, ty, tz;
+                to_light(Lt, H.px, H.py, H.pz, tx, ty, tz);
+                ddx[r] = (float)((H.px + 0.00001 * tx) - Lt.px);
+                ddy[r] = (float)((H.py + 0.00001 * ty) - Lt.py);
+                ddz[r] = (float)((H.pz + 0.00001 * tz) - Lt.pz);
+            }
+        }
+        Dir4 D;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            D.x[p] = f2{ddx[2 * p], ddx[2 * p + 1]};
+            D.y[p] = f2{ddy[2 * p], ddy[2 * p + 1]};
+            D.z[p] = f2{ddz[2 * p], ddz[2 * p + 1]};
+        }
+        shadow_sphere_loop(P, as_const(P.sph_rec + ro * (size_t)P.nsph), D, pix, Lt, nd, nexact);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (!nd[r]) need &= ~(1u << (4 * h + r));
+    }
+    // a ray is lit when neither lane half found an occluder; each half reports 4 of the 8 ray blocks
+    need &= (unsigned)__shfl_xor((int)need, 32);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int b = 4 * h + r;
+        if ((need >> b) & 1u) atomicOr(&P.lit[q[wave * 256u + (unsigned)(b * 32 + c)]], 1u << pl);
+    }
+    for (int o = 32; o > 0; o >>= 1) nexact += __shfl_down(nexact, o);
+    if (lane == 0 && nexact) atomicAdd(&P.counters[2], (unsigned long long)nexact);
+}
+
+// Kernel 1 on the matrix cores.  One wave = 32 x 8 pixel tile; ray block b = tile row b, column c = lane & 31.
+// The nearest hit of every pixel lives in LDS, one table per lane half (the halves test different leaves of a
+// block for the same pixels), merged at the end.
+__global__ void RT_HOT(RT_WAVES_EU_MFMA) k_primary_mfma(const RenderParams P) {
+    __shared__ double s_bt[RT_WAVES_PER_BLOCK][2][256];
+    __shared__ int s_bid[RT_WAVES_PER_BLOCK][2][256];
+    const int wv = (int)(threadIdx.x >> 6);
+    const int wave = (int)(blockIdx.x * RT_WAVES_PER_BLOCK) + wv;
+    const int lane = (int)(threadIdx.x & 63), c = lane & 31, h = lane >> 5;
+    const int tx = wave % P.tiles_x, ty = wave / P.tiles_x;
+    if (ty >= P.tiles_y) return;
+    const int x = tx * RT_TILE_W + c;
+    const int ly0 = ty * RT_TILE_H;
+    double *bt = s_bt[wv][h];
+    int *bid = s_bid[wv][h];
+    bf16x8 B[8];
+    const float dzf = (float)P.cam.d;
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        const bool ok = x < P.w && ly0 + b < P.nrows;
+        double ox, oy;
+        sample_offset(P, x, P.row0 + ly0 + b, ox, oy);
+        const float dx = (float)(P.cam.scaleX * ((double)x + ox) + P.cam.dX);
+        const float dy = (float)(P.cam.scaleY * ((double)(P.row0 + ly0 + b) + oy) + P.cam.dY);
+        B[b] = ray_fragment(dx, dy, dzf, ok, h);
+        bt[b * 32 + c] = INFINITY;
+        bid[b * 32 + c] = -1;
+    }
+    const i32x4 *blocks = reinterpret_cast<const i32x4 *>(P.mf_rows) + c;      // apex 0 = the eye
+    unsigned nexact = 0;
+    i32x4 a_next = blocks[0];
+    for (int g = 0; g < P.mf_groups; ++g) {
+        const bf16x8 A = __builtin_bit_cast(bf16x8, a_next);
+        a_next = blocks[(size_t)(g + 1) * 32];
+        unsigned pend0 = 0, pend1 = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) pend0 |= mfma_step(A, B[b]) << (5 * b);
+#pragma unroll
+        for (int b = 4; b < 8; ++b) pend1 |= mfma_step(A, B[b]) << (5 * (b - 4));
+        if (pend0 | pend1) {
+            unsigned long long bits = (unsigned long long)pend0 | ((unsigned long long)pend1 << 20);
+            while (bits) {
+                const int k = __ffsll((long long)bits) - 1;
+                bits &= bits - 1;
+                const int b = k / 5, t = k - 5 * b;
+                const int gid = P.mf_gid[g * MF_LEAVES + 5 * h + t];
+                const int y = P.row0 + ly0 + b;
+                if (gid < 0 || x >= P.w || ly0 + b >= P.nrows) continue;
+                const LeafD &L = P.leaves[gid];
+                const int kind = L.kind;
+                double ox, oy;
+                sample_offset(P, x, y, ox, oy);
+                const float px = (float)(P.cam.scaleX * ((double)x + ox) + P.cam.dX);
+                const float py = (float)(P.cam.scaleY * ((double)y + oy) + P.cam.dY);
+                // eye records are affine in (posX, posY): the z column already holds c_z * d
+                if (!record_test((kind == LEAF_TRI ? P.tri_rec : P.rect_rec) + L.slot, kind, px, py, 1.0f)) continue;
+                const RayD ray = camera_ray(P, x, y);
+                double ix, iy, iz, tt;
+                ++nexact;
+                const bool hit = kind == LEAF_TRI ? leaf_isect<LEAF_TRI>(L, ray, ix, iy, iz, tt) : leaf_isect<LEAF_RECT>(L, ray, ix, iy, iz, tt);
+                if (hit && guards_ok(P.guards, L.guard, ray)) {
+                    // nearest wins; equal t -> the left-most leaf of the tree (Main.hs:213-214)
+                    const int e = b * 32 + c;
+                    const double ct = bt[e]; const int cid = bid[e];
+                    if (tt < ct || (tt == ct && gid < cid) || cid < 0) { bt[e] = tt; bid[e] = gid; }
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // pixels (4h + r, c): spheres, then the merge of the two tables
+    double mt[4]; int mid[4]; bool act[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int e = (4 * h + r) * 32 + c;
+        const double t0 = s_bt[wv][0][e], t1 = s_bt[wv][1][e];
+        const int i0 = s_bid[wv][0][e], i1 = s_bid[wv][1][e];
+        const bool second = i0 < 0 || (i1 >= 0 && (t1 < t0 || (t1 == t0 && i1 < i0)));
+        mt[r] = second ? t1 : t0; mid[r] = second ? i1 : i0;
+        act[r] = x < P.w && ly0 + 4 * h + r < P.nrows;
+    }
+    if (P.nsph > 0) {
+        Dir4 D; f2 dd[2];
+        float dx[4], dy[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            double ox, oy;
+            sample_offset(P, x, P.row0 + ly0 + 4 * h + r, ox, oy);
+            dx[r] = (float)(P.cam.scaleX * ((double)x + ox) + P.cam.dX);
+            dy[r] = (float)(P.cam.scaleY * ((double)(P.row0 + ly0 + 4 * h + r) + oy) + P.cam.dY);
+        }
+#pragma unroll
+        for (int p = 0; p < 2; ++p) { D.x[p] = f2{dx[2 * p], dx[2 * p + 1]}; D.y[p] = f2{dy[2 * p], dy[2 * p + 1]}; D.z[p] = f2{dzf, dzf}; }
+        dir_norms(D, dd);
+        CRecPtr recs = as_const(P.sph_rec);
+        CIntPtr gids = as_const(P.sph_gid);
+        for (int i = 0; i < P.nsph; ++i) {
+            const FilterRec cur = load_rec(recs + i);
+            float z[4];
+            if (filter4_sphere(cur, D, dd, z)) {
+                const int gid = gids[i];
+                const LeafD &L = P.leaves[gid];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if ((z[r] >= cur.c[9]) & act[r]) {
+                        int yr = P.row0 + ly0 + 4 * h + r;
+                        asm volatile("" : "+v"(yr));
+                        const RayD ray = camera_ray(P, x, yr);
+                        double ix, iy, iz, tt;
+                        ++nexact;
+                        if (leaf_isect<LEAF_SPHERE>(L, ray, ix, iy, iz, tt) && guards_ok(P.guards, L.guard, ray)) {
+                            if (tt < mt[r] || (tt == mt[r] && gid < mid[r]) || mid[r] < 0) { mt[r] = tt; mid[r] = gid; }
+                        }
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (act[r]) P.hit_id[P.out_off + (long long)(ly0 + 4 * h + r) * P.w + x] = mid[r];
+    for (int o = 32; o > 0; o >>= 1) nexact += __shfl_down(nexact, o);
+    if (lane == 0 && nexact) atomicAdd(&P.counters[1], (unsigned long long)nexact);
+}
+
+// ------------------------------------------------------------------------------------------
 // Kernel 4: `light lights hit ray` (Main.hs:545, 436-441) = pointLight (467-487) + ambient (490-492),
 //   saturating 8-bit sums, coalesced RGBA8 store.
 
@@ -962,6 +1275,8 @@ __global__ void k_resolve(const uint32_t *__restrict__ accum, uint8_t *__restric
 
 hipStream_t g_stream = nullptr;
 int g_device = -1;
+// RT_FILTER=valu selects the scalar-record VALU kernels (k_primary / k_shadow) instead of the matrix-core ones
+bool g_use_mfma = true;
 
 bool hip_ok(hipError_t e, const char *what) {
     if (e == hipSuccess) return true;
@@ -1007,6 +1322,8 @@ int prepare(rt_scene &s, int w, int h) {
         if ((rc = upload(s.dev.rect_rec, s.rect_rec))) return rc;
         if ((rc = upload(s.dev.sph_rec, s.sph_rec))) return rc;
         if ((rc = upload(s.dev.sph_gid, s.sph_gid))) return rc;
+        if ((rc = upload(s.dev.mf_rows, s.mf_rows))) return rc;
+        if ((rc = upload(s.dev.mf_gid, s.mf_gid))) return rc;
         if (s.reflective) {
             if ((rc = upload(s.dev.gen_sph, s.gen_sph))) return rc;
             if ((rc = upload(s.dev.gen_tri, s.gen_tri))) return rc;
@@ -1053,6 +1370,8 @@ int rt_init(int device) {
     if (g_stream && g_device != device) { (void)hipStreamDestroy(g_stream); g_stream = nullptr; }
     if (!g_stream) HIP_TRY(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
     g_device = device;
+    const char *f = getenv("RT_FILTER");
+    g_use_mfma = !(f && std::string(f) == "valu");
     return RT_OK;
 }
 
@@ -1060,7 +1379,7 @@ void rt_scene_destroy(rt_scene *s) {
     if (!s) return;
     DeviceScene &d = s->dev;
     void *ptrs[] = {d.leaves, d.aux, d.guards, d.mats, d.lights, d.tri_rec, d.rect_rec, d.tri_gid, d.rect_gid,
-                    d.counters, d.qcount, d.hit_id, d.accum, d.rgba, d.hit_out, d.hitrec, d.queue, d.lit, d.gen_tri, d.gen_rect, d.sph_rec, d.gen_sph, d.sph_gid};
+                    d.counters, d.qcount, d.hit_id, d.accum, d.rgba, d.hit_out, d.hitrec, d.queue, d.lit, d.gen_tri, d.gen_rect, d.sph_rec, d.gen_sph, d.sph_gid, d.mf_rows, d.mf_gid};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (int k = 0; k < 8; ++k) {
         if (d.lvl_rays[k]) (void)hipFree(d.lvl_rays[k]);
@@ -1129,6 +1448,7 @@ int rt_render_device(rt_scene *s, int w, int h, int depth, int spp, uint64_t see
     P.hitrec = reinterpret_cast<HitRec *>(s->dev.hitrec); P.queue = s->dev.queue; P.qcount = s->dev.qcount; P.lit = s->dev.lit;
     P.gen_tri = s->dev.gen_tri; P.gen_rect = s->dev.gen_rect;
     P.sph_rec = s->dev.sph_rec; P.gen_sph = s->dev.gen_sph; P.sph_gid = s->dev.sph_gid; P.nsph = (int)s->sph_gid.size();
+    P.mf_rows = s->dev.mf_rows; P.mf_gid = s->dev.mf_gid; P.mf_groups = s->mf_groups;
     P.cam = fixed_camera(w, h);
     P.eps = ray_eps();
     P.ntri = (int)s->tri_gid.size(); P.nrect = (int)s->rect_gid.size();
@@ -1156,7 +1476,8 @@ int rt_render_device(rt_scene *s, int w, int h, int depth, int spp, uint64_t see
             if (depth == 0) {      // trace 0 = black (Main.hs:542): every pixel misses
                 HIP_TRY(hipMemsetAsync(P.hit_id + P.out_off, 0xff, (size_t)P.qcap * sizeof(int32_t), st));
             } else {
-                if (spp == 1) hipLaunchKernelGGL(k_primary<true>, dim3(tblocks), dim3(RT_WAVES_PER_BLOCK * 64), 0, st, P);
+                if (g_use_mfma) hipLaunchKernelGGL(k_primary_mfma, dim3(tblocks), dim3(RT_WAVES_PER_BLOCK * 64), 0, st, P);
+                else if (spp == 1) hipLaunchKernelGGL(k_primary<true>, dim3(tblocks), dim3(RT_WAVES_PER_BLOCK * 64), 0, st, P);
                 else hipLaunchKernelGGL(k_primary<false>, dim3(tblocks), dim3(RT_WAVES_PER_BLOCK * 64), 0, st, P);
             }
             if ((rc = next_event(*s, st, 1))) return rc;
@@ -1181,8 +1502,10 @@ int rt_render_device(rt_scene *s, int w, int h, int depth, int spp, uint64_t see
                 P.colour = (levels > 1) ? s->dev.lvl_col[lvl] : nullptr;
                 hipLaunchKernelGGL(k_setup, dim3(pblocks), dim3(256), 0, st, P);
                 if ((rc = next_event(*s, st, 2))) return rc;
-                if (s->npoint > 0)
-                    hipLaunchKernelGGL(k_shadow, dim3(sblocks, (unsigned)s->npoint), dim3(RT_WAVES_PER_BLOCK * 64), 0, st, P);
+                if (s->npoint > 0) {
+                    if (g_use_mfma) hipLaunchKernelGGL(k_shadow_mfma, dim3(sblocks, (unsigned)s->npoint), dim3(RT_WAVES_PER_BLOCK * 64), 0, st, P);
+                    else hipLaunchKernelGGL(k_shadow, dim3(sblocks, (unsigned)s->npoint), dim3(RT_WAVES_PER_BLOCK * 64), 0, st, P);
+                }
                 if ((rc = next_event(*s, st, 3))) return rc;
                 hipLaunchKernelGGL(k_final, dim3(pblocks), dim3(256), 0, st, P);
                 if ((rc = next_event(*s, st, 4))) return rc;

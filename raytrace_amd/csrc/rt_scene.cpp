@@ -203,8 +203,12 @@ static FilterRec always_rec() {  // apex (numerically) in the leaf's plane: let 
     return r;
 }
 
-// eye_d: 0 for a light apex; the camera's d for the eye apex, whose records are affine in (posX, posY).
-static FilterRec make_rec(const LeafD &L, const double A[3], const double dmax[3], double eye_d = 0.0) {
+// The linear forms of one leaf seen from one apex, in double: c1, c2 (the two inside coordinates times N) and cn (N),
+// sign-normalised to K >= 0.  status: 0 usable, 1 the leaf can never be hit, 2 let the exact path decide every ray.
+struct Forms { double c1[3], c2[3], cn[3], K, m, mK; int status; };
+
+static Forms leaf_forms(const LeafD &L, const double A[3], const double dmax[3]) {
+    Forms F{};
     const double n[3] = {L.nx, L.ny, L.nz};
     const double e1[3] = {L.e1x, L.e1y, L.e1z}, e2[3] = {L.e2x, L.e2y, L.e2z};
     double g1[3], g2[3], q1A, q2A;   // gradients of the two inside coordinates and their value at A
@@ -227,7 +231,7 @@ static FilterRec make_rec(const LeafD &L, const double A[3], const double dmax[3
         q2A = g2[0] * w[0] + g2[1] * w[1] + g2[2] * w[2];
     }
     double K = -(L.d + (n[0] * A[0] + n[1] * A[1] + n[2] * A[2]));
-    double c1[3], c2[3], cn[3];
+    double *c1 = F.c1, *c2 = F.c2, *cn = F.cn;
     for (int i = 0; i < 3; ++i) { c1[i] = q1A * n[i] + K * g1[i]; c2[i] = q2A * n[i] + K * g2[i]; cn[i] = n[i]; }
     if (K < 0) { K = -K; for (int i = 0; i < 3; ++i) { c1[i] = -c1[i]; c2[i] = -c2[i]; cn[i] = -cn[i]; } }
     double S = 0, SN = 0;
@@ -235,12 +239,23 @@ static FilterRec make_rec(const LeafD &L, const double A[3], const double dmax[3
         S += (std::fabs(c1[i]) + std::fabs(c2[i]) + std::fabs(cn[i])) * dmax[i];
         SN += std::fabs(cn[i]) * dmax[i];
     }
-    if (!std::isfinite(S) || !std::isfinite(K)) return never_rec();
+    if (!std::isfinite(S) || !std::isfinite(K)) { F.status = 1; return F; }
     // margins: every input is rounded to FP32 once (2^-24 relative) and each linear form takes
     // three FP32 operations, W two more; 2^-20 of the magnitude sum leaves a factor > 3 of slack.
-    const double m = std::ldexp(S, -20) + 1e-30;
-    const double mK = std::ldexp(SN + K, -20) + 1e-30;
-    if (K <= 4 * mK) return always_rec();
+    F.K = K;
+    F.m = std::ldexp(S, -20) + 1e-30;
+    F.mK = std::ldexp(SN + K, -20) + 1e-30;
+    if (K <= 4 * F.mK) F.status = 2;
+    return F;
+}
+
+// eye_d: 0 for a light apex; the camera's d for the eye apex, whose records are affine in (posX, posY).
+static FilterRec make_rec(const LeafD &L, const double A[3], const double dmax[3], double eye_d = 0.0) {
+    const Forms F = leaf_forms(L, A, dmax);
+    if (F.status == 1) return never_rec();
+    if (F.status == 2) return always_rec();
+    const double *c1 = F.c1, *c2 = F.c2, *cn = F.cn;
+    const double K = F.K, m = F.m, mK = F.mK;
     FilterRec r{};
     if (eye_d != 0.0) {
         // Eye apex: D = (posX, posY, d) with d constant, so every form is  f.x*posX + f.y*posY + f.z*d.
@@ -276,6 +291,52 @@ static FilterRec make_rec(const LeafD &L, const double A[3], const double dmax[3
     for (int i = 0; i < 3; ++i) r.c[11 + i] = (float)cn[i];
     for (int i = 0; i < 14; ++i) if (!std::isfinite(r.c[i])) return always_rec();   // FP32 overflow
     return r;
+}
+
+// ------------------------------------------------------------------------------------------
+// MFMA rows: the same forms for the matrix cores (v_mfma_f32_32x32x16_bf16).  A form  f(D) = c.D + m  over
+// D = (x, y, z, 1) becomes one row of 8 bf16: every coefficient as hi + mid (hi = bf16(c), mid = bf16(c - hi),
+// together 2^-16 relative), and the kernels split D the same way, so the 16 products of one MFMA row x column are
+// (c_hi + c_mid) * (D_hi + D_mid) over the 4 components.  Three forms per leaf, all >= 0 inside:
+//   triangle : U, V, W                rectangle: N + A, N + B, 2N - A - B  (a triangle around the parallelogram;
+//   the FP32 record of the leaf, tested next on the rare path, has the exact shape).
+// The margin m = 2^-13 of the magnitude sum (a factor > 4 above the split and accumulation errors) is the
+// constant term, so the kernels test  min(f0, f1, f2) > 0.
+static inline uint16_t bf16_rne(float f) {
+    uint32_t u; std::memcpy(&u, &f, 4);
+    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+static inline float bf16_val(uint16_t b) { const uint32_t u = (uint32_t)b << 16; float f; std::memcpy(&f, &u, 4); return f; }
+static bool split_bf16(double v, uint16_t &hi, uint16_t &mid) {
+    if (!std::isfinite(v) || std::fabs(v) > 3.0e38) return false;
+    hi = bf16_rne((float)v);
+    const float fh = bf16_val(hi);
+    if (!std::isfinite(fh)) return false;
+    mid = bf16_rne((float)(v - (double)fh));
+    return true;
+}
+static void const_rows(uint16_t rows[3][8], float w) {
+    for (int k = 0; k < 3; ++k) { for (int j = 0; j < 8; ++j) rows[k][j] = 0; rows[k][6] = bf16_rne(w); }
+}
+static void make_mfma_rows(const LeafD &L, const double A[3], const double dmax[3], uint16_t rows[3][8]) {
+    const Forms F = leaf_forms(L, A, dmax);
+    if (F.status == 1) { const_rows(rows, -1.0f); return; }       // never > 0
+    if (F.status == 2) { const_rows(rows, 1.0f); return; }        // always > 0: the exact path decides
+    double r[3][3];
+    for (int i = 0; i < 3; ++i) {
+        if (L.kind == LEAF_TRI) { r[0][i] = F.c1[i]; r[1][i] = F.c2[i]; r[2][i] = F.cn[i] - F.c1[i] - F.c2[i]; }
+        else { r[0][i] = F.cn[i] + F.c1[i]; r[1][i] = F.cn[i] + F.c2[i]; r[2][i] = 2 * F.cn[i] - F.c1[i] - F.c2[i]; }
+    }
+    double S = 0;
+    for (int k = 0; k < 3; ++k) for (int i = 0; i < 3; ++i) S += std::fabs(r[k][i]) * dmax[i];
+    const double m = std::ldexp(S, -13) + 1e-30;
+    bool ok = std::isfinite(S);
+    for (int k = 0; k < 3 && ok; ++k) {
+        for (int i = 0; i < 3 && ok; ++i) ok = split_bf16(r[k][i], rows[k][2 * i], rows[k][2 * i + 1]);
+        if (ok) ok = split_bf16(m, rows[k][6], rows[k][7]);
+        // the split of m must not round the margin down by more than the slack: hi + mid >= m (1 - 2^-15)
+    }
+    if (!ok) const_rows(rows, 1.0f);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -406,8 +467,30 @@ void build_filter_records(rt_scene &s, int w, int h) {
                 if (std::isfinite(p[k][i])) { lo[i] = std::fmin(lo[i], p[k][i]); hi[i] = std::fmax(hi[i], p[k][i]); }
     }
     const CameraD cam = fixed_camera(w, h);
+    // MFMA stream: the planar leaves in tree order, 10 per block of 32 rows (see rt_types.h), two blocks of padding
+    s.mf_gid.clear();
+    for (size_t g = 0; g < s.leaves.size(); ++g) if (s.leaves[g].kind != LEAF_SPHERE) s.mf_gid.push_back((int32_t)g);
+    const size_t nplanar = s.mf_gid.size();
+    s.mf_groups = (int)((nplanar + MF_LEAVES - 1) / MF_LEAVES);
+    const size_t gstride = (size_t)s.mf_groups + 2;
+    s.mf_gid.resize(gstride * MF_LEAVES, -1);
+    s.mf_rows.assign(gstride * (size_t)napex * 32 * 8, 0);
+    {
+        uint16_t never[3][8];
+        const_rows(never, -1.0f);
+        for (size_t r = 0; r < gstride * (size_t)napex * 32; ++r) std::memcpy(&s.mf_rows[r * 8], never[0], 16);
+    }
     int apex = 0;
     auto fill = [&](const double A[3], const double dmax[3], double eye_d) {
+        for (size_t k = 0; k < nplanar; ++k) {
+            uint16_t rows[3][8];
+            make_mfma_rows(s.leaves[s.mf_gid[k]], A, dmax, rows);
+            const size_t g = k / MF_LEAVES, hh = (k % MF_LEAVES) / 5, t = k % 5;
+            for (size_t f = 0; f < 3; ++f) {
+                const size_t q = 3 * t + f, row = (q & 3) + 8 * (q >> 2) + 4 * hh;   // accumulator register q of lane half hh
+                std::memcpy(&s.mf_rows[(((size_t)apex * gstride + g) * 32 + row) * 8], rows[f], 16);
+            }
+        }
         for (size_t k = 0; k < ntri; ++k) s.tri_rec[(size_t)apex * ntri + k] = make_rec(s.leaves[s.tri_gid[k]], A, dmax, eye_d);
         for (size_t k = 0; k < nrect; ++k) s.rect_rec[(size_t)apex * nrect + k] = make_rec(s.leaves[s.rect_gid[k]], A, dmax, eye_d);
         for (size_t k = 0; k < nsph; ++k) s.sph_rec[(size_t)apex * nsph + k] = make_sphere_rec(s.leaves[s.sph_gid[k]], A, dmax);

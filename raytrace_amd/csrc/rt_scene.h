@@ -26,6 +26,8 @@ struct DeviceScene {          // device copies (HBM), owned by the scene
     FilterRec *sph_rec = nullptr;    // (1 + npoint) blocks of nsph sphere records
     GenRec *gen_sph = nullptr;
     int32_t *sph_gid = nullptr;
+    uint16_t *mf_rows = nullptr;     // MFMA row blocks (rt_types.h), per apex
+    int32_t *mf_gid = nullptr;
     unsigned long long *counters = nullptr;  // 8 x u64
     // work buffers, grown on demand
     int32_t *hit_id = nullptr;  size_t hit_id_cap = 0;     // per band pixel
@@ -67,6 +69,9 @@ struct rt_scene {
     // filter records, rebuilt when the camera (w, h) or the scene changes
     std::vector<rt::FilterRec> tri_rec, rect_rec, sph_rec;
     std::vector<rt::GenRec> gen_tri, gen_rect, gen_sph;   // only filled when a material reflects
+    std::vector<uint16_t> mf_rows;        // MFMA rows: (1 + npoint) x (mf_groups + 2) blocks of 32 rows x 8 bf16
+    std::vector<int32_t> mf_gid;          // MFMA stream position -> leaf index (-1: padding)
+    int mf_groups = 0;
     bool reflective = false;
     int rec_w = -1, rec_h = -1;
     bool dirty = true;                    // host scene changed since the last upload
