@@ -70,6 +70,7 @@ struct RenderParams {
     const int32_t *sph_gid;
     const uint16_t *mf_rows;        // MFMA row blocks, per apex (rt_types.h)
     const int32_t *mf_gid;          // MFMA stream position -> leaf index
+    const FilterRec *mf_rec;        // FP32 records in MFMA stream order, per apex (c[14] = kind, c[15] = leaf index)
     unsigned long long *counters;   // [0] shadow rays cast, [1] exact evals (primary), [2] exact evals (shadow)
     int32_t *hit_id;                // band-local output, indexed out_off + pix
     uint8_t *rgba;                  // band-local output (spp == 1) or nullptr
@@ -739,20 +740,34 @@ __device__ __forceinline__ bf16x8 ray_fragment(float x, float y, float z, bool a
     return __builtin_bit_cast(bf16x8, v);
 }
 
-// One MFMA step: 32 rays (B) against the 10 leaves of block A.  Returns the lane's 5-bit pass mask (0 almost always).
-__device__ __forceinline__ unsigned mfma_step(const bf16x8 A, const bf16x8 B) {
-    f32x16 acc = {0};
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, acc, 0, 0, 0);
-    const float z0 = __builtin_fminf(__builtin_fminf(acc[0], acc[1]), acc[2]);
-    const float z1 = __builtin_fminf(__builtin_fminf(acc[3], acc[4]), acc[5]);
-    const float z2 = __builtin_fminf(__builtin_fminf(acc[6], acc[7]), acc[8]);
-    const float z3 = __builtin_fminf(__builtin_fminf(acc[9], acc[10]), acc[11]);
-    const float z4 = __builtin_fminf(__builtin_fminf(acc[12], acc[13]), acc[14]);
-    const float mx = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(z0, z1), z2), __builtin_fmaxf(z3, z4));
+// NB MFMA steps, one branch: 32 rays (B[k]) each against the 10 leaves of block A.  Returns the lane's 5-bit pass
+// masks, packed 5 bits per step (0 almost always).  The NB accumulators are independent, so their MFMAs run back
+// to back while the VALU works on the previous results.
+#ifndef RT_MF_NB
+#define RT_MF_NB 2
+#endif
+template <int NB>
+__device__ __forceinline__ unsigned mfma_steps(const bf16x8 A, const bf16x8 *B) {
+    float z[NB][5];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        f32x16 acc = {0};
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B[k], acc, 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 5; ++t) z[k][t] = __builtin_fminf(__builtin_fminf(acc[3 * t], acc[3 * t + 1]), acc[3 * t + 2]);
+    }
+    float mx = z[0][0];
+#pragma unroll
+    for (int k = 0; k < NB; ++k)
+#pragma unroll
+        for (int t = (k == 0 ? 1 : 0); t < 5; ++t) mx = __builtin_fmaxf(mx, z[k][t]);      // folded into v_max3_f32
     unsigned bits = 0;
     if (mx > 0.f) {
         asm volatile("" ::: "memory");      // a real branch: the block below runs for a few percent of the steps
-        bits = (z0 > 0.f ? 1u : 0u) | (z1 > 0.f ? 2u : 0u) | (z2 > 0.f ? 4u : 0u) | (z3 > 0.f ? 8u : 0u) | (z4 > 0.f ? 16u : 0u);
+#pragma unroll
+        for (int k = 0; k < NB; ++k)
+#pragma unroll
+            for (int t = 0; t < 5; ++t) bits |= (z[k][t] > 0.f ? 1u : 0u) << (5 * k + t);
     }
     return bits;
 }
@@ -783,6 +798,11 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_shadow_mfma(const RenderParams P) {
     for (int k = -1; li < P.nlights; ++li) if (P.lights[li].kind == 0 && ++k == pl) break;
     const LightD &Lt = P.lights[li];
     const uint32_t *q = P.queue + (size_t)pl * (size_t)P.qcap;
+    // per ray of the wave: D (FP32), the queue entry and the leaf it starts on — read back on the rare path
+    __shared__ float s_d[RT_WAVES_PER_BLOCK][3][256];
+    __shared__ uint32_t s_pix[RT_WAVES_PER_BLOCK][256];
+    __shared__ int s_own[RT_WAVES_PER_BLOCK][256];
+    const int wv = (int)(threadIdx.x >> 6);
     bf16x8 B[8];
     unsigned need = 0;                       // bit b: ray (b, c) exists and no occluder found by this lane yet
 #pragma unroll
@@ -791,18 +811,28 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_shadow_mfma(const RenderParams P) {
         const bool ok = j < count;
         float dx = 0.f, dy = 0.f, dz = 0.f;
         if (ok) {
-            const HitRec H = P.hitrec[q[j]];
+            const uint32_t pix = q[j];
+            const HitRec H = P.hitrec[pix];
             double tx, ty, tz;
             to_light(Lt, H.px, H.py, H.pz, tx, ty, tz);
             dx = (float)((H.px + 0.00001 * tx) - Lt.px);
             dy = (float)((H.py + 0.00001 * ty) - Lt.py);
             dz = (float)((H.pz + 0.00001 * tz) - Lt.pz);
             need |= 1u << b;
+            if (h == 0) {
+                const int e = b * 32 + c;
+                s_d[wv][0][e] = dx; s_d[wv][1][e] = dy; s_d[wv][2][e] = dz;
+                s_pix[wv][e] = pix;
+                s_own[wv][e] = P.hit_id[P.out_off + pix];
+            }
         }
         B[b] = ray_fragment(dx, dy, dz, ok, h);
     }
+    __builtin_amdgcn_wave_barrier();
     const size_t ro = (size_t)__builtin_amdgcn_readfirstlane(Lt.rec_offset);
-    const i32x4 *blocks = reinterpret_cast<const i32x4 *>(P.mf_rows) + ro * (size_t)(P.mf_groups + 2) * 32 + c;
+    const size_t gstride = (size_t)(P.mf_groups + 2);
+    const i32x4 *blocks = reinterpret_cast<const i32x4 *>(P.mf_rows) + ro * gstride * 32 + c;
+    const FilterRec *recs = P.mf_rec + ro * gstride * MF_LEAVES + 5 * h;
     unsigned nexact = 0;
     i32x4 a_next = blocks[0];
     for (int g = 0; g < P.mf_groups; ++g) {
@@ -810,33 +840,40 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_shadow_mfma(const RenderParams P) {
         a_next = blocks[(size_t)(g + 1) * 32];             // two blocks of padding follow the last one
         unsigned pend0 = 0, pend1 = 0;
 #pragma unroll
-        for (int b = 0; b < 4; ++b) pend0 |= mfma_step(A, B[b]) << (5 * b);
+        for (int b = 0; b < 4; b += RT_MF_NB) pend0 |= mfma_steps<RT_MF_NB>(A, B + b) << (5 * b);
 #pragma unroll
-        for (int b = 4; b < 8; ++b) pend1 |= mfma_step(A, B[b]) << (5 * (b - 4));
+        for (int b = 4; b < 8; b += RT_MF_NB) pend1 |= mfma_steps<RT_MF_NB>(A, B + b) << (5 * (b - 4));
+#ifdef RT_MF_NOSLOW
+        if (pend0 == 0xffffffffu)
+#endif
         if (pend0 | pend1) {
             unsigned long long bits = (unsigned long long)pend0 | ((unsigned long long)pend1 << 20);
+#ifdef RT_COUNT_EVENTS
+            if (lane == __builtin_amdgcn_readfirstlane(lane)) atomicAdd(&P.counters[3], 1ull);
+            atomicAdd(&P.counters[5], (unsigned long long)__popcll(bits));
+#endif
             while (bits) {
+#ifdef RT_COUNT_EVENTS
+                if (lane == __builtin_amdgcn_readfirstlane(lane)) atomicAdd(&P.counters[4], 1ull);
+#endif
                 const int k = __ffsll((long long)bits) - 1;
                 bits &= bits - 1;
                 const int b = k / 5, t = k - 5 * b;
                 if (!((need >> b) & 1u)) continue;
-                const int gid = P.mf_gid[g * MF_LEAVES + 5 * h + t];
-                if (gid < 0) continue;
-                const uint32_t pix = q[wave * 256u + (unsigned)(b * 32 + c)];
-                // the hit leaf itself lies 1e-5 behind the shadow-ray origin (Main.hs:472): t < 0
-                if (P.hit_id[P.out_off + pix] == gid) continue;
-                const LeafD &L = P.leaves[gid];
-                const int kind = L.kind;
-                const HitRec H = P.hitrec[pix];
-                double tx, ty, tz;
-                to_light(Lt, H.px, H.py, H.pz, tx, ty, tz);
-                const double ox = H.px + 0.00001 * tx, oy = H.py + 0.00001 * ty, oz = H.pz + 0.00001 * tz;
-                const float dx = (float)(ox - Lt.px), dy = (float)(oy - Lt.py), dz = (float)(oz - Lt.pz);
-                const FilterRec *R = (kind == LEAF_TRI ? P.tri_rec + ro * (size_t)P.ntri : P.rect_rec + ro * (size_t)P.nrect) + L.slot;
-                if (!record_test(R, kind, dx, dy, dz)) continue;
+                const int e = b * 32 + c;
+                const FilterRec *R = recs + (size_t)g * MF_LEAVES + t;
+                const float dx = s_d[wv][0][e], dy = s_d[wv][1][e], dz = s_d[wv][2][e];
+                const int kind = __float_as_int(R->c[14]), gid = __float_as_int(R->c[15]);
+                if (gid < 0 || !record_test(R, kind, dx, dy, dz)) continue;
                 // only leaves between the light and the origin: N.D >= Kq (Main.hs:474 needs t <= distance)
                 if (!(__builtin_fmaf(R->c[11], dx, __builtin_fmaf(R->c[12], dy, R->c[13] * dz)) >= R->c[10])) continue;
-                const RayD ray = mkray(ox, oy, oz, tx, ty, tz, P.eps);                 // Main.hs:472
+                // the hit leaf itself lies 1e-5 behind the shadow-ray origin (Main.hs:472): t < 0
+                if (s_own[wv][e] == gid) continue;
+                const LeafD &L = P.leaves[gid];
+                const HitRec H = P.hitrec[s_pix[wv][e]];
+                double tx, ty, tz;
+                to_light(Lt, H.px, H.py, H.pz, tx, ty, tz);
+                const RayD ray = mkray(H.px + 0.00001 * tx, H.py + 0.00001 * ty, H.pz + 0.00001 * tz, tx, ty, tz, P.eps);   // Main.hs:472
                 double ix, iy, iz, tt;
                 ++nexact;
                 const bool hit = kind == LEAF_TRI ? leaf_isect<LEAF_TRI>(L, ray, ix, iy, iz, tt) : leaf_isect<LEAF_RECT>(L, ray, ix, iy, iz, tt);
@@ -924,26 +961,36 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_primary_mfma(const RenderParams P) {
         a_next = blocks[(size_t)(g + 1) * 32];
         unsigned pend0 = 0, pend1 = 0;
 #pragma unroll
-        for (int b = 0; b < 4; ++b) pend0 |= mfma_step(A, B[b]) << (5 * b);
+        for (int b = 0; b < 4; b += RT_MF_NB) pend0 |= mfma_steps<RT_MF_NB>(A, B + b) << (5 * b);
 #pragma unroll
-        for (int b = 4; b < 8; ++b) pend1 |= mfma_step(A, B[b]) << (5 * (b - 4));
+        for (int b = 4; b < 8; b += RT_MF_NB) pend1 |= mfma_steps<RT_MF_NB>(A, B + b) << (5 * (b - 4));
+#ifdef RT_MF_NOSLOW
+        if (pend0 == 0xffffffffu)
+#endif
         if (pend0 | pend1) {
             unsigned long long bits = (unsigned long long)pend0 | ((unsigned long long)pend1 << 20);
+#ifdef RT_COUNT_EVENTS
+            if (lane == __builtin_amdgcn_readfirstlane(lane)) atomicAdd(&P.counters[3], 1ull);
+            atomicAdd(&P.counters[5], (unsigned long long)__popcll(bits));
+#endif
             while (bits) {
+#ifdef RT_COUNT_EVENTS
+                if (lane == __builtin_amdgcn_readfirstlane(lane)) atomicAdd(&P.counters[4], 1ull);
+#endif
                 const int k = __ffsll((long long)bits) - 1;
                 bits &= bits - 1;
                 const int b = k / 5, t = k - 5 * b;
-                const int gid = P.mf_gid[g * MF_LEAVES + 5 * h + t];
                 const int y = P.row0 + ly0 + b;
-                if (gid < 0 || x >= P.w || ly0 + b >= P.nrows) continue;
-                const LeafD &L = P.leaves[gid];
-                const int kind = L.kind;
+                if (x >= P.w || ly0 + b >= P.nrows) continue;
+                const FilterRec *R = P.mf_rec + (size_t)g * MF_LEAVES + 5 * h + t;      // apex 0 = the eye
+                const int kind = __float_as_int(R->c[14]), gid = __float_as_int(R->c[15]);
                 double ox, oy;
                 sample_offset(P, x, y, ox, oy);
                 const float px = (float)(P.cam.scaleX * ((double)x + ox) + P.cam.dX);
                 const float py = (float)(P.cam.scaleY * ((double)y + oy) + P.cam.dY);
                 // eye records are affine in (posX, posY): the z column already holds c_z * d
-                if (!record_test((kind == LEAF_TRI ? P.tri_rec : P.rect_rec) + L.slot, kind, px, py, 1.0f)) continue;
+                if (gid < 0 || !record_test(R, kind, px, py, 1.0f)) continue;
+                const LeafD &L = P.leaves[gid];
                 const RayD ray = camera_ray(P, x, y);
                 double ix, iy, iz, tt;
                 ++nexact;
@@ -1324,6 +1371,7 @@ int prepare(rt_scene &s, int w, int h) {
         if ((rc = upload(s.dev.sph_gid, s.sph_gid))) return rc;
         if ((rc = upload(s.dev.mf_rows, s.mf_rows))) return rc;
         if ((rc = upload(s.dev.mf_gid, s.mf_gid))) return rc;
+        if ((rc = upload(s.dev.mf_rec, s.mf_rec))) return rc;
         if (s.reflective) {
             if ((rc = upload(s.dev.gen_sph, s.gen_sph))) return rc;
             if ((rc = upload(s.dev.gen_tri, s.gen_tri))) return rc;
@@ -1379,7 +1427,7 @@ void rt_scene_destroy(rt_scene *s) {
     if (!s) return;
     DeviceScene &d = s->dev;
     void *ptrs[] = {d.leaves, d.aux, d.guards, d.mats, d.lights, d.tri_rec, d.rect_rec, d.tri_gid, d.rect_gid,
-                    d.counters, d.qcount, d.hit_id, d.accum, d.rgba, d.hit_out, d.hitrec, d.queue, d.lit, d.gen_tri, d.gen_rect, d.sph_rec, d.gen_sph, d.sph_gid, d.mf_rows, d.mf_gid};
+                    d.counters, d.qcount, d.hit_id, d.accum, d.rgba, d.hit_out, d.hitrec, d.queue, d.lit, d.gen_tri, d.gen_rect, d.sph_rec, d.gen_sph, d.sph_gid, d.mf_rows, d.mf_gid, d.mf_rec};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (int k = 0; k < 8; ++k) {
         if (d.lvl_rays[k]) (void)hipFree(d.lvl_rays[k]);
@@ -1448,7 +1496,7 @@ int rt_render_device(rt_scene *s, int w, int h, int depth, int spp, uint64_t see
     P.hitrec = reinterpret_cast<HitRec *>(s->dev.hitrec); P.queue = s->dev.queue; P.qcount = s->dev.qcount; P.lit = s->dev.lit;
     P.gen_tri = s->dev.gen_tri; P.gen_rect = s->dev.gen_rect;
     P.sph_rec = s->dev.sph_rec; P.gen_sph = s->dev.gen_sph; P.sph_gid = s->dev.sph_gid; P.nsph = (int)s->sph_gid.size();
-    P.mf_rows = s->dev.mf_rows; P.mf_gid = s->dev.mf_gid; P.mf_groups = s->mf_groups;
+    P.mf_rows = s->dev.mf_rows; P.mf_gid = s->dev.mf_gid; P.mf_rec = s->dev.mf_rec; P.mf_groups = s->mf_groups;
     P.cam = fixed_camera(w, h);
     P.eps = ray_eps();
     P.ntri = (int)s->tri_gid.size(); P.nrect = (int)s->rect_gid.size();
@@ -1578,7 +1626,7 @@ int rt_get_stats(rt_scene *s, rt_stats *out) {
         st.rect_tests = (st.primary_rays + st.shadow_rays) * (uint64_t)s->rect_gid.size();
         st.exact_evals = c[1] + c[2];
 #ifdef RT_COUNT_EVENTS
-        fprintf(stderr, "[rt] shadow filter events (wave x leaf) %llu, with a segment candidate %llu, exact evals primary %llu shadow %llu\n", c[3], c[4], c[1], c[2]);
+        fprintf(stderr, "[rt] slow-path entries (wave x block) %llu, wave iterations %llu, lane passes of the first stage %llu, exact evals primary %llu shadow %llu\n", c[3], c[4], c[5], c[1], c[2]);
 #endif
         st.ms_primary = ms[1]; st.ms_setup = ms[2]; st.ms_shadow = ms[3]; st.ms_final = ms[4]; st.ms_total = tot;
         s->stats = st;

@@ -475,6 +475,8 @@ void build_filter_records(rt_scene &s, int w, int h) {
     const size_t gstride = (size_t)s.mf_groups + 2;
     s.mf_gid.resize(gstride * MF_LEAVES, -1);
     s.mf_rows.assign(gstride * (size_t)napex * 32 * 8, 0);
+    s.mf_rec.assign(gstride * (size_t)napex * MF_LEAVES, never_rec());
+    for (FilterRec &r : s.mf_rec) { const int32_t none = -1; std::memcpy(&r.c[15], &none, 4); }
     {
         uint16_t never[3][8];
         const_rows(never, -1.0f);
@@ -484,7 +486,14 @@ void build_filter_records(rt_scene &s, int w, int h) {
     auto fill = [&](const double A[3], const double dmax[3], double eye_d) {
         for (size_t k = 0; k < nplanar; ++k) {
             uint16_t rows[3][8];
-            make_mfma_rows(s.leaves[s.mf_gid[k]], A, dmax, rows);
+            const LeafD &L = s.leaves[s.mf_gid[k]];
+            make_mfma_rows(L, A, dmax, rows);
+            // second stage of the matrix-core kernels: the leaf's FP32 record, found by stream position; the two
+            // spare floats carry the leaf kind and index (bit patterns)
+            FilterRec &r2 = s.mf_rec[((size_t)apex * gstride) * MF_LEAVES + k];
+            r2 = make_rec(L, A, dmax, eye_d);
+            std::memcpy(&r2.c[14], &L.kind, 4);
+            std::memcpy(&r2.c[15], &s.mf_gid[k], 4);
             const size_t g = k / MF_LEAVES, hh = (k % MF_LEAVES) / 5, t = k % 5;
             for (size_t f = 0; f < 3; ++f) {
                 const size_t q = 3 * t + f, row = (q & 3) + 8 * (q >> 2) + 4 * hh;   // accumulator register q of lane half hh
