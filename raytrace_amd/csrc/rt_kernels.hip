@@ -480,8 +480,12 @@ __device__ __forceinline__ void to_light(const LightD &Lt, double hx, double hy,
     tx = lx / ln; ty = ly / ln; tz = lz / ln;
 }
 
-__global__ void __launch_bounds__(256) k_setup(const RenderParams P) {
-    const int pix = (int)(blockIdx.x * 256 + threadIdx.x);
+#define RT_SETUP_THREADS 1024
+__global__ void __launch_bounds__(RT_SETUP_THREADS) k_setup(const RenderParams P) {
+    // shadow jobs of the block per light: per-wave counts, then ONE returning atomic per (block, light)
+    __shared__ unsigned s_cnt[32][RT_SETUP_THREADS / 64];
+    __shared__ unsigned s_base[32];
+    const int pix = (int)(blockIdx.x * RT_SETUP_THREADS + threadIdx.x);
     const bool act = (unsigned)pix < num_slots(P);
     const int id = act ? P.hit_id[P.out_off + pix] : -1;
     HitRec H = {0, 0, 0, 0, 0, 0};
@@ -519,7 +523,8 @@ __global__ void __launch_bounds__(256) k_setup(const RenderParams P) {
         P.hitrec[pix] = H;
     }
     if (act) P.lit[pix] = 0u;
-    const int lane = (int)(threadIdx.x & 63);
+    const int lane = (int)(threadIdx.x & 63), wv = (int)(threadIdx.x >> 6);
+    uint32_t needmask = 0;
     int pl = 0;
     for (int li = 0; li < P.nlights; ++li) {
         const LightD &Lt = P.lights[li];
@@ -531,18 +536,27 @@ __global__ void __launch_bounds__(256) k_setup(const RenderParams P) {
             const double lndot = tx * H.nx + ty * H.ny + tz * H.nz;                    // Main.hs:476
             need = !(lndot <= 0);
         }
+        if (need) needmask |= 1u << pl;
         const unsigned long long m = __ballot(need);
-        if (m) {
-            const int leader = __ffsll((long long)m) - 1;
-            unsigned base = 0;
-            if (lane == leader) {
-                base = atomicAdd(&P.qcount[pl], (unsigned)__popcll(m));
-                atomicAdd(&P.counters[0], (unsigned long long)__popcll(m));
-            }
-            base = __shfl(base, leader);
-            if (need) P.queue[(size_t)pl * (size_t)P.qcap + base + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)pix;
-        }
+        if (lane == 0) s_cnt[pl][wv] = (unsigned)__popcll(m);
         ++pl;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < P.npoint) {
+        unsigned run = 0;
+        for (int k = 0; k < RT_SETUP_THREADS / 64; ++k) { const unsigned c = s_cnt[threadIdx.x][k]; s_cnt[threadIdx.x][k] = run; run += c; }
+        unsigned base = 0;
+        if (run) {
+            base = atomicAdd(&P.qcount[threadIdx.x], run);
+            atomicAdd(&P.counters[0], (unsigned long long)run);
+        }
+        s_base[threadIdx.x] = base;
+    }
+    __syncthreads();
+    for (pl = 0; pl < P.npoint; ++pl) {
+        const bool need = (needmask >> pl) & 1u;
+        const unsigned long long m = __ballot(need);
+        if (need) P.queue[(size_t)pl * (size_t)P.qcap + s_base[pl] + s_cnt[pl][wv] + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)pix;
     }
 }
 
@@ -740,38 +754,71 @@ __device__ __forceinline__ bf16x8 ray_fragment(float x, float y, float z, bool a
     return __builtin_bit_cast(bf16x8, v);
 }
 
-// NB MFMA steps, one branch: 32 rays (B[k]) each against the 10 leaves of block A.  Returns the lane's 5-bit pass
-// masks, packed 5 bits per step (0 almost always).  The NB accumulators are independent, so their MFMAs run back
-// to back while the VALU works on the previous results.
-#ifndef RT_MF_NB
-#define RT_MF_NB 2
+// First stage on the matrix cores, software-pipelined.  One step = one MFMA (32 rays x the 10 leaves of a block) and 7
+// VALU instructions on its 16 results per lane: z = min3 of a leaf's three forms, m = max of the lane's 5 leaves.
+// The MFMA of step k + 1 is issued BEFORE the VALU work on step k, into a second accumulator, so the matrix pipe
+// (32 cycles per MFMA) and the vector pipe (8 cycles of issue hold per MFMA + 4 per VALU instruction) of the SIMD run
+// side by side inside one wave and no s_nop separates an MFMA from the read of its result.  There is one branch per
+// block of 8 steps; it is taken for a few percent of the blocks.  Only the per-step maxima m[0..7] are kept: the
+// rare path re-issues the MFMA of a step that has a positive lane (bit-identical) and derives the 5-bit pass mask.
+#ifndef RT_MF_SCHED
+#define RT_MF_SCHED 1
 #endif
-template <int NB>
-__device__ __forceinline__ unsigned mfma_steps(const bf16x8 A, const bf16x8 *B) {
-    float z[NB][5];
+__device__ __forceinline__ float step_max(const f32x16 acc) {
+    float z[5];
 #pragma unroll
-    for (int k = 0; k < NB; ++k) {
-        f32x16 acc = {0};
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B[k], acc, 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < 5; ++t) z[k][t] = __builtin_fminf(__builtin_fminf(acc[3 * t], acc[3 * t + 1]), acc[3 * t + 2]);
-    }
-    float mx = z[0][0];
-#pragma unroll
-    for (int k = 0; k < NB; ++k)
-#pragma unroll
-        for (int t = (k == 0 ? 1 : 0); t < 5; ++t) mx = __builtin_fmaxf(mx, z[k][t]);      // folded into v_max3_f32
+    for (int t = 0; t < 5; ++t) z[t] = __builtin_fminf(__builtin_fminf(acc[3 * t], acc[3 * t + 1]), acc[3 * t + 2]);
+    return __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(z[0], z[1]), z[2]), z[3]), z[4]);
+}
+__device__ __forceinline__ f32x16 mfma0(const i32x4 a, const bf16x8 b) {
+    const f32x16 zero = {0};
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), b, zero, 0, 0, 0);
+}
+__device__ __forceinline__ unsigned step_bits(const f32x16 acc) {
     unsigned bits = 0;
-    if (mx > 0.f) {
-        asm volatile("" ::: "memory");      // a real branch: the block below runs for a few percent of the steps
 #pragma unroll
-        for (int k = 0; k < NB; ++k)
-#pragma unroll
-            for (int t = 0; t < 5; ++t) bits |= (z[k][t] > 0.f ? 1u : 0u) << (5 * k + t);
-    }
+    for (int t = 0; t < 5; ++t)
+        bits |= (__builtin_fminf(__builtin_fminf(acc[3 * t], acc[3 * t + 1]), acc[3 * t + 2]) > 0.f ? 1u : 0u) << t;
     return bits;
 }
-
+// Scans `groups` blocks starting at `blocks` (lane-adjusted pointer, 32 x i32x4 per block; two blocks of padding
+// follow the last one).  candidates(g, bits): bit 5 b + t set = ray block b passes leaf 5 h + t of block g.
+template <class F>
+__device__ __forceinline__ void mfma_scan(const i32x4 *blocks, int groups, const bf16x8 (&B)[8], F &&candidates) {
+    i32x4 a_cur = blocks[0], a_next = blocks[32];
+    f32x16 acc = mfma0(a_cur, B[0]);
+    for (int g = 0; g < groups; ++g) {
+        const i32x4 a_next2 = blocks[(size_t)(g + 2) * 32];
+        float m[8];
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const f32x16 nxt = b < 7 ? mfma0(a_cur, B[b + 1]) : mfma0(a_next, B[0]);
+            m[b] = step_max(acc);
+            // register 15 of a tile is unused (5 leaves x 3 forms); keep it occupied until the tile is consumed, or the
+            // allocator puts temporaries into the destination of the MFMA in flight (WAW hazard -> s_nop)
+            asm volatile("" :: "v"(nxt[15]));
+            acc = nxt;
+#if RT_MF_SCHED
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);      // 7 VALU
+#endif
+        }
+        const float mx = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(m[0], m[1]), __builtin_fmaxf(m[2], m[3])),
+                                         __builtin_fmaxf(__builtin_fmaxf(m[4], m[5]), __builtin_fmaxf(m[6], m[7])));
+#ifdef RT_MF_NOSLOW
+        if (mx == 12345.f)
+#endif
+        if (__builtin_amdgcn_ballot_w64(mx > 0.f)) {       // wave-uniform: every lane takes part in the MFMAs below
+            unsigned long long bits = 0;
+#pragma unroll
+            for (int b = 0; b < 8; ++b)
+                if (__builtin_amdgcn_ballot_w64(m[b] > 0.f))
+                    bits |= (unsigned long long)step_bits(mfma0(a_cur, B[b])) << (5 * b);
+            if (bits) candidates(g, bits);
+        }
+        a_cur = a_next; a_next = a_next2;
+    }
+}
 // FP32 record test of ONE ray (the second stage, rare path): the exact shape of the leaf, same margins as filter4.
 __device__ __forceinline__ bool record_test(const FilterRec *R, int kind, float x, float y, float z) {
     const float q1 = __builtin_fmaf(R->c[0], x, __builtin_fmaf(R->c[1], y, R->c[2] * z));
@@ -834,56 +881,42 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_shadow_mfma(const RenderParams P) {
     const i32x4 *blocks = reinterpret_cast<const i32x4 *>(P.mf_rows) + ro * gstride * 32 + c;
     const FilterRec *recs = P.mf_rec + ro * gstride * MF_LEAVES + 5 * h;
     unsigned nexact = 0;
-    i32x4 a_next = blocks[0];
-    for (int g = 0; g < P.mf_groups; ++g) {
-        const bf16x8 A = __builtin_bit_cast(bf16x8, a_next);
-        a_next = blocks[(size_t)(g + 1) * 32];             // two blocks of padding follow the last one
-        unsigned pend0 = 0, pend1 = 0;
-#pragma unroll
-        for (int b = 0; b < 4; b += RT_MF_NB) pend0 |= mfma_steps<RT_MF_NB>(A, B + b) << (5 * b);
-#pragma unroll
-        for (int b = 4; b < 8; b += RT_MF_NB) pend1 |= mfma_steps<RT_MF_NB>(A, B + b) << (5 * (b - 4));
-#ifdef RT_MF_NOSLOW
-        if (pend0 == 0xffffffffu)
-#endif
-        if (pend0 | pend1) {
-            unsigned long long bits = (unsigned long long)pend0 | ((unsigned long long)pend1 << 20);
+    mfma_scan(blocks, P.mf_groups, B, [&](int g, unsigned long long bits) {
 #ifdef RT_COUNT_EVENTS
-            if (lane == __builtin_amdgcn_readfirstlane(lane)) atomicAdd(&P.counters[3], 1ull);
-            atomicAdd(&P.counters[5], (unsigned long long)__popcll(bits));
+        if (lane == __builtin_amdgcn_readfirstlane(lane)) atomicAdd(&P.counters[3], 1ull);
+        atomicAdd(&P.counters[5], (unsigned long long)__popcll(bits));
 #endif
-            while (bits) {
+        while (bits) {
 #ifdef RT_COUNT_EVENTS
-                if (lane == __builtin_amdgcn_readfirstlane(lane)) atomicAdd(&P.counters[4], 1ull);
+            if (lane == __builtin_amdgcn_readfirstlane(lane)) atomicAdd(&P.counters[4], 1ull);
 #endif
-                const int k = __ffsll((long long)bits) - 1;
-                bits &= bits - 1;
-                const int b = k / 5, t = k - 5 * b;
-                if (!((need >> b) & 1u)) continue;
-                const int e = b * 32 + c;
-                const FilterRec *R = recs + (size_t)g * MF_LEAVES + t;
-                const float dx = s_d[wv][0][e], dy = s_d[wv][1][e], dz = s_d[wv][2][e];
-                const int kind = __float_as_int(R->c[14]), gid = __float_as_int(R->c[15]);
-                if (gid < 0 || !record_test(R, kind, dx, dy, dz)) continue;
-                // only leaves between the light and the origin: N.D >= Kq (Main.hs:474 needs t <= distance)
-                if (!(__builtin_fmaf(R->c[11], dx, __builtin_fmaf(R->c[12], dy, R->c[13] * dz)) >= R->c[10])) continue;
-                // the hit leaf itself lies 1e-5 behind the shadow-ray origin (Main.hs:472): t < 0
-                if (s_own[wv][e] == gid) continue;
-                const LeafD &L = P.leaves[gid];
-                const HitRec H = P.hitrec[s_pix[wv][e]];
-                double tx, ty, tz;
-                to_light(Lt, H.px, H.py, H.pz, tx, ty, tz);
-                const RayD ray = mkray(H.px + 0.00001 * tx, H.py + 0.00001 * ty, H.pz + 0.00001 * tz, tx, ty, tz, P.eps);   // Main.hs:472
-                double ix, iy, iz, tt;
-                ++nexact;
-                const bool hit = kind == LEAF_TRI ? leaf_isect<LEAF_TRI>(L, ray, ix, iy, iz, tt) : leaf_isect<LEAF_RECT>(L, ray, ix, iy, iz, tt);
-                if (hit && guards_ok(P.guards, L.guard, ray)) {
-                    const double tl = (Lt.pz - ray.pz) * ray.rz;                       // rayDistance ray lpos
-                    if (tt <= tl) need &= ~(1u << b);                                  // Main.hs:474 -> black
-                }
+            const int k = __ffsll((long long)bits) - 1;
+            bits &= bits - 1;
+            const int b = k / 5, t = k - 5 * b;
+            if (!((need >> b) & 1u)) continue;
+            const int e = b * 32 + c;
+            const FilterRec *R = recs + (size_t)g * MF_LEAVES + t;
+            const float dx = s_d[wv][0][e], dy = s_d[wv][1][e], dz = s_d[wv][2][e];
+            const int kind = __float_as_int(R->c[14]), gid = __float_as_int(R->c[15]);
+            if (gid < 0 || !record_test(R, kind, dx, dy, dz)) continue;
+            // only leaves between the light and the origin: N.D >= Kq (Main.hs:474 needs t <= distance)
+            if (!(__builtin_fmaf(R->c[11], dx, __builtin_fmaf(R->c[12], dy, R->c[13] * dz)) >= R->c[10])) continue;
+            // the hit leaf itself lies 1e-5 behind the shadow-ray origin (Main.hs:472): t < 0
+            if (s_own[wv][e] == gid) continue;
+            const LeafD &L = P.leaves[gid];
+            const HitRec H = P.hitrec[s_pix[wv][e]];
+            double tx, ty, tz;
+            to_light(Lt, H.px, H.py, H.pz, tx, ty, tz);
+            const RayD ray = mkray(H.px + 0.00001 * tx, H.py + 0.00001 * ty, H.pz + 0.00001 * tz, tx, ty, tz, P.eps);   // Main.hs:472
+            double ix, iy, iz, tt;
+            ++nexact;
+            const bool hit = kind == LEAF_TRI ? leaf_isect<LEAF_TRI>(L, ray, ix, iy, iz, tt) : leaf_isect<LEAF_RECT>(L, ray, ix, iy, iz, tt);
+            if (hit && guards_ok(P.guards, L.guard, ray)) {
+                const double tl = (Lt.pz - ray.pz) * ray.rz;                       // rayDistance ray lpos
+                if (tt <= tl) need &= ~(1u << b);                                  // Main.hs:474 -> black
             }
         }
-    }
+    });
     // spheres: lane (c, h) takes the rays (4h + r, c) with the scalar-record loop
     if (P.nsph > 0) {
         uint32_t pix[4]; bool nd[4]; float ddx[4], ddy[4], ddz[4];
@@ -955,55 +988,41 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_primary_mfma(const RenderParams P) {
     }
     const i32x4 *blocks = reinterpret_cast<const i32x4 *>(P.mf_rows) + c;      // apex 0 = the eye
     unsigned nexact = 0;
-    i32x4 a_next = blocks[0];
-    for (int g = 0; g < P.mf_groups; ++g) {
-        const bf16x8 A = __builtin_bit_cast(bf16x8, a_next);
-        a_next = blocks[(size_t)(g + 1) * 32];
-        unsigned pend0 = 0, pend1 = 0;
-#pragma unroll
-        for (int b = 0; b < 4; b += RT_MF_NB) pend0 |= mfma_steps<RT_MF_NB>(A, B + b) << (5 * b);
-#pragma unroll
-        for (int b = 4; b < 8; b += RT_MF_NB) pend1 |= mfma_steps<RT_MF_NB>(A, B + b) << (5 * (b - 4));
-#ifdef RT_MF_NOSLOW
-        if (pend0 == 0xffffffffu)
-#endif
-        if (pend0 | pend1) {
-            unsigned long long bits = (unsigned long long)pend0 | ((unsigned long long)pend1 << 20);
+    mfma_scan(blocks, P.mf_groups, B, [&](int g, unsigned long long bits) {
 #ifdef RT_COUNT_EVENTS
-            if (lane == __builtin_amdgcn_readfirstlane(lane)) atomicAdd(&P.counters[3], 1ull);
-            atomicAdd(&P.counters[5], (unsigned long long)__popcll(bits));
+        if (lane == __builtin_amdgcn_readfirstlane(lane)) atomicAdd(&P.counters[3], 1ull);
+        atomicAdd(&P.counters[5], (unsigned long long)__popcll(bits));
 #endif
-            while (bits) {
+        while (bits) {
 #ifdef RT_COUNT_EVENTS
-                if (lane == __builtin_amdgcn_readfirstlane(lane)) atomicAdd(&P.counters[4], 1ull);
+            if (lane == __builtin_amdgcn_readfirstlane(lane)) atomicAdd(&P.counters[4], 1ull);
 #endif
-                const int k = __ffsll((long long)bits) - 1;
-                bits &= bits - 1;
-                const int b = k / 5, t = k - 5 * b;
-                const int y = P.row0 + ly0 + b;
-                if (x >= P.w || ly0 + b >= P.nrows) continue;
-                const FilterRec *R = P.mf_rec + (size_t)g * MF_LEAVES + 5 * h + t;      // apex 0 = the eye
-                const int kind = __float_as_int(R->c[14]), gid = __float_as_int(R->c[15]);
-                double ox, oy;
-                sample_offset(P, x, y, ox, oy);
-                const float px = (float)(P.cam.scaleX * ((double)x + ox) + P.cam.dX);
-                const float py = (float)(P.cam.scaleY * ((double)y + oy) + P.cam.dY);
-                // eye records are affine in (posX, posY): the z column already holds c_z * d
-                if (gid < 0 || !record_test(R, kind, px, py, 1.0f)) continue;
-                const LeafD &L = P.leaves[gid];
-                const RayD ray = camera_ray(P, x, y);
-                double ix, iy, iz, tt;
-                ++nexact;
-                const bool hit = kind == LEAF_TRI ? leaf_isect<LEAF_TRI>(L, ray, ix, iy, iz, tt) : leaf_isect<LEAF_RECT>(L, ray, ix, iy, iz, tt);
-                if (hit && guards_ok(P.guards, L.guard, ray)) {
-                    // nearest wins; equal t -> the left-most leaf of the tree (Main.hs:213-214)
-                    const int e = b * 32 + c;
-                    const double ct = bt[e]; const int cid = bid[e];
-                    if (tt < ct || (tt == ct && gid < cid) || cid < 0) { bt[e] = tt; bid[e] = gid; }
-                }
+            const int k = __ffsll((long long)bits) - 1;
+            bits &= bits - 1;
+            const int b = k / 5, t = k - 5 * b;
+            const int y = P.row0 + ly0 + b;
+            if (x >= P.w || ly0 + b >= P.nrows) continue;
+            const FilterRec *R = P.mf_rec + (size_t)g * MF_LEAVES + 5 * h + t;      // apex 0 = the eye
+            const int kind = __float_as_int(R->c[14]), gid = __float_as_int(R->c[15]);
+            double ox, oy;
+            sample_offset(P, x, y, ox, oy);
+            const float px = (float)(P.cam.scaleX * ((double)x + ox) + P.cam.dX);
+            const float py = (float)(P.cam.scaleY * ((double)y + oy) + P.cam.dY);
+            // eye records are affine in (posX, posY): the z column already holds c_z * d
+            if (gid < 0 || !record_test(R, kind, px, py, 1.0f)) continue;
+            const LeafD &L = P.leaves[gid];
+            const RayD ray = camera_ray(P, x, y);
+            double ix, iy, iz, tt;
+            ++nexact;
+            const bool hit = kind == LEAF_TRI ? leaf_isect<LEAF_TRI>(L, ray, ix, iy, iz, tt) : leaf_isect<LEAF_RECT>(L, ray, ix, iy, iz, tt);
+            if (hit && guards_ok(P.guards, L.guard, ray)) {
+                // nearest wins; equal t -> the left-most leaf of the tree (Main.hs:213-214)
+                const int e = b * 32 + c;
+                const double ct = bt[e]; const int cid = bid[e];
+                if (tt < ct || (tt == ct && gid < cid) || cid < 0) { bt[e] = tt; bid[e] = gid; }
             }
         }
-    }
+    });
     __builtin_amdgcn_wave_barrier();
     // pixels (4h + r, c): spheres, then the merge of the two tables
     double mt[4]; int mid[4]; bool act[4];
@@ -1548,7 +1567,7 @@ int rt_render_device(rt_scene *s, int w, int h, int depth, int spp, uint64_t see
                 P.next_rays = (lvl + 1 < levels) ? s->dev.lvl_rays[lvl + 1] : nullptr;
                 P.next_count = lvl_count + lvl + 1;
                 P.colour = (levels > 1) ? s->dev.lvl_col[lvl] : nullptr;
-                hipLaunchKernelGGL(k_setup, dim3(pblocks), dim3(256), 0, st, P);
+                hipLaunchKernelGGL(k_setup, dim3((unsigned)(((size_t)P.qcap + RT_SETUP_THREADS - 1) / RT_SETUP_THREADS)), dim3(RT_SETUP_THREADS), 0, st, P);
                 if ((rc = next_event(*s, st, 2))) return rc;
                 if (s->npoint > 0) {
                     if (g_use_mfma) hipLaunchKernelGGL(k_shadow_mfma, dim3(sblocks, (unsigned)s->npoint), dim3(RT_WAVES_PER_BLOCK * 64), 0, st, P);
