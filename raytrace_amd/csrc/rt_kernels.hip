@@ -781,10 +781,48 @@ __device__ __forceinline__ unsigned step_bits(const f32x16 acc) {
         bits |= (__builtin_fminf(__builtin_fminf(acc[3 * t], acc[3 * t + 1]), acc[3 * t + 2]) > 0.f ? 1u : 0u) << t;
     return bits;
 }
+// Candidate queues of one wave, in LDS.  The first stage appends one entry per (ray, leaf) pair that passes; entries
+// are taken off 64 at a time, so that every lane of the wave works on one: stage1 (the FP32 record test) sends its
+// survivors to a second queue, whose entries go through the exact FP64 evaluation, again 64 at a time.  Without the
+// queues those two stages ran on the few lanes that happened to hold a candidate (5 % of the lanes on average).
+// entry = (position in the MFMA leaf stream << 8) | ray of the wave (0..255).  The counts are wave-uniform.
+constexpr int RT_Q1_CAP = 128, RT_Q2_CAP = 128;
+struct WaveQueues {
+    uint32_t *q1, *q2;
+    unsigned n1, n2;
+};
+__device__ __forceinline__ void q_push(uint32_t *q, unsigned &n, bool pred, uint32_t entry) {
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(pred);
+    if (pred) q[n + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = entry;
+    n += (unsigned)__popcll(m);
+}
+template <class S1, class EX>
+__device__ __forceinline__ void q_drain(WaveQueues &Q, unsigned keep, S1 &&stage1, EX &&exact) {
+    const unsigned lane = threadIdx.x & 63u;
+    while (Q.n1 > keep) {
+        const unsigned take = Q.n1 < 64u ? Q.n1 : 64u;
+        Q.n1 -= take;
+        const bool have = lane < take;
+        const uint32_t entry = have ? Q.q1[Q.n1 + lane] : 0u;
+        const bool pass = have && stage1(entry);
+        q_push(Q.q2, Q.n2, pass, entry);
+        if (Q.n2 >= 64u) {
+            Q.n2 -= 64u;
+            exact(Q.q2[Q.n2 + lane]);
+        }
+    }
+    if (keep == 0u && Q.n2 > 0u) {
+        const bool have = lane < Q.n2;
+        const uint32_t entry = have ? Q.q2[lane] : 0u;
+        Q.n2 = 0u;
+        if (have) exact(entry);
+    }
+}
 // Scans `groups` blocks starting at `blocks` (lane-adjusted pointer, 32 x i32x4 per block; two blocks of padding
-// follow the last one).  candidates(g, bits): bit 5 b + t set = ray block b passes leaf 5 h + t of block g.
-template <class F>
-__device__ __forceinline__ void mfma_scan(const i32x4 *blocks, int groups, const bf16x8 (&B)[8], F &&candidates) {
+// follow the last one).  Lane (c, h) owns ray column c and leaves 5 h .. 5 h + 4 of every block.
+template <class S1, class EX>
+__device__ __forceinline__ void mfma_scan(const i32x4 *blocks, int groups, const bf16x8 (&B)[8], WaveQueues &Q, int c, int h,
+                                          S1 &&stage1, EX &&exact) {
     i32x4 a_cur = blocks[0], a_next = blocks[32];
     f32x16 acc = mfma0(a_cur, B[0]);
     for (int g = 0; g < groups; ++g) {
@@ -814,10 +852,19 @@ __device__ __forceinline__ void mfma_scan(const i32x4 *blocks, int groups, const
             for (int b = 0; b < 8; ++b)
                 if (__builtin_amdgcn_ballot_w64(m[b] > 0.f))
                     bits |= (unsigned long long)step_bits(mfma0(a_cur, B[b])) << (5 * b);
-            if (bits) candidates(g, bits);
+            // bit 5 b + t: ray block b passes leaf 5 h + t of block g.  One entry per lane and round.
+            const uint32_t k0 = (uint32_t)(g * MF_LEAVES + 5 * h);
+            while (__builtin_amdgcn_ballot_w64(bits != 0ull)) {
+                const int k = __ffsll((long long)bits) - 1;
+                const int b = k / 5, t = k - 5 * b;
+                q_push(Q.q1, Q.n1, bits != 0ull, ((k0 + (uint32_t)t) << 8) | (uint32_t)(b * 32 + c));
+                bits &= bits - 1ull;
+                q_drain(Q, 63u, stage1, exact);
+            }
         }
         a_cur = a_next; a_next = a_next2;
     }
+    q_drain(Q, 0u, stage1, exact);
 }
 // FP32 record test of ONE ray (the second stage, rare path): the exact shape of the leaf, same margins as filter4.
 __device__ __forceinline__ bool record_test(const FilterRec *R, int kind, float x, float y, float z) {
@@ -845,33 +892,35 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_shadow_mfma(const RenderParams P) {
     for (int k = -1; li < P.nlights; ++li) if (P.lights[li].kind == 0 && ++k == pl) break;
     const LightD &Lt = P.lights[li];
     const uint32_t *q = P.queue + (size_t)pl * (size_t)P.qcap;
-    // per ray of the wave: D (FP32), the queue entry and the leaf it starts on — read back on the rare path
+    // per ray of the wave: D (FP32), the queue entry, the leaf it starts on, "an occluder was found"
     __shared__ float s_d[RT_WAVES_PER_BLOCK][3][256];
     __shared__ uint32_t s_pix[RT_WAVES_PER_BLOCK][256];
     __shared__ int s_own[RT_WAVES_PER_BLOCK][256];
+    __shared__ uint32_t s_occ[RT_WAVES_PER_BLOCK][256];
+    __shared__ uint32_t s_q1[RT_WAVES_PER_BLOCK][RT_Q1_CAP], s_q2[RT_WAVES_PER_BLOCK][RT_Q2_CAP];
     const int wv = (int)(threadIdx.x >> 6);
     bf16x8 B[8];
-    unsigned need = 0;                       // bit b: ray (b, c) exists and no occluder found by this lane yet
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
         const unsigned j = wave * 256u + (unsigned)(b * 32 + c);
         const bool ok = j < count;
         float dx = 0.f, dy = 0.f, dz = 0.f;
+        uint32_t pix = 0u;
         if (ok) {
-            const uint32_t pix = q[j];
+            pix = q[j];
             const HitRec H = P.hitrec[pix];
             double tx, ty, tz;
             to_light(Lt, H.px, H.py, H.pz, tx, ty, tz);
             dx = (float)((H.px + 0.00001 * tx) - Lt.px);
             dy = (float)((H.py + 0.00001 * ty) - Lt.py);
             dz = (float)((H.pz + 0.00001 * tz) - Lt.pz);
-            need |= 1u << b;
-            if (h == 0) {
-                const int e = b * 32 + c;
-                s_d[wv][0][e] = dx; s_d[wv][1][e] = dy; s_d[wv][2][e] = dz;
-                s_pix[wv][e] = pix;
-                s_own[wv][e] = P.hit_id[P.out_off + pix];
-            }
+        }
+        if (h == 0) {
+            const int e = b * 32 + c;
+            s_d[wv][0][e] = dx; s_d[wv][1][e] = dy; s_d[wv][2][e] = dz;
+            s_pix[wv][e] = pix;
+            s_own[wv][e] = ok ? P.hit_id[P.out_off + pix] : -1;
+            s_occ[wv][e] = ok ? 0u : 1u;          // a ray that does not exist counts as occluded: never lit
         }
         B[b] = ray_fragment(dx, dy, dz, ok, h);
     }
@@ -879,30 +928,26 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_shadow_mfma(const RenderParams P) {
     const size_t ro = (size_t)__builtin_amdgcn_readfirstlane(Lt.rec_offset);
     const size_t gstride = (size_t)(P.mf_groups + 2);
     const i32x4 *blocks = reinterpret_cast<const i32x4 *>(P.mf_rows) + ro * gstride * 32 + c;
-    const FilterRec *recs = P.mf_rec + ro * gstride * MF_LEAVES + 5 * h;
+    const FilterRec *recs = P.mf_rec + ro * gstride * MF_LEAVES;
     unsigned nexact = 0;
-    mfma_scan(blocks, P.mf_groups, B, [&](int g, unsigned long long bits) {
-#ifdef RT_COUNT_EVENTS
-        if (lane == __builtin_amdgcn_readfirstlane(lane)) atomicAdd(&P.counters[3], 1ull);
-        atomicAdd(&P.counters[5], (unsigned long long)__popcll(bits));
-#endif
-        while (bits) {
-#ifdef RT_COUNT_EVENTS
-            if (lane == __builtin_amdgcn_readfirstlane(lane)) atomicAdd(&P.counters[4], 1ull);
-#endif
-            const int k = __ffsll((long long)bits) - 1;
-            bits &= bits - 1;
-            const int b = k / 5, t = k - 5 * b;
-            if (!((need >> b) & 1u)) continue;
-            const int e = b * 32 + c;
-            const FilterRec *R = recs + (size_t)g * MF_LEAVES + t;
+    WaveQueues Q = {s_q1[wv], s_q2[wv], 0u, 0u};
+    mfma_scan(blocks, P.mf_groups, B, Q, c, h,
+        [&](uint32_t entry) -> bool {           // FP32 record test of one (ray, leaf) pair
+            const int e = (int)(entry & 255u);
+            const FilterRec *R = recs + (entry >> 8);
+            if (s_occ[wv][e]) return false;
             const float dx = s_d[wv][0][e], dy = s_d[wv][1][e], dz = s_d[wv][2][e];
             const int kind = __float_as_int(R->c[14]), gid = __float_as_int(R->c[15]);
-            if (gid < 0 || !record_test(R, kind, dx, dy, dz)) continue;
+            if (gid < 0 || !record_test(R, kind, dx, dy, dz)) return false;
             // only leaves between the light and the origin: N.D >= Kq (Main.hs:474 needs t <= distance)
-            if (!(__builtin_fmaf(R->c[11], dx, __builtin_fmaf(R->c[12], dy, R->c[13] * dz)) >= R->c[10])) continue;
+            if (!(__builtin_fmaf(R->c[11], dx, __builtin_fmaf(R->c[12], dy, R->c[13] * dz)) >= R->c[10])) return false;
             // the hit leaf itself lies 1e-5 behind the shadow-ray origin (Main.hs:472): t < 0
-            if (s_own[wv][e] == gid) continue;
+            return s_own[wv][e] != gid;
+        },
+        [&](uint32_t entry) {                   // exact: intersect world ray_to_light, t <= distance (Main.hs:472-474)
+            const int e = (int)(entry & 255u);
+            const FilterRec *R = recs + (entry >> 8);
+            const int kind = __float_as_int(R->c[14]), gid = __float_as_int(R->c[15]);
             const LeafD &L = P.leaves[gid];
             const HitRec H = P.hitrec[s_pix[wv][e]];
             double tx, ty, tz;
@@ -913,66 +958,52 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_shadow_mfma(const RenderParams P) {
             const bool hit = kind == LEAF_TRI ? leaf_isect<LEAF_TRI>(L, ray, ix, iy, iz, tt) : leaf_isect<LEAF_RECT>(L, ray, ix, iy, iz, tt);
             if (hit && guards_ok(P.guards, L.guard, ray)) {
                 const double tl = (Lt.pz - ray.pz) * ray.rz;                       // rayDistance ray lpos
-                if (tt <= tl) need &= ~(1u << b);                                  // Main.hs:474 -> black
+                if (tt <= tl) s_occ[wv][e] = 1u;                                   // Main.hs:474 -> black
             }
-        }
-    });
-    // spheres: lane (c, h) takes the rays (4h + r, c) with the scalar-record loop
-    if (P.nsph > 0) {
-        uint32_t pix[4]; bool nd[4]; float ddx[4], ddy[4], ddz[4];
+        });
+    __builtin_amdgcn_wave_barrier();
+    // lane (c, h) finishes the rays (4h + r, c): spheres with the scalar-record loop, then the lit bits
+    uint32_t pix[4]; bool nd[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int b = 4 * h + r;
-            const unsigned j = wave * 256u + (unsigned)(b * 32 + c);
-            nd[r] = j < count;
-            pix[r] = nd[r] ? q[j] : 0u;
-            ddx[r] = ddy[r] = ddz[r] = 0.f;
-            if (nd[r]) {
-                const HitRec H = P.hitrec[pix[r]];
-                double tx, ty, tz;
-                to_light(Lt, H.px, H.py, H.pz, tx, ty, tz);
-                ddx[r] = (float)((H.px + 0.00001 * tx) - Lt.px);
-                ddy[r] = (float)((H.py + 0.00001 * ty) - Lt.py);
-                ddz[r] = (float)((H.pz + 0.00001 * tz) - Lt.pz);
-            }
-        }
+    for (int r = 0; r < 4; ++r) {
+        const int e = (4 * h + r) * 32 + c;
+        nd[r] = s_occ[wv][e] == 0u;
+        pix[r] = s_pix[wv][e];
+    }
+    if (P.nsph > 0) {
         Dir4 D;
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-            D.x[p] = f2{ddx[2 * p], ddx[2 * p + 1]};
-            D.y[p] = f2{ddy[2 * p], ddy[2 * p + 1]};
-            D.z[p] = f2{ddz[2 * p], ddz[2 * p + 1]};
+            const int e0 = (4 * h + 2 * p) * 32 + c, e1 = e0 + 32;
+            D.x[p] = f2{s_d[wv][0][e0], s_d[wv][0][e1]};
+            D.y[p] = f2{s_d[wv][1][e0], s_d[wv][1][e1]};
+            D.z[p] = f2{s_d[wv][2][e0], s_d[wv][2][e1]};
         }
         shadow_sphere_loop(P, as_const(P.sph_rec + ro * (size_t)P.nsph), D, pix, Lt, nd, nexact);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) if (!nd[r]) need &= ~(1u << (4 * h + r));
     }
-    // a ray is lit when neither lane half found an occluder; each half reports 4 of the 8 ray blocks
-    need &= (unsigned)__shfl_xor((int)need, 32);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int b = 4 * h + r;
-        if ((need >> b) & 1u) atomicOr(&P.lit[q[wave * 256u + (unsigned)(b * 32 + c)]], 1u << pl);
-    }
+    for (int r = 0; r < 4; ++r)
+        if (nd[r]) atomicOr(&P.lit[pix[r]], 1u << pl);
     for (int o = 32; o > 0; o >>= 1) nexact += __shfl_down(nexact, o);
     if (lane == 0 && nexact) atomicAdd(&P.counters[2], (unsigned long long)nexact);
 }
 
 // Kernel 1 on the matrix cores.  One wave = 32 x 8 pixel tile; ray block b = tile row b, column c = lane & 31.
-// The nearest hit of every pixel lives in LDS, one table per lane half (the halves test different leaves of a
-// block for the same pixels), merged at the end.
+// The nearest hit of every pixel of the tile lives in LDS: t as the bit pattern of the double (t >= 0, so the
+// patterns order like the values) and the leaf index.
 __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_primary_mfma(const RenderParams P) {
-    __shared__ double s_bt[RT_WAVES_PER_BLOCK][2][256];
-    __shared__ int s_bid[RT_WAVES_PER_BLOCK][2][256];
+    __shared__ unsigned long long s_bt[RT_WAVES_PER_BLOCK][256];
+    __shared__ int s_bid[RT_WAVES_PER_BLOCK][256];
+    __shared__ uint32_t s_q1[RT_WAVES_PER_BLOCK][RT_Q1_CAP], s_q2[RT_WAVES_PER_BLOCK][RT_Q2_CAP];
     const int wv = (int)(threadIdx.x >> 6);
     const int wave = (int)(blockIdx.x * RT_WAVES_PER_BLOCK) + wv;
     const int lane = (int)(threadIdx.x & 63), c = lane & 31, h = lane >> 5;
     const int tx = wave % P.tiles_x, ty = wave / P.tiles_x;
     if (ty >= P.tiles_y) return;
-    const int x = tx * RT_TILE_W + c;
+    const int x0 = tx * RT_TILE_W, x = x0 + c;
     const int ly0 = ty * RT_TILE_H;
-    double *bt = s_bt[wv][h];
-    int *bid = s_bid[wv][h];
+    unsigned long long *bt = s_bt[wv];
+    int *bid = s_bid[wv];
     bf16x8 B[8];
     const float dzf = (float)P.cam.d;
 #pragma unroll
@@ -983,56 +1014,56 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_primary_mfma(const RenderParams P) {
         const float dx = (float)(P.cam.scaleX * ((double)x + ox) + P.cam.dX);
         const float dy = (float)(P.cam.scaleY * ((double)(P.row0 + ly0 + b) + oy) + P.cam.dY);
         B[b] = ray_fragment(dx, dy, dzf, ok, h);
-        bt[b * 32 + c] = INFINITY;
-        bid[b * 32 + c] = -1;
+        if (h == 0) { bt[b * 32 + c] = ~0ull; bid[b * 32 + c] = -1; }
     }
+    __builtin_amdgcn_wave_barrier();
     const i32x4 *blocks = reinterpret_cast<const i32x4 *>(P.mf_rows) + c;      // apex 0 = the eye
     unsigned nexact = 0;
-    mfma_scan(blocks, P.mf_groups, B, [&](int g, unsigned long long bits) {
-#ifdef RT_COUNT_EVENTS
-        if (lane == __builtin_amdgcn_readfirstlane(lane)) atomicAdd(&P.counters[3], 1ull);
-        atomicAdd(&P.counters[5], (unsigned long long)__popcll(bits));
-#endif
-        while (bits) {
-#ifdef RT_COUNT_EVENTS
-            if (lane == __builtin_amdgcn_readfirstlane(lane)) atomicAdd(&P.counters[4], 1ull);
-#endif
-            const int k = __ffsll((long long)bits) - 1;
-            bits &= bits - 1;
-            const int b = k / 5, t = k - 5 * b;
-            const int y = P.row0 + ly0 + b;
-            if (x >= P.w || ly0 + b >= P.nrows) continue;
-            const FilterRec *R = P.mf_rec + (size_t)g * MF_LEAVES + 5 * h + t;      // apex 0 = the eye
+    WaveQueues Q = {s_q1[wv], s_q2[wv], 0u, 0u};
+    mfma_scan(blocks, P.mf_groups, B, Q, c, h,
+        [&](uint32_t entry) -> bool {           // FP32 record test of one (pixel, leaf) pair
+            const int e = (int)(entry & 255u);
+            const FilterRec *R = P.mf_rec + (entry >> 8);                         // apex 0 = the eye
+            const int xe = x0 + (e & 31), ye = P.row0 + ly0 + (e >> 5);
             const int kind = __float_as_int(R->c[14]), gid = __float_as_int(R->c[15]);
             double ox, oy;
-            sample_offset(P, x, y, ox, oy);
-            const float px = (float)(P.cam.scaleX * ((double)x + ox) + P.cam.dX);
-            const float py = (float)(P.cam.scaleY * ((double)y + oy) + P.cam.dY);
+            sample_offset(P, xe, ye, ox, oy);
+            const float px = (float)(P.cam.scaleX * ((double)xe + ox) + P.cam.dX);
+            const float py = (float)(P.cam.scaleY * ((double)ye + oy) + P.cam.dY);
             // eye records are affine in (posX, posY): the z column already holds c_z * d
-            if (gid < 0 || !record_test(R, kind, px, py, 1.0f)) continue;
+            return gid >= 0 && record_test(R, kind, px, py, 1.0f);
+        },
+        [&](uint32_t entry) {                   // exact: intersect leaf (cast camera x y), Main.hs:543
+            const int e = (int)(entry & 255u);
+            const FilterRec *R = P.mf_rec + (entry >> 8);
+            const int kind = __float_as_int(R->c[14]), gid = __float_as_int(R->c[15]);
             const LeafD &L = P.leaves[gid];
-            const RayD ray = camera_ray(P, x, y);
+            const RayD ray = camera_ray(P, x0 + (e & 31), P.row0 + ly0 + (e >> 5));
             double ix, iy, iz, tt;
             ++nexact;
-            const bool hit = kind == LEAF_TRI ? leaf_isect<LEAF_TRI>(L, ray, ix, iy, iz, tt) : leaf_isect<LEAF_RECT>(L, ray, ix, iy, iz, tt);
-            if (hit && guards_ok(P.guards, L.guard, ray)) {
-                // nearest wins; equal t -> the left-most leaf of the tree (Main.hs:213-214)
-                const int e = b * 32 + c;
-                const double ct = bt[e]; const int cid = bid[e];
-                if (tt < ct || (tt == ct && gid < cid) || cid < 0) { bt[e] = tt; bid[e] = gid; }
-            }
-        }
-    });
+            const bool hit = (kind == LEAF_TRI ? leaf_isect<LEAF_TRI>(L, ray, ix, iy, iz, tt) : leaf_isect<LEAF_RECT>(L, ray, ix, iy, iz, tt))
+                             && guards_ok(P.guards, L.guard, ray);
+            // Nearest wins; equal t -> the left-most leaf of the tree (Main.hs:213-214).  Several lanes may hold hits of
+            // the same pixel: the wave runs in lockstep and its LDS operations complete in order, so (1) all read the
+            // old t, (2) all fold their t in with an atomic min, (3) the lanes whose t is the new minimum reset the
+            // leaf index if the minimum moved, (4) and fold their leaf index in with an atomic min.
+            const unsigned long long tb = (unsigned long long)__double_as_longlong(tt);
+            unsigned long long old = 0;
+            if (hit) { old = bt[e]; atomicMin(&bt[e], tb); }
+            __builtin_amdgcn_wave_barrier();
+            const bool win = hit && bt[e] == tb;
+            if (win && tb < old) bid[e] = 0x7fffffff;
+            __builtin_amdgcn_wave_barrier();
+            if (win) atomicMin(&bid[e], gid);
+        });
     __builtin_amdgcn_wave_barrier();
-    // pixels (4h + r, c): spheres, then the merge of the two tables
+    // pixels (4h + r, c): the table, then spheres
     double mt[4]; int mid[4]; bool act[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int e = (4 * h + r) * 32 + c;
-        const double t0 = s_bt[wv][0][e], t1 = s_bt[wv][1][e];
-        const int i0 = s_bid[wv][0][e], i1 = s_bid[wv][1][e];
-        const bool second = i0 < 0 || (i1 >= 0 && (t1 < t0 || (t1 == t0 && i1 < i0)));
-        mt[r] = second ? t1 : t0; mid[r] = second ? i1 : i0;
+        mid[r] = bid[e];
+        mt[r] = mid[r] >= 0 ? __longlong_as_double((long long)bt[e]) : (double)INFINITY;
         act[r] = x < P.w && ly0 + 4 * h + r < P.nrows;
     }
     if (P.nsph > 0) {
