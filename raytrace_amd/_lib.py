@@ -48,6 +48,7 @@ SYMBOLS = {
     "rt_scene_get_leaf": (C.c_int, [C.c_void_p, C.c_int, _D3]),
     "rt_scene_prepare_host": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "rt_scene_get_filter_record": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]),
+    "rt_scene_get_mfma_row": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_uint16)]),
     "rt_scene_get_guards": (C.c_int, [C.c_void_p, C.c_int, _D3, C.c_int]),
     "rt_camera_params": (C.c_int, [C.c_int, C.c_int, _D3]),
     "rt_render": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int,

@@ -721,64 +721,59 @@ __global__ void RT_HOT(RT_WAVES_EU_SHADOW) k_shadow(const RenderParams P) {
 // ------------------------------------------------------------------------------------------
 // Matrix-core versions of kernels 1 and 3.
 //
-// The filter's linear forms are a matrix product: (leaves x 3 forms) x (D components) x (rays).  Here it runs on
-// v_mfma_f32_32x32x16_bf16: the A operand is one block of 32 rows = 10 leaves x 3 forms (rt_scene.cpp builds them,
-// coefficients as bf16 hi + mid pairs), the B operand is 32 rays (D = x, y, z, 1 split the same way; lanes 0-31 hold
-// the hi parts, lanes 32-63 the mid parts), the K = 16 products of a row and a column are exactly
-// (c_hi + c_mid) (D_hi + D_mid) over the four components, summed in FP32.  A lane then owns one ray (column) and 16
-// forms (registers) = 5 leaves: z = min3 of a leaf's three forms, max over the 5 leaves, one compare — 8 VALU
-// instructions per 32 rays x 10 leaves, beside a 32-cycle MFMA, instead of 25 per 256 rays x 1 leaf.
-// A wave carries 8 B operands (256 rays).  Pairs that pass are queued in two bit masks per lane and handled after
-// the 8 MFMAs of the block: FP32 record test (exact shape, segment clip), then the exact FP64 path as before.
+// First stage: every ray against the bounding cone of every planar leaf, ONE linear form per pair,
+//     a . D^ - cos(theta) + margin > 0        (rt_scene.cpp: make_cone_row),
+// which is a matrix product (leaves x 4) x (4 x rays) and runs on v_mfma_f32_32x32x16_f16: the A operand is a block
+// of 32 leaves (rows = 2^7 (a, margin - cos theta) as FP16 hi + mid pairs), the B operand is 32 rays (2^7 (D^, 1)
+// split the same way: lanes 0-31 hold the hi parts, lanes 32-63 the mid parts), and the K = 16 products of a row and
+// a column are exactly (a_hi + a_mid)(D_hi + D_mid) over x, y, z plus the constant.  A lane then owns one ray
+// (column) and 16 leaves (registers): 8 v_max3_f32 per 32 rays x 32 leaves, beside a 32-cycle MFMA.
+// A wave carries 8 B operands (256 rays).  Pairs that pass go to the wave's candidate queues (below): FP32 record
+// test (exact shape, segment clip), then the exact FP64 evaluation.
 
-typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((__vector_size__(16 * sizeof(float)))) float f32x16;
 typedef __attribute__((__vector_size__(4 * sizeof(int)))) int i32x4;
 
-__device__ __forceinline__ uint32_t bf16_bits(float f) {        // round to nearest even; f finite
-    const uint32_t u = __float_as_uint(f);
-    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
-}
-// B fragment of one ray for lane half h: h = 0 -> (x_hi, x_hi, y_hi, y_hi, z_hi, z_hi, w, w), h = 1 -> the mid parts
-// and w = 0.  An inactive ray is all zero: every form is then 0, which is not > 0.
-__device__ __forceinline__ bf16x8 ray_fragment(float x, float y, float z, bool active, int h) {
-    uint32_t px = bf16_bits(x), py = bf16_bits(y), pz = bf16_bits(z), pw = 0x3f80u;
+// B fragment of one ray for lane half h: 2^7 D^ = v: h = 0 -> (x_hi, x_hi, y_hi, y_hi, z_hi, z_hi, w, w) with w = 2^7,
+// h = 1 -> the mid parts and w = 0.  An inactive ray is all zero: every form is then 0, which is not > 0.
+__device__ __forceinline__ f16x8 ray_fragment(float x, float y, float z, bool active, int h) {
+    const float s = 128.f * __builtin_amdgcn_rsqf(__builtin_fmaf(x, x, __builtin_fmaf(y, y, z * z)));
+    const float vx = x * s, vy = y * s, vz = z * s;
+    _Float16 hx = (_Float16)vx, hy = (_Float16)vy, hz = (_Float16)vz, hw = (_Float16)128.f;
     if (h) {
-        px = bf16_bits(x - __uint_as_float(px << 16));
-        py = bf16_bits(y - __uint_as_float(py << 16));
-        pz = bf16_bits(z - __uint_as_float(pz << 16));
-        pw = 0u;
+        hx = (_Float16)(vx - (float)hx);
+        hy = (_Float16)(vy - (float)hy);
+        hz = (_Float16)(vz - (float)hz);
+        hw = (_Float16)0.f;
     }
-    if (!active) px = py = pz = pw = 0u;
-    i32x4 v = {(int)(px | (px << 16)), (int)(py | (py << 16)), (int)(pz | (pz << 16)), (int)(pw | (pw << 16))};
-    return __builtin_bit_cast(bf16x8, v);
+    if (!active) hx = hy = hz = hw = (_Float16)0.f;
+    return f16x8{hx, hx, hy, hy, hz, hz, hw, hw};
 }
 
-// First stage on the matrix cores, software-pipelined.  One step = one MFMA (32 rays x the 10 leaves of a block) and 7
-// VALU instructions on its 16 results per lane: z = min3 of a leaf's three forms, m = max of the lane's 5 leaves.
-// The MFMA of step k + 1 is issued BEFORE the VALU work on step k, into a second accumulator, so the matrix pipe
-// (32 cycles per MFMA) and the vector pipe (8 cycles of issue hold per MFMA + 4 per VALU instruction) of the SIMD run
-// side by side inside one wave and no s_nop separates an MFMA from the read of its result.  There is one branch per
-// block of 8 steps; it is taken for a few percent of the blocks.  Only the per-step maxima m[0..7] are kept: the
-// rare path re-issues the MFMA of a step that has a positive lane (bit-identical) and derives the 5-bit pass mask.
+// The scan is software-pipelined.  One step = one MFMA (32 rays x the 32 leaves of a block) and 8 v_max3_f32 over
+// its 16 results per lane.  The MFMA of step k + 1 is issued BEFORE the VALU work on step k, into a second
+// accumulator, so the matrix pipe (32 cycles per MFMA) and the vector pipe (8 cycles of issue hold per MFMA + 4
+// per VALU instruction) of the SIMD run side by side inside one wave and no s_nop separates an MFMA from the read of
+// its result.  There is one branch per block of 8 steps.  Only the per-step maxima m[0..7] are kept: the rare path
+// re-issues the MFMA of a step that has a positive lane (bit-identical) and derives the 16-bit pass mask.
 #ifndef RT_MF_SCHED
 #define RT_MF_SCHED 1
 #endif
-__device__ __forceinline__ float step_max(const f32x16 acc) {
-    float z[5];
-#pragma unroll
-    for (int t = 0; t < 5; ++t) z[t] = __builtin_fminf(__builtin_fminf(acc[3 * t], acc[3 * t + 1]), acc[3 * t + 2]);
-    return __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(z[0], z[1]), z[2]), z[3]), z[4]);
+__device__ __forceinline__ float max3f(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
+__device__ __forceinline__ float step_max(const f32x16 a) {
+    const float m0 = max3f(a[0], a[1], a[2]), m1 = max3f(a[3], a[4], a[5]), m2 = max3f(a[6], a[7], a[8]);
+    const float m3 = max3f(a[9], a[10], a[11]), m4 = max3f(a[12], a[13], a[14]);
+    return __builtin_fmaxf(max3f(m0, m1, m2), max3f(m3, m4, a[15]));
 }
-__device__ __forceinline__ f32x16 mfma0(const i32x4 a, const bf16x8 b) {
+__device__ __forceinline__ f32x16 mfma0(const i32x4 a, const f16x8 b) {
     const f32x16 zero = {0};
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), b, zero, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), b, zero, 0, 0, 0);
 }
 __device__ __forceinline__ unsigned step_bits(const f32x16 acc) {
     unsigned bits = 0;
 #pragma unroll
-    for (int t = 0; t < 5; ++t)
-        bits |= (__builtin_fminf(__builtin_fminf(acc[3 * t], acc[3 * t + 1]), acc[3 * t + 2]) > 0.f ? 1u : 0u) << t;
+    for (int q = 0; q < 16; ++q) bits |= (acc[q] > 0.f ? 1u : 0u) << q;
     return bits;
 }
 // Candidate queues of one wave, in LDS.  The first stage appends one entry per (ray, leaf) pair that passes; entries
@@ -819,9 +814,9 @@ __device__ __forceinline__ void q_drain(WaveQueues &Q, unsigned keep, S1 &&stage
     }
 }
 // Scans `groups` blocks starting at `blocks` (lane-adjusted pointer, 32 x i32x4 per block; two blocks of padding
-// follow the last one).  Lane (c, h) owns ray column c and leaves 5 h .. 5 h + 4 of every block.
+// follow the last one).  Lane (c, h) owns ray column c and 16 of the 32 leaves of every block.
 template <class S1, class EX>
-__device__ __forceinline__ void mfma_scan(const i32x4 *blocks, int groups, const bf16x8 (&B)[8], WaveQueues &Q, int c, int h,
+__device__ __forceinline__ void mfma_scan(const i32x4 *blocks, int groups, const f16x8 (&B)[8], WaveQueues &Q, int c, int h,
                                           S1 &&stage1, EX &&exact) {
     i32x4 a_cur = blocks[0], a_next = blocks[32];
     f32x16 acc = mfma0(a_cur, B[0]);
@@ -832,13 +827,10 @@ __device__ __forceinline__ void mfma_scan(const i32x4 *blocks, int groups, const
         for (int b = 0; b < 8; ++b) {
             const f32x16 nxt = b < 7 ? mfma0(a_cur, B[b + 1]) : mfma0(a_next, B[0]);
             m[b] = step_max(acc);
-            // register 15 of a tile is unused (5 leaves x 3 forms); keep it occupied until the tile is consumed, or the
-            // allocator puts temporaries into the destination of the MFMA in flight (WAW hazard -> s_nop)
-            asm volatile("" :: "v"(nxt[15]));
             acc = nxt;
 #if RT_MF_SCHED
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // 1 MFMA
-            __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);      // 7 VALU
+            __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);      // 8 VALU
 #endif
         }
         const float mx = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(m[0], m[1]), __builtin_fmaxf(m[2], m[3])),
@@ -847,18 +839,22 @@ __device__ __forceinline__ void mfma_scan(const i32x4 *blocks, int groups, const
         if (mx == 12345.f)
 #endif
         if (__builtin_amdgcn_ballot_w64(mx > 0.f)) {       // wave-uniform: every lane takes part in the MFMAs below
-            unsigned long long bits = 0;
+            unsigned long long lo = 0, hi = 0;      // bit 16 b + q: ray block b passes the leaf of accumulator register q
 #pragma unroll
             for (int b = 0; b < 8; ++b)
-                if (__builtin_amdgcn_ballot_w64(m[b] > 0.f))
-                    bits |= (unsigned long long)step_bits(mfma0(a_cur, B[b])) << (5 * b);
-            // bit 5 b + t: ray block b passes leaf 5 h + t of block g.  One entry per lane and round.
-            const uint32_t k0 = (uint32_t)(g * MF_LEAVES + 5 * h);
-            while (__builtin_amdgcn_ballot_w64(bits != 0ull)) {
-                const int k = __ffsll((long long)bits) - 1;
-                const int b = k / 5, t = k - 5 * b;
-                q_push(Q.q1, Q.n1, bits != 0ull, ((k0 + (uint32_t)t) << 8) | (uint32_t)(b * 32 + c));
-                bits &= bits - 1ull;
+                if (__builtin_amdgcn_ballot_w64(m[b] > 0.f)) {
+                    const unsigned long long sb = (unsigned long long)step_bits(mfma0(a_cur, B[b])) << (16 * (b & 3));
+                    if (b < 4) lo |= sb; else hi |= sb;
+                }
+            // one entry per lane and round; register q of lane half h is row (q & 3) + 8 (q >> 2) + 4 h of the block
+            const uint32_t k0 = (uint32_t)(g * MF_LEAVES + 4 * h);
+            while (__builtin_amdgcn_ballot_w64((lo | hi) != 0ull)) {
+                const bool any = (lo | hi) != 0ull, first = lo != 0ull;
+                const unsigned long long wd = first ? lo : hi;
+                const int k = __ffsll((long long)wd) - 1;
+                const int b = (k >> 4) + (first ? 0 : 4), q = k & 15;
+                q_push(Q.q1, Q.n1, any, ((k0 + (uint32_t)((q & 3) + 8 * (q >> 2))) << 8) | (uint32_t)(b * 32 + c));
+                if (first) lo &= lo - 1ull; else hi &= hi - 1ull;
                 q_drain(Q, 63u, stage1, exact);
             }
         }
@@ -881,7 +877,7 @@ __device__ __forceinline__ bool record_test(const FilterRec *R, int kind, float 
 #endif
 
 // Kernel 3 on the matrix cores.  Lane (c = lane & 31, h = lane >> 5): ray column c of each of the wave's 8 ray
-// blocks, leaves 5h .. 5h + 4 of each leaf block.
+// blocks, half of the leaves of each leaf block.
 __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_shadow_mfma(const RenderParams P) {
     const int pl = (int)blockIdx.y;
     const unsigned count = P.qcount[pl];
@@ -899,7 +895,7 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_shadow_mfma(const RenderParams P) {
     __shared__ uint32_t s_occ[RT_WAVES_PER_BLOCK][256];
     __shared__ uint32_t s_q1[RT_WAVES_PER_BLOCK][RT_Q1_CAP], s_q2[RT_WAVES_PER_BLOCK][RT_Q2_CAP];
     const int wv = (int)(threadIdx.x >> 6);
-    bf16x8 B[8];
+    f16x8 B[8];
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
         const unsigned j = wave * 256u + (unsigned)(b * 32 + c);
@@ -1004,7 +1000,7 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_primary_mfma(const RenderParams P) {
     const int ly0 = ty * RT_TILE_H;
     unsigned long long *bt = s_bt[wv];
     int *bid = s_bid[wv];
-    bf16x8 B[8];
+    f16x8 B[8];
     const float dzf = (float)P.cam.d;
 #pragma unroll
     for (int b = 0; b < 8; ++b) {

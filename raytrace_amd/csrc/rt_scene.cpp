@@ -294,49 +294,124 @@ static FilterRec make_rec(const LeafD &L, const double A[3], const double dmax[3
 }
 
 // ------------------------------------------------------------------------------------------
-// MFMA rows: the same forms for the matrix cores (v_mfma_f32_32x32x16_bf16).  A form  f(D) = c.D + m  over
-// D = (x, y, z, 1) becomes one row of 8 bf16: every coefficient as hi + mid (hi = bf16(c), mid = bf16(c - hi),
-// together 2^-16 relative), and the kernels split D the same way, so the 16 products of one MFMA row x column are
-// (c_hi + c_mid) * (D_hi + D_mid) over the 4 components.  Three forms per leaf, all >= 0 inside:
-//   triangle : U, V, W                rectangle: N + A, N + B, 2N - A - B  (a triangle around the parallelogram;
-//   the FP32 record of the leaf, tested next on the rare path, has the exact shape).
-// The margin m = 2^-13 of the magnitude sum (a factor > 4 above the split and accumulation errors) is the
-// constant term, so the kernels test  min(f0, f1, f2) > 0.
-static inline uint16_t bf16_rne(float f) {
+// MFMA rows (v_mfma_f32_32x32x16_f16): the first stage of the matrix-core kernels tests every ray against a
+// bounding cone of every planar leaf — ONE linear form per (ray, leaf), so a 32 x 32 tile of the matrix product
+// decides 32 leaves x 32 rays.
+//
+// Seen from the apex A (the eye, or a light), the directions to the points of a convex planar leaf form a convex
+// spherical polygon.  If it lies inside a cap  { u : a.u >= cos(theta) }  around a unit axis a (theta < 90 deg:
+// the angular distance to a is then largest at a vertex), a ray  A + u D (u > 0)  can only meet the leaf if
+//     a . D^ - cos(theta) >= 0          with D^ = D / |D|.
+// The kernels normalise D in FP32 and split 2^7 D^ into FP16 hi + mid (hi = fp16(v), mid = fp16(v - hi): 22
+// significant bits; the factor 2^7 keeps every mid part a normal number, whether or not the matrix core flushes
+// FP16 denormals); a row holds 2^7 (a_x, a_y, a_z, M - cos(theta)) split the same way, and the 16 products of one
+// row x column are exactly (a_hi + a_mid)(D_hi + D_mid) over x, y, z plus the constant times w = 2^7.
+// Error budget (unscaled units, |a| = 1, |D^| <= 1 + 2^-22): splits 2 * 2^-22, constant 2^-22, D^ 2^-21,
+// FP32 accumulation of 16 products of magnitude <= 2: 2^-19.  The margin M = 2^-17 is more than 4 times their sum.
+// The exact shape (the FP32 record of the leaf, then the FP64 evaluation) is tested on the candidates only.
+static inline uint16_t f16_rne(float f) {             // float -> IEEE half, round to nearest even; |f| < 65504
     uint32_t u; std::memcpy(&u, &f, 4);
-    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+    const uint32_t sign = (u >> 16) & 0x8000u;
+    const int32_t e = (int32_t)((u >> 23) & 0xffu) - 127 + 15;
+    uint32_t m = u & 0x7fffffu;
+    if (((u >> 23) & 0xffu) == 0) return (uint16_t)sign;                  // zero / float denormal
+    if (e >= 31) return (uint16_t)(sign | 0x7c00u);                        // overflow -> inf (callers check the range)
+    if (e <= 0) {                                                          // half denormal
+        if (e < -10) return (uint16_t)sign;
+        m |= 0x800000u;
+        const int shift = 14 - e;                                          // 14 .. 24
+        uint32_t r = m >> shift;
+        const uint32_t rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
+        if (rem > half || (rem == half && (r & 1u))) ++r;
+        return (uint16_t)(sign | r);
+    }
+    uint32_t r = ((uint32_t)e << 10) | (m >> 13);
+    const uint32_t rem = m & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (r & 1u))) ++r;               // may carry into the exponent: still correct
+    return (uint16_t)(sign | r);
 }
-static inline float bf16_val(uint16_t b) { const uint32_t u = (uint32_t)b << 16; float f; std::memcpy(&f, &u, 4); return f; }
-static bool split_bf16(double v, uint16_t &hi, uint16_t &mid) {
-    if (!std::isfinite(v) || std::fabs(v) > 3.0e38) return false;
-    hi = bf16_rne((float)v);
-    const float fh = bf16_val(hi);
-    if (!std::isfinite(fh)) return false;
-    mid = bf16_rne((float)(v - (double)fh));
-    return true;
+static inline float f16_val(uint16_t hbits) {
+    const uint32_t sign = (uint32_t)(hbits & 0x8000u) << 16, e = (hbits >> 10) & 0x1fu, m = hbits & 0x3ffu;
+    float f;
+    if (e == 0) { f = std::ldexp((float)m, -24); uint32_t u; std::memcpy(&u, &f, 4); u |= sign; std::memcpy(&f, &u, 4); return f; }
+    const uint32_t u = sign | ((e - 15 + 127) << 23) | (m << 13);
+    std::memcpy(&f, &u, 4);
+    return f;
 }
-static void const_rows(uint16_t rows[3][8], float w) {
-    for (int k = 0; k < 3; ++k) { for (int j = 0; j < 8; ++j) rows[k][j] = 0; rows[k][6] = bf16_rne(w); }
+static void split_f16(double v, uint16_t &hi, uint16_t &mid) {             // |v| <= 2^8
+    hi = f16_rne((float)v);
+    mid = f16_rne((float)(v - (double)f16_val(hi)));
 }
-static void make_mfma_rows(const LeafD &L, const double A[3], const double dmax[3], uint16_t rows[3][8]) {
+static constexpr double MF_SCALE = 128.0;                                  // 2^7, on both operands
+static constexpr double MF_MARGIN = 1.0 / 131072.0;                        // 2^-17
+static void const_row(uint16_t row[8], float w) {                          // form = w * 2^14: never (< 0) or always (> 0) a candidate
+    for (int j = 0; j < 8; ++j) row[j] = 0;
+    row[6] = f16_rne(w * (float)MF_SCALE);
+}
+// Smallest cap around the unit vectors u[0..n-1] (n <= 4) among the caps through two or three of them; returns
+// cos(theta) (or -2: none found) and the axis.
+static double bounding_cap(const double u[4][3], int n, double axis[3]) {
+    double best = -2.0;
+    auto consider = [&](const double a[3]) {
+        const double len = std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+        if (!(len > 1e-300)) return;
+        const double c[3] = {a[0] / len, a[1] / len, a[2] / len};
+        double mn = 2.0;
+        for (int i = 0; i < n; ++i) mn = std::fmin(mn, c[0] * u[i][0] + c[1] * u[i][1] + c[2] * u[i][2]);
+        if (mn > best) { best = mn; for (int k = 0; k < 3; ++k) axis[k] = c[k]; }
+    };
+    for (int i = 0; i < n; ++i)
+        for (int j = i + 1; j < n; ++j) {
+            const double a[3] = {u[i][0] + u[j][0], u[i][1] + u[j][1], u[i][2] + u[j][2]};
+            consider(a);
+            for (int k = j + 1; k < n; ++k) {       // the circle through three of them: axis = normal of their plane
+                const double p[3] = {u[j][0] - u[i][0], u[j][1] - u[i][1], u[j][2] - u[i][2]};
+                const double q[3] = {u[k][0] - u[i][0], u[k][1] - u[i][1], u[k][2] - u[i][2]};
+                double a3[3] = {p[1] * q[2] - p[2] * q[1], p[2] * q[0] - p[0] * q[2], p[0] * q[1] - p[1] * q[0]};
+                if (a3[0] * u[i][0] + a3[1] * u[i][1] + a3[2] * u[i][2] < 0) for (int t = 0; t < 3; ++t) a3[t] = -a3[t];
+                consider(a3);
+            }
+        }
+    double mean[3] = {0, 0, 0};
+    for (int i = 0; i < n; ++i) for (int k = 0; k < 3; ++k) mean[k] += u[i][k];
+    consider(mean);
+    return best;
+}
+// The points of the plane that the reference's inside test accepts: the triangle pa pb pc (Main.hs:382), or the
+// parallelogram 0 <= dV.w <= ww, 0 <= dV.h <= hh (Main.hs:238-241; w and h need not be orthogonal).
+static int leaf_polygon(const LeafD &L, double v[4][3]) {
+    const double p0[3] = {L.p0x, L.p0y, L.p0z}, e1[3] = {L.e1x, L.e1y, L.e1z}, e2[3] = {L.e2x, L.e2y, L.e2z};
+    if (L.kind == LEAF_TRI) {
+        for (int i = 0; i < 3; ++i) { v[0][i] = p0[i]; v[1][i] = p0[i] + e1[i]; v[2][i] = p0[i] + e2[i]; }
+        return 3;
+    }
+    const double ww = L.c0, hh = L.c1, wh = e1[0] * e2[0] + e1[1] * e2[1] + e1[2] * e2[2];
+    const double det = ww * hh - wh * wh;
+    if (!(std::fabs(det) > 1e-12 * std::fabs(ww * hh)) || !std::isfinite(det)) return 0;
+    const double st[4][2] = {{0, 0}, {ww, 0}, {ww, hh}, {0, hh}};
+    for (int k = 0; k < 4; ++k) {
+        const double al = (st[k][0] * hh - st[k][1] * wh) / det, be = (st[k][1] * ww - st[k][0] * wh) / det;
+        for (int i = 0; i < 3; ++i) v[k][i] = p0[i] + al * e1[i] + be * e2[i];
+    }
+    return 4;
+}
+static void make_cone_row(const LeafD &L, const double A[3], const double dmax[3], uint16_t row[8]) {
     const Forms F = leaf_forms(L, A, dmax);
-    if (F.status == 1) { const_rows(rows, -1.0f); return; }       // never > 0
-    if (F.status == 2) { const_rows(rows, 1.0f); return; }        // always > 0: the exact path decides
-    double r[3][3];
-    for (int i = 0; i < 3; ++i) {
-        if (L.kind == LEAF_TRI) { r[0][i] = F.c1[i]; r[1][i] = F.c2[i]; r[2][i] = F.cn[i] - F.c1[i] - F.c2[i]; }
-        else { r[0][i] = F.cn[i] + F.c1[i]; r[1][i] = F.cn[i] + F.c2[i]; r[2][i] = 2 * F.cn[i] - F.c1[i] - F.c2[i]; }
+    if (F.status == 1) { const_row(row, -1.0f); return; }        // the reference never hits this leaf (NaN constants)
+    double v[4][3], u[4][3], axis[3] = {0, 0, 0};
+    const int n = leaf_polygon(L, v);
+    bool ok = n > 0;
+    for (int k = 0; k < n && ok; ++k) {
+        double d[3], len2 = 0, scale = 0;
+        for (int i = 0; i < 3; ++i) { d[i] = v[k][i] - A[i]; len2 += d[i] * d[i]; scale += std::fabs(v[k][i]) + std::fabs(A[i]); }
+        const double len = std::sqrt(len2);
+        ok = std::isfinite(len) && len > 1e-9 * (1.0 + scale);
+        for (int i = 0; i < 3 && ok; ++i) u[k][i] = d[i] / len;
     }
-    double S = 0;
-    for (int k = 0; k < 3; ++k) for (int i = 0; i < 3; ++i) S += std::fabs(r[k][i]) * dmax[i];
-    const double m = std::ldexp(S, -13) + 1e-30;
-    bool ok = std::isfinite(S);
-    for (int k = 0; k < 3 && ok; ++k) {
-        for (int i = 0; i < 3 && ok; ++i) ok = split_bf16(r[k][i], rows[k][2 * i], rows[k][2 * i + 1]);
-        if (ok) ok = split_bf16(m, rows[k][6], rows[k][7]);
-        // the split of m must not round the margin down by more than the slack: hi + mid >= m (1 - 2^-15)
-    }
-    if (!ok) const_rows(rows, 1.0f);
+    const double cs = ok ? bounding_cap(u, n, axis) : -2.0;
+    if (!(cs > 0.05)) { const_row(row, 1.0f); return; }           // wide or degenerate: every ray is a candidate
+    for (int i = 0; i < 3; ++i) split_f16(MF_SCALE * axis[i], row[2 * i], row[2 * i + 1]);
+    split_f16(MF_SCALE * (MF_MARGIN - cs * (1.0 - 1e-12)), row[6], row[7]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -467,7 +542,7 @@ void build_filter_records(rt_scene &s, int w, int h) {
                 if (std::isfinite(p[k][i])) { lo[i] = std::fmin(lo[i], p[k][i]); hi[i] = std::fmax(hi[i], p[k][i]); }
     }
     const CameraD cam = fixed_camera(w, h);
-    // MFMA stream: the planar leaves in tree order, 10 per block of 32 rows (see rt_types.h), two blocks of padding
+    // MFMA stream: the planar leaves in tree order, one row each, 32 per block (see rt_types.h), two blocks of padding
     s.mf_gid.clear();
     for (size_t g = 0; g < s.leaves.size(); ++g) if (s.leaves[g].kind != LEAF_SPHERE) s.mf_gid.push_back((int32_t)g);
     const size_t nplanar = s.mf_gid.size();
@@ -478,27 +553,21 @@ void build_filter_records(rt_scene &s, int w, int h) {
     s.mf_rec.assign(gstride * (size_t)napex * MF_LEAVES, never_rec());
     for (FilterRec &r : s.mf_rec) { const int32_t none = -1; std::memcpy(&r.c[15], &none, 4); }
     {
-        uint16_t never[3][8];
-        const_rows(never, -1.0f);
-        for (size_t r = 0; r < gstride * (size_t)napex * 32; ++r) std::memcpy(&s.mf_rows[r * 8], never[0], 16);
+        uint16_t never[8];
+        const_row(never, -1.0f);
+        for (size_t r = 0; r < gstride * (size_t)napex * 32; ++r) std::memcpy(&s.mf_rows[r * 8], never, 16);
     }
     int apex = 0;
     auto fill = [&](const double A[3], const double dmax[3], double eye_d) {
         for (size_t k = 0; k < nplanar; ++k) {
-            uint16_t rows[3][8];
             const LeafD &L = s.leaves[s.mf_gid[k]];
-            make_mfma_rows(L, A, dmax, rows);
+            make_cone_row(L, A, dmax, &s.mf_rows[((size_t)apex * gstride * MF_LEAVES + k) * 8]);
             // second stage of the matrix-core kernels: the leaf's FP32 record, found by stream position; the two
             // spare floats carry the leaf kind and index (bit patterns)
             FilterRec &r2 = s.mf_rec[((size_t)apex * gstride) * MF_LEAVES + k];
             r2 = make_rec(L, A, dmax, eye_d);
             std::memcpy(&r2.c[14], &L.kind, 4);
             std::memcpy(&r2.c[15], &s.mf_gid[k], 4);
-            const size_t g = k / MF_LEAVES, hh = (k % MF_LEAVES) / 5, t = k % 5;
-            for (size_t f = 0; f < 3; ++f) {
-                const size_t q = 3 * t + f, row = (q & 3) + 8 * (q >> 2) + 4 * hh;   // accumulator register q of lane half hh
-                std::memcpy(&s.mf_rows[(((size_t)apex * gstride + g) * 32 + row) * 8], rows[f], 16);
-            }
         }
         for (size_t k = 0; k < ntri; ++k) s.tri_rec[(size_t)apex * ntri + k] = make_rec(s.leaves[s.tri_gid[k]], A, dmax, eye_d);
         for (size_t k = 0; k < nrect; ++k) s.rect_rec[(size_t)apex * nrect + k] = make_rec(s.leaves[s.rect_gid[k]], A, dmax, eye_d);
@@ -711,6 +780,20 @@ int rt_scene_get_filter_record(const rt_scene *s, int apex, int leaf, float out[
     const size_t n = L.kind == LEAF_TRI ? s->tri_gid.size() : (L.kind == LEAF_SPHERE ? s->sph_gid.size() : s->rect_gid.size());
     std::memcpy(out, v[(size_t)apex * n + (size_t)L.slot].c, sizeof(float) * 16);
     return RT_OK;
+}
+
+int rt_scene_get_mfma_row(const rt_scene *s, int apex, int leaf, uint16_t out[8]) {
+    if (!s || !out || leaf < 0 || (size_t)leaf >= s->leaves.size() || apex < 0 || apex > s->npoint || s->rec_w < 0) {
+        set_error("rt_scene_get_mfma_row: bad argument (call rt_scene_prepare_host first)"); return RT_ERR_ARG;
+    }
+    const size_t gstride = (size_t)s->mf_groups + 2;
+    for (size_t k = 0; k < gstride * MF_LEAVES; ++k)
+        if (s->mf_gid[k] == leaf) {
+            std::memcpy(out, &s->mf_rows[((size_t)apex * gstride * MF_LEAVES + k) * 8], 16);
+            return (int)k;
+        }
+    set_error("rt_scene_get_mfma_row: the leaf has no row (spheres are tested by their own loop)");
+    return RT_ERR_ARG;
 }
 
 int rt_scene_get_guards(const rt_scene *s, int leaf, double *out, int cap) {

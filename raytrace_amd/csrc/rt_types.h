@@ -60,11 +60,12 @@ struct FilterRec { float c[16]; };
 // Sphere, apex form: oc xyz (apex - centre), cs = |oc|^2 - r^2, ..., c[9] = negm: the line A + u D meets the
 // sphere iff (D.oc)^2 - |D|^2 cs >= 0.  Sphere, general form (GenRec): centre xyz, r^2, ..., c[12] = negm.
 
-// MFMA stream (v_mfma_f32_32x32x16_bf16): blocks of 32 rows x 8 bf16 (512 bytes) = MF_LEAVES planar leaves x 3
-// forms.  Row r of a block is the A-operand fragment of lanes r and r + 32; the D tile puts rows
-// (q & 3) + 8 (q >> 2) + 4 hh into accumulator register q of lane half hh, so leaf 5 hh + t of the block
-// owns registers 3t .. 3t + 2 there (register 15 is unused).  Row = c_x, c_y, c_z, margin as hi/mid bf16 pairs.
-constexpr int MF_LEAVES = 10;
+// MFMA stream (v_mfma_f32_32x32x16_f16): blocks of 32 rows x 8 halves (512 bytes), one row per planar leaf in tree
+// order (leaf at stream position k = row k % 32 of block k / 32).  Row r of a block is the A-operand fragment of
+// lanes r and r + 32; the D tile puts row (q & 3) + 8 (q >> 2) + 4 hh into accumulator register q of lane half hh.
+// Row = 2^7 (a_x, a_y, a_z, margin - cos theta) as FP16 hi/mid pairs: the bounding cone of the leaf seen from the
+// apex (rt_scene.cpp: make_cone_row).
+constexpr int MF_LEAVES = 32;
 
 // 16 floats per leaf for rays with arbitrary origins (reflected rays, Main.hs:549-552):
 //   n xyz, dpl, g1 xyz, c1, g2 xyz, c2, negm, 0, 0, 0     with q_k(p) = g_k . p + c_k the two inside coordinates

@@ -27,6 +27,129 @@ def records(sc, apex, w, h):
     return recs, kinds
 
 
+def cone_rows(sc, apex, w, h):
+    """First-stage rows of the matrix-core kernels (rt_scene_get_mfma_row), as the FP16 values the MFMA multiplies."""
+    L = _lib.lib()
+    assert L.rt_scene_prepare_host(sc.handle, w, h) >= 0
+    out = (C.c_uint16 * 8)()
+    rows = np.zeros((sc.num_leaves, 8), np.float64)
+    for i in range(sc.num_leaves):
+        assert L.rt_scene_get_mfma_row(sc.handle, apex, i, out) >= 0
+        rows[i] = np.frombuffer(out, np.float16).astype(np.float64)
+    return rows
+
+
+def cone_form(row, D):
+    """ray_fragment + one row x column of v_mfma_f32_32x32x16_f16 (rt_kernels.hip), for float32 directions D[n, 3]:
+    2^7 D^ split into FP16 hi + mid, 16 exact products, summed here in float32 one after the other."""
+    D = D.astype(np.float32)
+    s = np.float32(128.0) * (np.float32(1.0) / np.sqrt(fma32(D[:, 0], D[:, 0], fma32(D[:, 1], D[:, 1], D[:, 2] * D[:, 2]))))
+    v = (D * s[:, None]).astype(np.float32)
+    hi = v.astype(np.float16)
+    mid = (v - hi.astype(np.float32)).astype(np.float16)
+    acc = np.zeros(len(D), np.float32)
+    for part, wv in ((hi, 128.0), (mid, 0.0)):
+        for i in range(3):
+            for j in range(2):
+                acc = (acc + (row[2 * i + j] * part[:, i].astype(np.float64)).astype(np.float32)).astype(np.float32)
+        for j in range(2):
+            acc = (acc + np.float32(row[6 + j] * wv)).astype(np.float32)
+    return acc
+
+
+@pytest.mark.parametrize("name,w,h", [("default", 128, 128), ("stacked_cubes", 96, 96), ("cylinder_axes", 100, 80),
+                                      ("triangle_example", 120, 66), ("intersection", 96, 96), ("planes", 80, 60)])
+def test_eye_cones_accept_every_oracle_hit(name, w, h):
+    """Matrix-core first stage, eye apex: the bounding cone of the hit leaf accepts the pixel's ray, and the margin
+    is not what saves it (the form stays positive with the margin taken away twice over is NOT required: only > 0)."""
+    world, lights = scenes.REFERENCE_SCENES[name]()
+    sc = api.Scene(world, lights)
+    rows = cone_rows(sc, 0, w, h)
+    cam = (C.c_double * 5)()
+    _lib.lib().rt_camera_params(w, h, cam)
+    hit = ob.OracleScene(world, lights).render(w, h, use_bbox=0)["hit_id"]
+    ys, xs = np.nonzero(hit >= 0)
+    D = np.stack([(cam[0] * xs.astype(np.float64) + cam[2]), (cam[1] * ys.astype(np.float64) + cam[3]),
+                  np.full(len(xs), cam[4])], axis=1).astype(np.float32)
+    ids = hit[ys, xs]
+    assert len(ids) > 100
+    kinds = np.array([int(sc.leaf(i)[0]) for i in range(sc.num_leaves)])
+    for leaf in np.unique(ids):
+        if kinds[leaf] == 2:
+            continue            # spheres have their own loop
+        m = ids == leaf
+        f = cone_form(rows[leaf], D[m])
+        assert (f > 0).all(), f"{name}: leaf {leaf} rejected by its bounding cone (min form {f.min()})"
+    sc.close()
+
+
+def test_eye_cones_are_selective():
+    """...and the cones are a filter: for the default scene fewer than 2 % of (pixel, leaf) pairs pass, and a
+    leaf's cone passes at most a few times the pixels the leaf really covers."""
+    world, lights = scenes.default_scene()
+    w = h = 96
+    sc = api.Scene(world, lights)
+    rows = cone_rows(sc, 0, w, h)
+    cam = (C.c_double * 5)()
+    _lib.lib().rt_camera_params(w, h, cam)
+    ys, xs = np.mgrid[0:h, 0:w]
+    D = np.stack([(cam[0] * xs.ravel().astype(np.float64) + cam[2]), (cam[1] * ys.ravel().astype(np.float64) + cam[3]),
+                  np.full(w * h, cam[4])], axis=1).astype(np.float32)
+    passed = sum(int((cone_form(rows[i], D) > 0).sum()) for i in range(sc.num_leaves))
+    assert passed < 0.02 * w * h * sc.num_leaves
+    sc.close()
+
+
+def test_light_cones_accept_every_occluder():
+    """Matrix-core first stage, light apex: for hit points of stacked_cubes and every leaf whose interior the segment
+    to the light crosses, the leaf's cone (seen from the light) accepts the shadow ray's direction."""
+    world, lights = scenes.stacked_cubes()
+    w = h = 64
+    sc = api.Scene(world, lights)
+    o = ob.OracleScene(world, lights).render(w, h, use_bbox=0, want_t=True)
+    point_lights = [l for l in lights if isinstance(l, api.PointLight)]
+    leaves = [sc.leaf(i) for i in range(sc.num_leaves)]
+    checked = 0
+    for k, lt in enumerate(point_lights):
+        rows = cone_rows(sc, 1 + k, w, h)
+        for y in range(0, h, 3):
+            for x in range(0, w, 3):
+                if o["hit_id"][y, x] < 0:
+                    continue
+                ray = (C.c_double * 9)()
+                ob.lib().orc_camera_ray(w, h, x, y, ray)
+                p = np.array(ray[0:3]) + o["t"][y, x] * np.array(ray[3:6])
+                tl = np.array(lt.pos) - p
+                tl /= np.linalg.norm(tl)
+                org = p + 1e-5 * tl
+                dist = np.linalg.norm(np.array(lt.pos) - org)
+                D = (org - np.array(lt.pos)).astype(np.float32)[None, :]
+                for i, lf in enumerate(leaves):
+                    n, d = np.array(lf[2:5]), lf[5]
+                    den = n @ tl
+                    if abs(den) < 1e-9:
+                        continue
+                    t = -(n @ org + d) / den
+                    if not (-1e-4 < t < dist):
+                        continue
+                    q = org + t * tl - np.array(lf[6:9])
+                    e1, e2 = np.array(lf[9:12]), np.array(lf[12:15])
+                    if lf[0] == 0:
+                        a, b = q @ e1 / lf[15], q @ e2 / lf[16]
+                        inside = 0 <= a <= 1 and 0 <= b <= 1
+                    else:
+                        wv, wu = q @ e2, q @ e1
+                        r, s = (lf[15] * wv - lf[17] * wu) / lf[18], (lf[15] * wu - lf[16] * wv) / lf[18]
+                        inside = r >= 0 and s >= 0 and r + s <= 1
+                    if not inside:
+                        continue
+                    f = cone_form(rows[i], D)[0]
+                    assert f > 0, f"light {k} pixel ({x},{y}) leaf {i}: rejected by its bounding cone ({f})"
+                    checked += 1
+    assert checked > 500
+    sc.close()
+
+
 def eye_z(rec, kind, px, py):
     """filter4_eye of rt_kernels.hip for one leaf and arrays of pixels."""
     q = []
