@@ -760,11 +760,17 @@ __device__ __forceinline__ f16x8 ray_fragment(float x, float y, float z, bool ac
 #ifndef RT_MF_SCHED
 #define RT_MF_SCHED 1
 #endif
-__device__ __forceinline__ float max3f(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
-__device__ __forceinline__ float step_max(const f32x16 a) {
-    const float m0 = max3f(a[0], a[1], a[2]), m1 = max3f(a[3], a[4], a[5]), m2 = max3f(a[6], a[7], a[8]);
-    const float m3 = max3f(a[9], a[10], a[11]), m4 = max3f(a[12], a[13], a[14]);
-    return __builtin_fmaxf(max3f(m0, m1, m2), max3f(m3, m4, a[15]));
+// "Some form is > 0" is tested on the bit patterns with v_max3_i32: a positive float is a positive integer, and an
+// integer max needs no NaN canonicalisation of its inputs (v_max3_f32 does: two more instructions per step).  A NaN
+// with a clear sign bit counts as a candidate, which is the safe side.
+__device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }
+__device__ __forceinline__ int step_max(const f32x16 acc) {
+    int a[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) a[q] = __float_as_int(acc[q]);
+    const int m0 = max3i(a[0], a[1], a[2]), m1 = max3i(a[3], a[4], a[5]), m2 = max3i(a[6], a[7], a[8]);
+    const int m3 = max3i(a[9], a[10], a[11]), m4 = max3i(a[12], a[13], a[14]);
+    return max(max3i(m0, m1, m2), max3i(m3, m4, a[15]));
 }
 __device__ __forceinline__ f32x16 mfma0(const i32x4 a, const f16x8 b) {
     const f32x16 zero = {0};
@@ -773,7 +779,7 @@ __device__ __forceinline__ f32x16 mfma0(const i32x4 a, const f16x8 b) {
 __device__ __forceinline__ unsigned step_bits(const f32x16 acc) {
     unsigned bits = 0;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) bits |= (acc[q] > 0.f ? 1u : 0u) << q;
+    for (int q = 0; q < 16; ++q) bits |= (__float_as_int(acc[q]) > 0 ? 1u : 0u) << q;
     return bits;
 }
 // Candidate queues of one wave, in LDS.  The first stage appends one entry per (ray, leaf) pair that passes; entries
@@ -822,27 +828,28 @@ __device__ __forceinline__ void mfma_scan(const i32x4 *blocks, int groups, const
     f32x16 acc = mfma0(a_cur, B[0]);
     for (int g = 0; g < groups; ++g) {
         const i32x4 a_next2 = blocks[(size_t)(g + 2) * 32];
-        float m[8];
+        int m[8];
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
             const f32x16 nxt = b < 7 ? mfma0(a_cur, B[b + 1]) : mfma0(a_next, B[0]);
-            m[b] = step_max(acc);
-            acc = nxt;
 #if RT_MF_SCHED
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // 1 MFMA
-            __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);      // 8 VALU
+            __builtin_amdgcn_sched_barrier(0);      // the MFMA of the next step goes first ...
 #endif
+            m[b] = step_max(acc);
+#if RT_MF_SCHED
+            __builtin_amdgcn_sched_barrier(0);      // ... and nothing of the next step moves up into this one
+#endif
+            acc = nxt;
         }
-        const float mx = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(m[0], m[1]), __builtin_fmaxf(m[2], m[3])),
-                                         __builtin_fmaxf(__builtin_fmaxf(m[4], m[5]), __builtin_fmaxf(m[6], m[7])));
+        const int mx = max3i(max3i(m[0], m[1], m[2]), max3i(m[3], m[4], m[5]), max(m[6], m[7]));
 #ifdef RT_MF_NOSLOW
-        if (mx == 12345.f)
+        if (mx == 0x7fffffff)
 #endif
-        if (__builtin_amdgcn_ballot_w64(mx > 0.f)) {       // wave-uniform: every lane takes part in the MFMAs below
+        if (__builtin_amdgcn_ballot_w64(mx > 0)) {       // wave-uniform: every lane takes part in the MFMAs below
             unsigned long long lo = 0, hi = 0;      // bit 16 b + q: ray block b passes the leaf of accumulator register q
 #pragma unroll
             for (int b = 0; b < 8; ++b)
-                if (__builtin_amdgcn_ballot_w64(m[b] > 0.f)) {
+                if (__builtin_amdgcn_ballot_w64(m[b] > 0)) {
                     const unsigned long long sb = (unsigned long long)step_bits(mfma0(a_cur, B[b])) << (16 * (b & 3));
                     if (b < 4) lo |= sb; else hi |= sb;
                 }
@@ -873,7 +880,7 @@ __device__ __forceinline__ bool record_test(const FilterRec *R, int kind, float 
 }
 
 #ifndef RT_WAVES_EU_MFMA
-#define RT_WAVES_EU_MFMA 4
+#define RT_WAVES_EU_MFMA 3
 #endif
 
 // Kernel 3 on the matrix cores.  Lane (c = lane & 31, h = lane >> 5): ray column c of each of the wave's 8 ray

@@ -205,3 +205,25 @@ def test_cpp_main_matches_oracle(gpu_lib, tmp_path):
     ref = ob.OracleScene(world, lights).render(w, h)
     assert (px == ref["rgb"]).all()
     assert (np.fromfile(ids, np.int32).reshape(h, w) == ref["hit_id"]).all()
+
+
+def test_matrix_core_and_valu_filters_agree_full_size(gpu_lib):
+    """Size-independent check at the benchmark sizes: the two first stages are independent conservative filters
+    (bounding cones on the matrix cores; per-leaf linear forms on the vector ALU, RT_FILTER=valu), and the exact
+    FP64 stage decides — so whole frames must agree bit for bit, hit IDs and colours."""
+    from raytrace_amd import _lib
+    cases = [(scenes.synthetic(), 3840, 2160, 1), (scenes.synthetic_cylinders(), 1920, 1080, 4), (scenes.default_scene(), 3840, 2160, 1)]
+    try:
+        for (world, lights), w, h, spp in cases:
+            out = {}
+            for mode in ("mfma", "valu"):
+                os.environ["RT_FILTER"] = mode
+                _lib.check(_lib.lib().rt_init(0), "rt_init")
+                sc = api.Scene(world, lights)
+                out[mode] = sc.render(w, h, spp=spp, seed=7)
+                sc.close()
+            assert (out["mfma"][1] == out["valu"][1]).all()
+            assert (out["mfma"][0] == out["valu"][0]).all()
+    finally:
+        os.environ.pop("RT_FILTER", None)
+        _lib.check(_lib.lib().rt_init(0), "rt_init")
