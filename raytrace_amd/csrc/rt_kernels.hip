@@ -819,19 +819,22 @@ __device__ __forceinline__ void q_drain(WaveQueues &Q, unsigned keep, S1 &&stage
         if (have) exact(entry);
     }
 }
-// Scans `groups` blocks starting at `blocks` (lane-adjusted pointer, 32 x i32x4 per block; two blocks of padding
-// follow the last one).  Lane (c, h) owns ray column c and 16 of the 32 leaves of every block.
+// Scans `groups` blocks (a multiple of 3; 32 x i32x4 per block, two blocks of padding follow the last one) starting
+// at the wave-uniform address `base`.  Lane (c, h) owns ray column c and 16 of the 32 leaves of every block.
+// The A fragments live in a ring of three registers (in use, next, in flight) and the loop body is written out three
+// times, so a fragment is loaded straight into the register it is used from: no copies, two blocks of prefetch.
 template <class S1, class EX>
-__device__ __forceinline__ void mfma_scan(const i32x4 *blocks, int groups, const f16x8 (&B)[8], WaveQueues &Q, int c, int h,
+__device__ __forceinline__ void mfma_scan(const i32x4 *base, int groups, const f16x8 (&B)[8], WaveQueues &Q, int c, int h,
                                           S1 &&stage1, EX &&exact) {
-    i32x4 a_cur = blocks[0], a_next = blocks[32];
-    f32x16 acc = mfma0(a_cur, B[0]);
-    for (int g = 0; g < groups; ++g) {
-        const i32x4 a_next2 = blocks[(size_t)(g + 2) * 32];
+    auto blk = [&](int g) { return (base + (size_t)g * 32)[c]; };      // uniform base + lane offset
+    i32x4 a0 = blk(0), a1 = blk(1), a2;
+    f32x16 acc = mfma0(a0, B[0]);
+    // one block: 8 steps on fragment a_use; the last step issues the first MFMA of the next block (fragment a_nxt)
+    auto block = [&](const i32x4 &a_use, const i32x4 &a_nxt, int g) {
         int m[8];
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
-            const f32x16 nxt = b < 7 ? mfma0(a_cur, B[b + 1]) : mfma0(a_next, B[0]);
+            const f32x16 nxt = b < 7 ? mfma0(a_use, B[b + 1]) : mfma0(a_nxt, B[0]);
 #if RT_MF_SCHED
             __builtin_amdgcn_sched_barrier(0);      // the MFMA of the next step goes first ...
 #endif
@@ -850,7 +853,7 @@ __device__ __forceinline__ void mfma_scan(const i32x4 *blocks, int groups, const
 #pragma unroll
             for (int b = 0; b < 8; ++b)
                 if (__builtin_amdgcn_ballot_w64(m[b] > 0)) {
-                    const unsigned long long sb = (unsigned long long)step_bits(mfma0(a_cur, B[b])) << (16 * (b & 3));
+                    const unsigned long long sb = (unsigned long long)step_bits(mfma0(a_use, B[b])) << (16 * (b & 3));
                     if (b < 4) lo |= sb; else hi |= sb;
                 }
             // one entry per lane and round; register q of lane half h is row (q & 3) + 8 (q >> 2) + 4 h of the block
@@ -865,7 +868,11 @@ __device__ __forceinline__ void mfma_scan(const i32x4 *blocks, int groups, const
                 q_drain(Q, 63u, stage1, exact);
             }
         }
-        a_cur = a_next; a_next = a_next2;
+    };
+    for (int g = 0; g < groups; g += 3) {
+        a2 = blk(g + 2); block(a0, a1, g);
+        a0 = blk(g + 3); block(a1, a2, g + 1);
+        a1 = blk(g + 4); block(a2, a0, g + 2);
     }
     q_drain(Q, 0u, stage1, exact);
 }
@@ -930,7 +937,7 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_shadow_mfma(const RenderParams P) {
     __builtin_amdgcn_wave_barrier();
     const size_t ro = (size_t)__builtin_amdgcn_readfirstlane(Lt.rec_offset);
     const size_t gstride = (size_t)(P.mf_groups + 2);
-    const i32x4 *blocks = reinterpret_cast<const i32x4 *>(P.mf_rows) + ro * gstride * 32 + c;
+    const i32x4 *blocks = reinterpret_cast<const i32x4 *>(P.mf_rows) + ro * gstride * 32;
     const FilterRec *recs = P.mf_rec + ro * gstride * MF_LEAVES;
     unsigned nexact = 0;
     WaveQueues Q = {s_q1[wv], s_q2[wv], 0u, 0u};
@@ -1020,7 +1027,7 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_primary_mfma(const RenderParams P) {
         if (h == 0) { bt[b * 32 + c] = ~0ull; bid[b * 32 + c] = -1; }
     }
     __builtin_amdgcn_wave_barrier();
-    const i32x4 *blocks = reinterpret_cast<const i32x4 *>(P.mf_rows) + c;      // apex 0 = the eye
+    const i32x4 *blocks = reinterpret_cast<const i32x4 *>(P.mf_rows);          // apex 0 = the eye
     unsigned nexact = 0;
     WaveQueues Q = {s_q1[wv], s_q2[wv], 0u, 0u};
     mfma_scan(blocks, P.mf_groups, B, Q, c, h,

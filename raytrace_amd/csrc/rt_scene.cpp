@@ -547,6 +547,7 @@ void build_filter_records(rt_scene &s, int w, int h) {
     for (size_t g = 0; g < s.leaves.size(); ++g) if (s.leaves[g].kind != LEAF_SPHERE) s.mf_gid.push_back((int32_t)g);
     const size_t nplanar = s.mf_gid.size();
     s.mf_groups = (int)((nplanar + MF_LEAVES - 1) / MF_LEAVES);
+    s.mf_groups = (s.mf_groups + 2) / 3 * 3;               // the scan handles three blocks per loop iteration (padding: never rows)
     const size_t gstride = (size_t)s.mf_groups + 2;
     s.mf_gid.resize(gstride * MF_LEAVES, -1);
     s.mf_rows.assign(gstride * (size_t)napex * 32 * 8, 0);
