@@ -13,9 +13,13 @@ The scene and its FP32 filter records are resident in HBM before the timed regio
 buffer stays in HBM.  value = primary rays of the whole frame / max-over-ranks wall time.
 
 Also on the JSON line:
-  roofline      — the dominant kernel (k_shadow: the shadow-ray loops) against the FP32 vector
-                  peak, in ALGORITHMIC flops (52 / 44 flops per ray x triangle / rectangle test + 1
-                  for the nearest select, SURVEY.md §8 d), timed with HIP events on the render stream.
+  roofline      — the dominant kernel (k_primary_mfma: every primary ray against every leaf) in
+                  ALGORITHMIC flops (52 / 44 flops per ray x triangle / rectangle test + 1 for the
+                  nearest select, SURVEY.md §8 d) over its launch time (HIP events on the render
+                  stream).  The first stage of that kernel runs on the matrix cores, so the bound is
+                  "mfma" and peak is the dense FP16 MFMA peak; the same rate against the FP32 vector
+                  peak of BASELINE.json's metric, and the EXECUTED matrix-core rate (one
+                  v_mfma_f32_32x32x16_f16 = 32768 flops per 32 rays x 32 leaves), are given beside it.
   cpu_baseline  — the CPU oracle (a C restatement of the reference, NOT the Haskell program) on the
                   host cores, on a bounded band of the same frame (rank 0, N = 1 only).
 """
@@ -36,11 +40,14 @@ from raytrace_amd.distributed import gather_bands, split_rows  # noqa: E402
 
 FLOPS_TRI, FLOPS_RECT = 52 + 1, 44 + 1
 PEAK_FP32_TFLOPS = 157.3                        # MI355X_MICROARCH.md: peak FP32 (vector), packed FMA
-# HBM bytes of one k_shadow launch on the default N = 1 workload, from the PMC passes committed under
-# profiles/ (r01_pmc_rd / r01_pmc_wr: FETCH_SIZE and WRITE_SIZE are in KiB and are summed as reported;
-# the guide's x2 correction applies to 16-B-per-lane streaming reads only, which this kernel has none of).
+PEAK_MFMA_F16_TFLOPS = 2500.0                   # MI355X_MICROARCH.md: peak BF16/FP16 MFMA, dense
+MFMA_FLOPS = 2 * 32 * 32 * 16                   # one v_mfma_f32_32x32x16_f16
+# HBM bytes of one k_primary_mfma launch on the default N = 1 workload, from the PMC passes committed under
+# profiles/ (r01_final_pmc_rd / _wr: FETCH_SIZE 9 685 KiB + WRITE_SIZE 33 133 KiB per dispatch, summed as reported:
+# the hit-ID buffer is 4 B x 8 294 400 px = 32 400 KiB of the writes; the guide's x2 correction applies to
+# 16-B-per-lane streaming reads, of which the kernel has only the L2-resident 256 KiB row stream).
 # The counters cannot be read from inside this process; for any other workload traffic is null.
-K_SHADOW_TRAFFIC_BYTES_DEFAULT = (329533 + 24400) * 1024
+K_PRIMARY_TRAFFIC_BYTES_DEFAULT = (9685 + 33133) * 1024
 
 
 def balanced_bands(scene, w, h, n, depth):
@@ -93,6 +100,8 @@ def main():
                          "use with --spp 16 --width 7680 --height 4320); default = the Main.hs scene (configs[0]/[1])")
     ap.add_argument("--spp", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--filter", default="mfma", choices=["mfma", "valu"],
+                    help="first stage: bounding cones on the matrix cores (default) or the FP32 vector-ALU kernels")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the measured path) or gloo (rehearsal on one GPU)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank renders on GPU 0 (gloo only)")
     ap.add_argument("--verify", action="store_true", help="rank 0 re-renders the whole frame alone and compares it with the gathered one")
@@ -120,6 +129,7 @@ def main():
         else:
             dist.init_process_group("gloo")
     staged = n > 1 and args.dist_backend != "nccl"               # gloo rehearsal: bands travel through host memory
+    os.environ["RT_FILTER"] = args.filter
     _lib.check(_lib.lib().rt_init(local_rank), "rt_init")
 
     w = args.width or (3840 if n == 1 else 16384)
@@ -205,27 +215,43 @@ def main():
         per_test = ntri * FLOPS_TRI + nrect * FLOPS_RECT
         ms_shade = float(np.mean(shade_ms)) if shade_ms else float(shade_t[0])
         ms_prim = float(np.mean(prim_ms)) if prim_ms else float(shade_t[1])
-        # per-launch algorithmic flops of the dominant kernel (k_shadow: one filter test per shadow ray x leaf)
-        shade_flops = shadow / n * per_test
-        achieved = shade_flops / (ms_shade * 1e-3) / 1e12
+        # per-launch algorithmic flops of the dominant kernel (k_primary*: one test per primary ray x leaf)
+        prim_flops = primary / n * per_test
+        achieved = prim_flops / (ms_prim * 1e-3) / 1e12
+        mfma = args.filter == "mfma"
+        # executed matrix-core work of that launch: one MFMA per 32 rays (a row of a 32 x 8 tile) x block of 32 leaves
+        tiles = -(-w // 32) * -(-nrows // 8)
+        blocks = -(-(ntri + nrect) // 32)
+        blocks = -(-blocks // 3) * 3            # the leaf stream is padded to a multiple of 3 blocks
+        mfma_steps = tiles * 8 * blocks * args.spp
+        executed = mfma_steps * MFMA_FLOPS / (ms_prim * 1e-3) / 1e12
+        peak = PEAK_MFMA_F16_TFLOPS if mfma else PEAK_FP32_TFLOPS
         out = {
             "metric": "primary Mrays/s (whole node)", "value": primary / (dt / args.steps) / 1e6, "unit": "Mrays/s",
             "n_gpus": n, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "strong" if n > 1 else "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{wname} ({ntri + nrect} leaves), {nlt} point light(s) + ambient, "
                                    f"{w}x{h}, depth {args.depth}, spp {args.spp}, brute force"
                                    + (f", {n} cost-balanced row bands gathered to GPU 0 over " + ("RCCL" if not staged else "gloo via host memory (rehearsal)") if n > 1 else ""),
+                       "arithmetic": "hits and colours decided in f64 (the reference's Double); conservative filters in front: "
+                                     + ("f16 bounding cones on the matrix cores, then f32 records" if args.filter == "mfma" else "f32 records on the vector ALU"),
                        "width": w, "height": h, "leaves": ntri + nrect, "lights": nlt, "spp": args.spp,
                        "bands": bands if n > 1 else None, "gathered_frame_equals_single_render": verified,
                        "shadow_rays_per_frame": shadow, "exact_fp64_evals_per_frame": exact,
                        "whole_frame_algorithmic_tflops": (primary + shadow) * per_test / (dt / args.steps) / 1e12,
                        "kernel_ms": {"k_primary": ms_prim, "k_setup": stats["ms_setup"], "k_shadow": ms_shade, "k_final": stats["ms_final"]}},
-            "roofline": {"bound": "valu_fp32", "kernel": "k_shadow", "achieved": achieved, "peak": PEAK_FP32_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS,
-                         "traffic": K_SHADOW_TRAFFIC_BYTES_DEFAULT if (n == 1 and args.spp == 1 and args.workload == "synthetic" and (w, h, ntri, nrect) == (3840, 2160, 10000, 6000)) else None,
-                         "traffic_unit": "bytes per launch (rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE, profiles/r01_pmc_*)",
-                         "note": "algorithmic flops (53/45 per ray x triangle/rectangle test) x shadow rays cast x leaves, per launch"},
+            "roofline": {"bound": "mfma" if mfma else "valu_fp32", "kernel": "k_primary_mfma" if mfma else "k_primary",
+                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                         "traffic": K_PRIMARY_TRAFFIC_BYTES_DEFAULT if (mfma and n == 1 and args.spp == 1 and args.workload == "synthetic" and (w, h, ntri, nrect) == (3840, 2160, 10000, 6000)) else None,
+                         "traffic_unit": "bytes per launch (rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE, profiles/r01_final_pmc_*)",
+                         "frac_of_fp32_valu_peak": achieved / PEAK_FP32_TFLOPS,
+                         "executed_mfma_tflops": executed if mfma else None,
+                         "executed_mfma_frac": executed / PEAK_MFMA_F16_TFLOPS if mfma else None,
+                         "note": "achieved = algorithmic flops (53/45 per ray x triangle/rectangle test, SURVEY.md 8d) x primary rays x leaves "
+                                 "of one launch / its HIP-event time; the kernel executes far fewer (one FP16 MFMA form per pair, then "
+                                 "FP32/FP64 on the candidates), so frac_of_fp32_valu_peak exceeds 1; executed_mfma_* is the matrix-core "
+                                 "work actually issued against the dense FP16 peak"},
         }
         if n == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(world, lights, w, h, args.depth)
