@@ -61,7 +61,7 @@ typedef struct {
     uint64_t exact_evals;        /* FP64 exact leaf evaluations (candidates of the filter)     */
     double   ms_primary;         /* HIP-event time of k_primary (nearest hit)                  */
     double   ms_setup;           /* ... of k_setup (exact hit records + shadow-job queues)     */
-    double   ms_shadow;          /* ... of k_shadow (shadow rays, the dominant kernel)         */
+    double   ms_shadow;          /* ... of k_shadow_mfma / k_shadow (shadow rays)               */
     double   ms_final;           /* ... of k_final (Phong + RGBA8 store)                       */
     double   ms_total;           /* first launch to last kernel end                            */
 } rt_stats;
