@@ -71,6 +71,14 @@ int  rt_init(int device);                       /* hipSetDevice + stream; call o
 const char *rt_last_error(void);
 const char *rt_version(void);
 
+/* Dialect of the scene: RT_DIALECT_MAIN = src/Main.hs (default); RT_DIALECT_TALK = the smaller program src/Talk.hs:
+ * normalize = scalar (recip (norm v)) v (Talk.hs:66-67), rectangle accepts D.(i - o) >= 0 (:119-128), nearest by
+ * squared distance and no bounding-box guards (:185-194), pointLight intensity lp = round (min 1 (max 0 (L.N) *
+ * intensity) * colour), shadowed iff (lp - p').L >= 0 (:237-248; pass the intensity as `diffuse` of
+ * rt_add_point_light), no reflection (traceAndShade, :255-258).  Rectangles only.  Call before the first shape. */
+enum { RT_DIALECT_MAIN = 0, RT_DIALECT_TALK = 1 };
+int  rt_scene_set_dialect(rt_scene *, int dialect);
+
 /* ---- scene construction (replaces the closure-building constructors) -------------------- */
 int  rt_scene_create(rt_scene **out);
 void rt_scene_destroy(rt_scene *);

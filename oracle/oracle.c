@@ -141,6 +141,7 @@ typedef struct {
 typedef struct { int kind; double diffuse, specular, f; v3 pos; } lightsrc; /* kind 0 point, 1 ambient */
 
 struct orc_scene {
+    int talk;      /* 1: the rules of src/Talk.hs (orc_scene_set_talk) */
     node *nodes; int nnodes, capnodes;
     orc_material *mats; int nmats, capmats;
     lightsrc *lights; int nlights, caplights;
@@ -177,6 +178,16 @@ static int add_mat(orc_scene *s, const orc_material *m) {
 }
 static inline v3 P(const double p[3]) { return V(p[0], p[1], p[2]); }
 
+/* Talk.hs dialect: its own normalize (:66-67), rectangle test (:119-128), nearest-by-squared-distance monoid
+ * without bounding boxes (:185-194), single-term point light (:237-248), no reflection (:255-258). */
+int orc_scene_set_talk(orc_scene *s, int on) {
+    if (!s || s->nnodes > 0) return -1;        /* before the first shape: constructors precompute normals */
+    s->talk = on ? 1 : 0;
+    return 0;
+}
+/* Talk.hs:66-67: normalize v = scalar (recip (norm v)) v */
+static inline v3 normalize_talk(v3 v) { double rn = 1.0 / norm(v); return V(rn * v.x, rn * v.y, rn * v.z); }
+
 int orc_mempty(orc_scene *s) { return new_node(s, N_EMPTY); }                          /* :204 */
 
 int orc_mappend(orc_scene *s, int l, int r) {                                          /* :205-216 */
@@ -209,7 +220,8 @@ int orc_rectangle(orc_scene *s, const orc_material *m, const double point_[3],
     int i = new_node(s, N_RECT);
     node *n = &s->nodes[i];
     n->mat = add_mat(s, m);
-    n->normal = normalize(cross(width, height));                                       /* :228 */
+    n->normal = s->talk ? normalize_talk(cross(width, height))                         /* Talk.hs:114 */
+                        : normalize(cross(width, height));                             /* :228 */
     n->ww = dot(width, width);                                                         /* :229 */
     n->hh = dot(height, height);                                                       /* :230 */
     n->p0 = vsub(vsub(point, scalar(0.5, width)), scalar(0.5, height));                /* :231 */
@@ -425,8 +437,20 @@ static inline int planeRayIsect(v3 normal, double d, const ray *r, v3 *isect, do
     return *t >= 0;                                                                    /* :257 */
 }
 
-static int isect_leaf(const node *n, const ray *r, hit *out) {
+static int isect_leaf(const node *n, const ray *r, hit *out, int talk) {
     v3 isect; double t;
+    if (talk) {                                                                        /* Talk.hs:119-128 */
+        if (n->kind != N_RECT) return 0;                                               /* Talk.hs has rectangles only */
+        if (!planeLineIsect(n->normal, n->d, r->pos, r->dir, &isect, NULL)) return 0;  /* :120 */
+        v3 v = vsub(isect, r->pos);
+        if (!(dot(r->dir, v) >= 0)) return 0;                                          /* :121-122 */
+        v3 dV = vsub(isect, n->p0);
+        double dw = dot(dV, n->e1), dh = dot(dV, n->e2);
+        if (!(0 <= dw && dw <= n->ww && 0 <= dh && dh <= n->hh)) return 0;             /* :123-127 */
+        out->pos = isect; out->normal = n->normal; out->mat = n->mat; out->leaf = n->leaf_id;
+        out->t = dot(v, v);                  /* the monoid's key: squared distance from the ray position, :192-193 */
+        return 1;
+    }
     switch (n->kind) {
     case N_RECT: case N_MANTLE: {                                                      /* :234-242 */
         if (!planeRayIsect(n->normal, n->d, r, &isect, &t)) return 0;
@@ -475,7 +499,7 @@ static int isect_node(const orc_scene *s, int idx, const ray *r, hit *out, int u
     const node *n = &s->nodes[idx];
     switch (n->kind) {
     case N_EMPTY: return 0;
-    case N_RECT: case N_TRI: case N_SPHERE: case N_MANTLE: return isect_leaf(n, r, out);
+    case N_RECT: case N_TRI: case N_SPHERE: case N_MANTLE: return isect_leaf(n, r, out, s->talk);
     case N_GAUSS: {                                                                    /* :959-963 */
         if (!isect_node(s, n->left, r, out, use_bbox)) return 0;
         v3 q = scalar(n->scale_inv, vsub(out->pos, n->offset));
@@ -530,8 +554,18 @@ static px8 shade(const orc_scene *s, int world, const hit *h, const ray *r, int 
     for (int i = 0; i < s->nlights; ++i) {
         const lightsrc *L = &s->lights[i];
         px8 c = { 0, 0, 0 };
-        if (L->kind == 1) c = scalePixel(L->f, m->diffuse);                            /* :490-492 */
-        else {                                                                         /* :467-487 */
+        if (L->kind == 1) c = scalePixel(L->f, m->diffuse);                            /* :490-492, Talk.hs:230-235 */
+        else if (s->talk) {                                                            /* Talk.hs:237-248 */
+            v3 to_light = normalize_talk(vsub(L->pos, h->pos));                        /* :239 */
+            ray rl = mkray(vadd(h->pos, scalar(0.00001, to_light)), to_light);         /* :240 */
+            hit sh;
+            if (isect_node(s, world, &rl, &sh, 0) && dot(vsub(L->pos, sh.pos), to_light) >= 0) { /* :241-242 */
+                /* black */
+            } else {
+                double f = hs_min(1, hs_max(0, dot(to_light, h->normal)) * L->diffuse); /* :244 */
+                c = scalePixel(f, m->diffuse);                                         /* :245-248 */
+            }
+        } else {                                                                         /* :467-487 */
             v3 to_light = normalize(vsub(L->pos, h->pos));
             double sp = m->specularity;
             ray rl = mkray(vadd(h->pos, scalar(0.00001, to_light)), to_light);
@@ -560,6 +594,7 @@ static px8 trace(const orc_scene *s, int world, int n, const ray *r, int use_bbo
     if (first_ok) { *first_ok = ok; if (ok) *first = h; }
     if (!ok) return black;
     px8 direct = shade(s, world, &h, r, use_bbox);
+    if (s->talk) return direct;                                                        /* Talk.hs:255-258 */
     double reflectivity = s->mats[h.mat].reflectivity;
     double rr = dot(h.normal, r->dir);                                                 /* :549 */
     px8 reflection = black;
@@ -588,10 +623,10 @@ static camera fixedCamera(int width, int height) {
     c.d = tan(fov / 2) * c.dX;                                                         /* :527 */
     return c;
 }
-static inline ray cast(const camera *c, double sx, double sy) {                        /* :528-533 */
+static inline ray cast(const camera *c, double sx, double sy, int talk) {              /* :528-533, Talk.hs:148-153 */
     double posX = c->scaleX * sx + c->dX;
     double posY = c->scaleY * sy + c->dY;
-    return mkray(V(posX, posY, 0), normalize(V(posX, posY, c->d)));
+    return mkray(V(posX, posY, 0), talk ? normalize_talk(V(posX, posY, c->d)) : normalize(V(posX, posY, c->d)));
 }
 
 double orc_eps(void) { pthread_once(&g_once, init_consts); return g_eps; }
@@ -602,7 +637,7 @@ void orc_camera_params(int w, int h, double out[5]) {
 void orc_camera_ray(int w, int h, int x, int y, double out[9]) {
     pthread_once(&g_once, init_consts);
     camera c = fixedCamera(w, h);
-    ray r = cast(&c, (double)x, (double)y);
+    ray r = cast(&c, (double)x, (double)y, 0);
     out[0] = r.pos.x; out[1] = r.pos.y; out[2] = r.pos.z;
     out[3] = r.dir.x; out[4] = r.dir.y; out[5] = r.dir.z;
     out[6] = r.recip.x; out[7] = r.recip.y; out[8] = r.recip.z;
@@ -695,7 +730,7 @@ static uint8_t analyze(const orc_scene *s, int root, const int *leaves, int nlea
     double t1 = INFINITY, t2 = INFINITY; int id1 = -1;
     for (int k = 0; k < nleaves; ++k) {
         hit h;
-        if (isect_leaf(&s->nodes[leaves[k]], r, &h)) {
+        if (isect_leaf(&s->nodes[leaves[k]], r, &h, s->talk)) {
             if (h.t < t1) { t2 = t1; t1 = h.t; id1 = k; }
             else if (h.t < t2) t2 = h.t;
         }
@@ -733,7 +768,7 @@ static void *render_rows(void *arg) {
             for (int sidx = 0; sidx < j->spp; ++sidx) {
                 double ox, oy;
                 sample_offset(x, y, sidx, j->spp, j->seed, &ox, &oy);
-                ray r = cast(&cam, (double)x + ox, (double)y + oy);
+                ray r = cast(&cam, (double)x + ox, (double)y + oy, j->s->talk);
                 hit h; int ok;
                 px8 c = trace(j->s, j->root, j->depth, &r, j->use_bbox, &h, &ok);
                 sum[0] += c.r; sum[1] += c.g; sum[2] += c.b;

@@ -44,6 +44,12 @@ typedef struct {
 orc_scene *orc_scene_new(void);
 void       orc_scene_free(orc_scene *);
 
+/* Switches the scene to the rules of src/Talk.hs (before the first shape): normalize = scalar (recip (norm v)) v
+ * (Talk.hs:66-67), rectangle accepts D.(i - o) >= 0 (:119-128), nearest by squared distance and no bounding boxes
+ * (:185-194), pointLight intensity = min 1 (max 0 (L.N) * intensity), shadow iff (lp - p').L >= 0 (:237-248; the
+ * intensity is passed as `diffuse`), no reflection (:255-258).  Rectangles only. */
+int orc_scene_set_talk(orc_scene *, int on);
+
 /* Shape constructors; every call returns a node handle (>= 0) or a negative error. */
 int orc_mempty(orc_scene *);                                                        /* Main.hs:204 */
 int orc_mappend(orc_scene *, int left, int right);                                  /* Main.hs:205-216 */

@@ -31,6 +31,7 @@ SYMBOLS = {
     "rt_version": (C.c_char_p, []),
     "rt_scene_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "rt_scene_destroy": (None, [C.c_void_p]),
+    "rt_scene_set_dialect": (C.c_int, [C.c_void_p, C.c_int]),
     "rt_add_rectangle": (C.c_int, [C.c_void_p, _MAT, _D3, _D3, _D3]),
     "rt_add_triangle": (C.c_int, [C.c_void_p, _MAT, _D3, _D3, _D3]),
     "rt_add_sphere": (C.c_int, [C.c_void_p, _MAT, _D3, C.c_double]),

@@ -14,6 +14,10 @@ Names, argument order and meaning follow the reference:
     linearInterpolation f fnorm (x1,y1) (x2,y2) step origin scale        Main.hs:937
     fixedCamera w h, trace depth lights world, parallelTrace w h camera tracer      Main.hs:506, 541, 623
     saveBmpImage path image                          Main.hs:621
+
+The smaller program src/Talk.hs (its own normalize, rectangle test, monoid and point light) is mirrored by
+talk_rectangle / talk_cube / talk_pointLight / traceAndShade / parallel (Talk.hs:112, 197, 237, 255, 171); a world
+wrapped in TalkDialect is rendered with Talk.hs's rules (rt_scene_set_dialect).
 """
 import ctypes as C
 import math
@@ -139,6 +143,12 @@ class GaussianNormals(Shape):
     offset: Vec
 
 
+@dataclass
+class TalkDialect(Shape):
+    """Marks a world as a src/Talk.hs world: rendered with Talk.hs's rules (rectangles only)."""
+    child: Shape
+
+
 mempty = Empty()
 
 
@@ -182,6 +192,35 @@ def cube(material, point, l) -> Shape:
 
 def cylinder(topM, botM, mantleM, point, n, h, r) -> Shape:
     return Cylinder(topM, botM, mantleM, tuple(point), int(n), h, r)
+
+
+# ---- src/Talk.hs constructors -----------------------------------------------------------------
+
+def talk_rectangle(colour, point, width, height) -> Shape:          # Talk.hs:112
+    m = colour if isinstance(colour, Material) else _colour(tuple(colour))
+    return Rectangle(m, tuple(point), tuple(width), tuple(height))
+
+
+def talk_cube(colours, s, p) -> Shape:                               # Talk.hs:197-218 (`<>` is infixr: a <> (b <> ...))
+    s2 = s / 2
+    c = [colours[i % len(colours)] for i in range(6)]                # take 6 $ cycle colours
+    px, py, pz = p
+    faces = [
+        talk_rectangle(c[0], (px, py + s2, pz), (s, 0, 0), (0, 0, -s)),      # top
+        talk_rectangle(c[1], (px, py - s2, pz), (0, 0, s), (s, 0, 0)),       # bottom
+        talk_rectangle(c[2], (px, py, pz + s2), (s, 0, 0), (0, s, 0)),       # front
+        talk_rectangle(c[3], (px, py, pz - s2), (s, 0, 0), (0, -s, 0)),      # back
+        talk_rectangle(c[4], (px + s2, py, pz), (0, s, 0), (0, 0, s)),       # left
+        talk_rectangle(c[5], (px - s2, py, pz), (0, s, 0), (0, 0, -s)),      # right
+    ]
+    out = faces[-1]
+    for f in reversed(faces[:-1]):
+        out = MAppend(f, out)
+    return out
+
+
+def talk_pointLight(intensity, lp):                                  # Talk.hs:237 (the world is bound at render time)
+    return [PointLight(intensity, 0.0, tuple(lp))]
 
 
 # ---------------------------------------------------------------------------------------------
@@ -290,6 +329,9 @@ class Scene:
         h = C.c_void_p()
         _lib.check(self._L.rt_scene_create(C.byref(h)), "rt_scene_create")
         self._h = h
+        if isinstance(world, TalkDialect):        # src/Talk.hs rules; must be set before the first shape
+            _lib.check(self._L.rt_scene_set_dialect(self._h, 1), "rt_scene_set_dialect")
+            world = world.child
         self._add(world)
         for l in lights:
             if isinstance(l, PointLight):
@@ -418,6 +460,15 @@ def parallelTrace(w, h, camera: Camera, tracer: Tracer):
     if (camera.width, camera.height) != (w, h):
         raise ValueError("parallelTrace: camera and image size differ")
     rgba, _ = tracer.scene().render(w, h, depth=tracer.depth, want_hit=False)
+    return rgba[:, :, :3].copy()
+
+
+def traceAndShade(world, camera: Camera, lights):        # Talk.hs:255-258
+    return Tracer(1, lights, world if isinstance(world, TalkDialect) else TalkDialect(world))
+
+
+def parallel(w, h, tracer: Tracer):             # Talk.hs:171-182
+    rgba, _ = tracer.scene().render(w, h, depth=1, want_hit=False)
     return rgba[:, :, :3].copy()
 
 

@@ -97,6 +97,7 @@ struct RenderParams {
     long long out_off;              // index of the chunk's first pixel inside the band-local outputs
     int qcap;                       // pixels in the chunk = capacity of one shadow queue
     int spp, sample;
+    int talk;                       // 1: the rules of src/Talk.hs (rt_scene_set_dialect)
     uint32_t seed_lo, seed_hi;
     int tiles_x, tiles_y;
 };
@@ -146,6 +147,10 @@ __device__ __forceinline__ RayD camera_ray(const RenderParams &P, int x, int y) 
     const double posX = P.cam.scaleX * ((double)x + ox) + P.cam.dX;
     const double posY = P.cam.scaleY * ((double)y + oy) + P.cam.dY;
     const double n = sqrt(posX * posX + posY * posY + P.cam.d * P.cam.d);
+    if (P.talk) {                                   // Talk.hs:66-67, 152: scalar (recip (norm v)) v
+        const double rn = 1.0 / n;
+        return mkray(posX, posY, 0.0, rn * posX, rn * posY, rn * P.cam.d, P.eps);
+    }
     return mkray(posX, posY, 0.0, posX / n, posY / n, P.cam.d / n, P.eps);
 }
 
@@ -167,7 +172,7 @@ __device__ __forceinline__ RayD slot_ray(const RenderParams &P, int slot) {
 // planeRayIsect + the inside test of rectangle (Main.hs:234-242) / triangle (Main.hs:374-383).
 // KIND is the leaf type; L is wave-uniform in the filter loops (scalar loads).
 template <int KIND>
-__device__ __forceinline__ bool leaf_isect(const LeafD &L, const RayD &r, double &ix, double &iy, double &iz, double &t) {
+__device__ __forceinline__ bool leaf_isect(const LeafD &L, const RayD &r, double &ix, double &iy, double &iz, double &t, bool talk) {
     if (KIND == LEAF_SPHERE) {                                                         // sphere, Main.hs:395-411
         const double ox = r.px - L.p0x, oy = r.py - L.p0y, oz = r.pz - L.p0z;          // :396
         const double sb = 2 * (r.dx * ox + r.dy * oy + r.dz * oz);                     // :398
@@ -192,8 +197,14 @@ __device__ __forceinline__ bool leaf_isect(const LeafD &L, const RayD &r, double
     const double x = (r.dx * (z - r.pz) / r.dz) + r.px;                                // :271
     const double y = (r.dy * (z - r.pz) / r.dz) + r.py;                                // :272
     if (fabs(frac) <= 0.00001) return false;                                           // :273
-    t = (z - r.pz) * r.rz;                                                             // :256, 122-126
-    if (!(t >= 0)) return false;                                                       // :257
+    if (talk) {                       // Talk.hs:121-122: ray_direction *@ (i - ray_position) >= 0; key = squared distance, :192-193
+        const double vx = x - r.px, vy = y - r.py, vz = z - r.pz;
+        if (!(r.dx * vx + r.dy * vy + r.dz * vz >= 0)) return false;
+        t = vx * vx + vy * vy + vz * vz;
+    } else {
+        t = (z - r.pz) * r.rz;                                                         // :256, 122-126
+        if (!(t >= 0)) return false;                                                   // :257
+    }
     ix = x; iy = y; iz = z;
     const double wx = x - L.p0x, wy = y - L.p0y, wz = z - L.p0z;
     if (KIND == LEAF_RECT) {
@@ -370,7 +381,7 @@ __device__ __forceinline__ void primary_loop(const RenderParams &P, CRecPtr recs
                     const RayD ray = camera_ray(P, xr, y);
                     double ix, iy, iz, t;
                     ++nexact;
-                    if (leaf_isect<KIND>(L, ray, ix, iy, iz, t) && guards_ok(P.guards, L.guard, ray)) {
+                    if (leaf_isect<KIND>(L, ray, ix, iy, iz, t, P.talk) && guards_ok(P.guards, L.guard, ray)) {
                         // nearest wins; equal t -> the left-most leaf of the tree (Main.hs:213-214)
                         if (t < bt[r] || (t == bt[r] && gid < bid[r]) || bid[r] < 0) { bt[r] = t; bid[r] = gid; }
                     }
@@ -421,7 +432,7 @@ __device__ __forceinline__ void primary_sphere_loop(const RenderParams &P, const
                     const RayD ray = camera_ray(P, xr, y);
                     double ix, iy, iz, t;
                     ++nexact;
-                    if (leaf_isect<LEAF_SPHERE>(L, ray, ix, iy, iz, t) && guards_ok(P.guards, L.guard, ray)) {
+                    if (leaf_isect<LEAF_SPHERE>(L, ray, ix, iy, iz, t, P.talk) && guards_ok(P.guards, L.guard, ray)) {
                         if (t < bt[r] || (t == bt[r] && gid < bid[r]) || bid[r] < 0) { bt[r] = t; bid[r] = gid; }
                     }
                 }
@@ -474,9 +485,10 @@ __global__ void RT_HOT(RT_WAVES_EU_PRIMARY) k_primary(const RenderParams P) {
 //   When L.N <= 0 both Phong terms are exactly 0 (Main.hs:480-484), so the shadow ray cannot change
 //   the pixel and is not cast.
 
-__device__ __forceinline__ void to_light(const LightD &Lt, double hx, double hy, double hz, double &tx, double &ty, double &tz) {
+__device__ __forceinline__ void to_light(bool talk, const LightD &Lt, double hx, double hy, double hz, double &tx, double &ty, double &tz) {
     const double lx = Lt.px - hx, ly = Lt.py - hy, lz = Lt.pz - hz;                    // Main.hs:470
     const double ln = sqrt(lx * lx + ly * ly + lz * lz);
+    if (talk) { const double rn = 1.0 / ln; tx = rn * lx; ty = rn * ly; tz = rn * lz; return; }   // Talk.hs:239, 66-67
     tx = lx / ln; ty = ly / ln; tz = lz / ln;
 }
 
@@ -493,9 +505,9 @@ __global__ void __launch_bounds__(RT_SETUP_THREADS) k_setup(const RenderParams P
         const LeafD L = P.leaves[id];
         const RayD ray = slot_ray(P, pix);
         double ix = 0, iy = 0, iz = 0, t;
-        if (L.kind == LEAF_RECT) leaf_isect<LEAF_RECT>(L, ray, ix, iy, iz, t);
-        else if (L.kind == LEAF_TRI) leaf_isect<LEAF_TRI>(L, ray, ix, iy, iz, t);
-        else leaf_isect<LEAF_SPHERE>(L, ray, ix, iy, iz, t);
+        if (L.kind == LEAF_RECT) leaf_isect<LEAF_RECT>(L, ray, ix, iy, iz, t, P.talk);
+        else if (L.kind == LEAF_TRI) leaf_isect<LEAF_TRI>(L, ray, ix, iy, iz, t, P.talk);
+        else leaf_isect<LEAF_SPHERE>(L, ray, ix, iy, iz, t, P.talk);
         double nx = L.nx, ny = L.ny, nz = L.nz;
         if (L.kind == LEAF_SPHERE) {                                                   // scalar (recip radius) (isect - center), :410
             const double rr = 1.0 / L.c0;
@@ -532,7 +544,7 @@ __global__ void __launch_bounds__(RT_SETUP_THREADS) k_setup(const RenderParams P
         bool need = false;
         if (id >= 0) {
             double tx, ty, tz;
-            to_light(Lt, H.px, H.py, H.pz, tx, ty, tz);
+            to_light(P.talk, Lt, H.px, H.py, H.pz, tx, ty, tz);
             const double lndot = tx * H.nx + ty * H.ny + tz * H.nz;                    // Main.hs:476
             need = !(lndot <= 0);
         }
@@ -607,14 +619,16 @@ __device__ __forceinline__ void shadow_loop(const RenderParams &P, CRecPtr recs,
                         asm volatile("" : "+v"(pr));   // keep the exact-path ray set-up inside this rare branch
                         const HitRec H = P.hitrec[pr];
                         double tx, ty, tz;
-                        to_light(Lt, H.px, H.py, H.pz, tx, ty, tz);
+                        to_light(P.talk, Lt, H.px, H.py, H.pz, tx, ty, tz);
                         const RayD ray = mkray(H.px + 0.00001 * tx, H.py + 0.00001 * ty, H.pz + 0.00001 * tz,
                                                tx, ty, tz, P.eps);                     // Main.hs:472
                         double ix, iy, iz, t;
                         ++nexact;
-                        if (leaf_isect<KIND>(L, ray, ix, iy, iz, t) && guards_ok(P.guards, L.guard, ray)) {
+                        if (leaf_isect<KIND>(L, ray, ix, iy, iz, t, P.talk) && guards_ok(P.guards, L.guard, ray)) {
                             const double tl = (Lt.pz - ray.pz) * ray.rz;               // rayDistance ray lpos
-                            if (t <= tl) need[r] = false;                              // Main.hs:474 -> black
+                            const bool occ = P.talk ? ((Lt.px - ix) * tx + (Lt.py - iy) * ty + (Lt.pz - iz) * tz >= 0)   // Talk.hs:242
+                                                    : (t <= tl);                        // Main.hs:474
+                            if (occ) need[r] = false;                                  // -> black
                         }
                     }
                 }
@@ -655,11 +669,11 @@ __device__ __forceinline__ void shadow_sphere_loop(const RenderParams &P, CRecPt
                     asm volatile("" : "+v"(pr));
                     const HitRec H = P.hitrec[pr];
                     double tx, ty, tz;
-                    to_light(Lt, H.px, H.py, H.pz, tx, ty, tz);
+                    to_light(P.talk, Lt, H.px, H.py, H.pz, tx, ty, tz);
                     const RayD ray = mkray(H.px + 0.00001 * tx, H.py + 0.00001 * ty, H.pz + 0.00001 * tz, tx, ty, tz, P.eps);
                     double ix, iy, iz, t;
                     ++nexact;
-                    if (leaf_isect<LEAF_SPHERE>(L, ray, ix, iy, iz, t) && guards_ok(P.guards, L.guard, ray)) {
+                    if (leaf_isect<LEAF_SPHERE>(L, ray, ix, iy, iz, t, P.talk) && guards_ok(P.guards, L.guard, ray)) {
                         const double tl = (Lt.pz - ray.pz) * ray.rz;
                         if (t <= tl) need[r] = false;
                     }
@@ -692,7 +706,7 @@ __global__ void RT_HOT(RT_WAVES_EU_SHADOW) k_shadow(const RenderParams P) {
         if (need[r]) {
             const HitRec H = P.hitrec[pix[r]];
             double tx, ty, tz;
-            to_light(Lt, H.px, H.py, H.pz, tx, ty, tz);
+            to_light(P.talk, Lt, H.px, H.py, H.pz, tx, ty, tz);
             ddx[r] = (float)((H.px + 0.00001 * tx) - Lt.px);
             ddy[r] = (float)((H.py + 0.00001 * ty) - Lt.py);
             ddz[r] = (float)((H.pz + 0.00001 * tz) - Lt.pz);
@@ -920,7 +934,7 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_shadow_mfma(const RenderParams P) {
             pix = q[j];
             const HitRec H = P.hitrec[pix];
             double tx, ty, tz;
-            to_light(Lt, H.px, H.py, H.pz, tx, ty, tz);
+            to_light(P.talk, Lt, H.px, H.py, H.pz, tx, ty, tz);
             dx = (float)((H.px + 0.00001 * tx) - Lt.px);
             dy = (float)((H.py + 0.00001 * ty) - Lt.py);
             dz = (float)((H.pz + 0.00001 * tz) - Lt.pz);
@@ -961,14 +975,16 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_shadow_mfma(const RenderParams P) {
             const LeafD &L = P.leaves[gid];
             const HitRec H = P.hitrec[s_pix[wv][e]];
             double tx, ty, tz;
-            to_light(Lt, H.px, H.py, H.pz, tx, ty, tz);
+            to_light(P.talk, Lt, H.px, H.py, H.pz, tx, ty, tz);
             const RayD ray = mkray(H.px + 0.00001 * tx, H.py + 0.00001 * ty, H.pz + 0.00001 * tz, tx, ty, tz, P.eps);   // Main.hs:472
             double ix, iy, iz, tt;
             ++nexact;
-            const bool hit = kind == LEAF_TRI ? leaf_isect<LEAF_TRI>(L, ray, ix, iy, iz, tt) : leaf_isect<LEAF_RECT>(L, ray, ix, iy, iz, tt);
+            const bool hit = kind == LEAF_TRI ? leaf_isect<LEAF_TRI>(L, ray, ix, iy, iz, tt, P.talk) : leaf_isect<LEAF_RECT>(L, ray, ix, iy, iz, tt, P.talk);
             if (hit && guards_ok(P.guards, L.guard, ray)) {
                 const double tl = (Lt.pz - ray.pz) * ray.rz;                       // rayDistance ray lpos
-                if (tt <= tl) s_occ[wv][e] = 1u;                                   // Main.hs:474 -> black
+                const bool occ = P.talk ? ((Lt.px - ix) * tx + (Lt.py - iy) * ty + (Lt.pz - iz) * tz >= 0)   // Talk.hs:242
+                                        : (tt <= tl);                               // Main.hs:474
+                if (occ) s_occ[wv][e] = 1u;                                        // -> black
             }
         });
     __builtin_amdgcn_wave_barrier();
@@ -1051,7 +1067,7 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_primary_mfma(const RenderParams P) {
             const RayD ray = camera_ray(P, x0 + (e & 31), P.row0 + ly0 + (e >> 5));
             double ix, iy, iz, tt;
             ++nexact;
-            const bool hit = (kind == LEAF_TRI ? leaf_isect<LEAF_TRI>(L, ray, ix, iy, iz, tt) : leaf_isect<LEAF_RECT>(L, ray, ix, iy, iz, tt))
+            const bool hit = (kind == LEAF_TRI ? leaf_isect<LEAF_TRI>(L, ray, ix, iy, iz, tt, P.talk) : leaf_isect<LEAF_RECT>(L, ray, ix, iy, iz, tt, P.talk))
                              && guards_ok(P.guards, L.guard, ray);
             // Nearest wins; equal t -> the left-most leaf of the tree (Main.hs:213-214).  Several lanes may hold hits of
             // the same pixel: the wave runs in lockstep and its LDS operations complete in order, so (1) all read the
@@ -1105,7 +1121,7 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_primary_mfma(const RenderParams P) {
                         const RayD ray = camera_ray(P, x, yr);
                         double ix, iy, iz, tt;
                         ++nexact;
-                        if (leaf_isect<LEAF_SPHERE>(L, ray, ix, iy, iz, tt) && guards_ok(P.guards, L.guard, ray)) {
+                        if (leaf_isect<LEAF_SPHERE>(L, ray, ix, iy, iz, tt, P.talk) && guards_ok(P.guards, L.guard, ray)) {
                             if (tt < mt[r] || (tt == mt[r] && gid < mid[r]) || mid[r] < 0) { mt[r] = tt; mid[r] = gid; }
                         }
                     }
@@ -1153,9 +1169,17 @@ __global__ void __launch_bounds__(256) k_final(const RenderParams P) {
                 cb = min(255, cb + round8(Lt.f * (double)M.diffuse[2]));
                 continue;
             }
-            if ((lit >> pl) & 1u) {                                                    // lit: Main.hs:476-487
+            if (((lit >> pl) & 1u) && P.talk) {                                        // Talk.hs:244-248
                 double tx, ty, tz;
-                to_light(Lt, H.px, H.py, H.pz, tx, ty, tz);
+                to_light(P.talk, Lt, H.px, H.py, H.pz, tx, ty, tz);
+                const double v = hs_max0(tx * H.nx + ty * H.ny + tz * H.nz) * Lt.diffuse;
+                const double f = (1.0 <= v) ? 1.0 : v;                                 // min 1 v
+                cr = min(255, cr + round8(f * (double)M.diffuse[0]));
+                cg = min(255, cg + round8(f * (double)M.diffuse[1]));
+                cb = min(255, cb + round8(f * (double)M.diffuse[2]));
+            } else if ((lit >> pl) & 1u) {                                             // lit: Main.hs:476-487
+                double tx, ty, tz;
+                to_light(P.talk, Lt, H.px, H.py, H.pz, tx, ty, tz);
                 const double lndot = tx * H.nx + ty * H.ny + tz * H.nz;
                 const double k2 = 2 * lndot;
                 const double rx = tx - k2 * H.nx, ry = ty - k2 * H.ny, rz = tz - k2 * H.nz;
@@ -1258,7 +1282,7 @@ __device__ __forceinline__ void general_loop(const RenderParams &P, CGenPtr recs
                     const RayD ray = slot_ray(P, (int)sr);
                     double ix, iy, iz, t;
                     ++nexact;
-                    if (leaf_isect<KIND>(L, ray, ix, iy, iz, t) && guards_ok(P.guards, L.guard, ray)) {
+                    if (leaf_isect<KIND>(L, ray, ix, iy, iz, t, P.talk) && guards_ok(P.guards, L.guard, ray)) {
                         if (t < bt[r] || (t == bt[r] && gid < bid[r]) || bid[r] < 0) { bt[r] = t; bid[r] = gid; }
                     }
                 }
@@ -1294,7 +1318,7 @@ __device__ __forceinline__ void general_sphere_loop(const RenderParams &P, const
                     const RayD ray = slot_ray(P, (int)sr);
                     double ix, iy, iz, t;
                     ++nexact;
-                    if (leaf_isect<LEAF_SPHERE>(L, ray, ix, iy, iz, t) && guards_ok(P.guards, L.guard, ray)) {
+                    if (leaf_isect<LEAF_SPHERE>(L, ray, ix, iy, iz, t, P.talk) && guards_ok(P.guards, L.guard, ray)) {
                         if (t < bt[r] || (t == bt[r] && gid < bid[r]) || bid[r] < 0) { bt[r] = t; bid[r] = gid; }
                     }
                 }
@@ -1517,7 +1541,7 @@ int rt_render_device(rt_scene *s, int w, int h, int depth, int spp, uint64_t see
     if (npix == 0) return RT_OK;
     // bounce levels: trace n reflects at most n - 1 times (trace 0 = black, Main.hs:542); only scenes with a
     // reflective material ever spawn a reflected ray (Main.hs:553)
-    const int levels = (s->reflective && depth > 1) ? (depth < 8 ? depth : 8) : 1;
+    const int levels = (s->reflective && depth > 1 && !s->talk) ? (depth < 8 ? depth : 8) : 1;
     if (s->reflective && depth > 8) { set_error("rt_render: trace depth > 8 with reflective materials is not supported"); return RT_ERR_UNSUPPORTED; }
     // rows per chunk: a multiple of the tile height
     size_t crow = (levels > 1 ? RT_CHUNK_PIXELS / 4 : RT_CHUNK_PIXELS) / (size_t)w;
@@ -1562,6 +1586,7 @@ int rt_render_device(rt_scene *s, int w, int h, int depth, int spp, uint64_t see
     P.ntri = (int)s->tri_gid.size(); P.nrect = (int)s->rect_gid.size();
     P.nlights = (int)s->lights.size(); P.nleaves = (int)s->leaves.size(); P.npoint = s->npoint;
     P.w = w; P.h = h;
+    P.talk = s->talk ? 1 : 0;
     P.spp = spp; P.seed_lo = (uint32_t)seed; P.seed_hi = (uint32_t)(seed >> 32);
 
     if ((rc = next_event(*s, st, 0))) return rc;

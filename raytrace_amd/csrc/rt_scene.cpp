@@ -96,7 +96,12 @@ static int add_rect(rt_scene &s, const rt_material &m, D3 point, D3 width, D3 he
     LeafD L{};
     L.kind = LEAF_RECT;
     L.mat = add_material(s, m);
-    const D3 normal = unit(cross3(width, height));
+    D3 normal = unit(cross3(width, height));                                          // Main.hs:228
+    if (s.talk) {                                                                     // Talk.hs:66-67, 114: scalar (recip (norm v)) v
+        const D3 c = cross3(width, height);
+        const double rn = 1.0 / std::sqrt(dot3(c, c));
+        normal = D3{rn * c.x, rn * c.y, rn * c.z};
+    }
     const D3 corner = (point - scale(0.5, width)) - scale(0.5, height);
     L.nx = normal.x; L.ny = normal.y; L.nz = normal.z;
     L.d = -(dot3(point, normal));
@@ -469,6 +474,10 @@ static void assign_guards(rt_scene &s, int id, int parent) {
 bool compute_guards(rt_scene &s) {
     if (!s.open.empty()) { set_error("rt_render: an rt_begin_mconcat/rt_begin_mappend bracket is still open"); return false; }
     s.guards.clear();
+    if (s.talk) {                                         // Talk.hs:185-194: the monoid has no bounding boxes
+        for (LeafD &L : s.leaves) L.guard = -1;
+        return true;
+    }
     if (s.top.empty()) return true;
     if (s.top.size() == 1) { assign_guards(s, s.top[0], -1); return true; }
     s.nodes.push_back(GNode{1, -1, s.top});                // implicit top-level mconcat
@@ -628,6 +637,16 @@ int rt_scene_create(rt_scene **out) {
     return RT_OK;
 }
 
+// Talk.hs dialect (before the first shape).  Talk.hs has rectangles (and `cube`, six of them) only.
+int rt_scene_set_dialect(rt_scene *s, int dialect) {
+    if (!s || (dialect != RT_DIALECT_MAIN && dialect != RT_DIALECT_TALK)) { set_error("rt_scene_set_dialect: bad argument"); return RT_ERR_ARG; }
+    if (!s->leaves.empty() || !s->nodes.empty()) { set_error("rt_scene_set_dialect: must be called before the first shape"); return RT_ERR_ARG; }
+    s->talk = dialect == RT_DIALECT_TALK;
+    s->dirty = true;
+    return RT_OK;
+}
+#define RT_TALK_ONLY_RECT(s, what) do { if ((s)->talk) { set_error(what ": the Talk.hs dialect has rectangles only"); return RT_ERR_UNSUPPORTED; } } while (0)
+
 int rt_add_rectangle(rt_scene *s, const rt_material *m, const double point[3],
                      const double width[3], const double height[3]) {
     if (!s || !m || !point || !width || !height) { set_error("rt_add_rectangle: NULL argument"); return RT_ERR_ARG; }
@@ -637,11 +656,13 @@ int rt_add_rectangle(rt_scene *s, const rt_material *m, const double point[3],
 int rt_add_triangle(rt_scene *s, const rt_material *m, const double pa[3], const double pb[3],
                     const double pc[3]) {
     if (!s || !m || !pa || !pb || !pc) { set_error("rt_add_triangle: NULL argument"); return RT_ERR_ARG; }
+    RT_TALK_ONLY_RECT(s, "rt_add_triangle");
     return add_tri(*s, *m, from(pa), from(pb), from(pc));
 }
 
 int rt_add_sphere(rt_scene *s, const rt_material *m, const double center[3], double radius) {
     if (!s || !m || !center) { set_error("rt_add_sphere: NULL argument"); return RT_ERR_ARG; }
+    RT_TALK_ONLY_RECT(s, "rt_add_sphere");
     return add_sphere(*s, *m, from(center), radius);
 }
 
@@ -651,6 +672,7 @@ int rt_add_cuboid(rt_scene *s, const rt_material *mats, int nmats, const double 
                   double l, double h, double d) {
     if (!s || !mats || !point) { set_error("rt_add_cuboid: NULL argument"); return RT_ERR_ARG; }
     if (nmats <= 0) { set_error("colorcuboid: list of materials must not be empty."); return RT_ERR_ARG; } // :302
+    RT_TALK_ONLY_RECT(s, "rt_add_cuboid");      // Talk.hs's cube has other faces (Talk.hs:197-218): build it from rectangles
     const D3 p = from(point);
     const double l2 = l / 2, h2 = h / 2, d2 = d / 2;
     open_group(*s, 1);                                                                // mconcat [...], :308
@@ -671,6 +693,7 @@ int rt_add_cylinder(rt_scene *s, const rt_material *top, const rt_material *bot,
                     const rt_material *mantle, const double point[3], int n, double h, double r) {
     if (!s || !top || !bot || !mantle || !point) { set_error("rt_add_cylinder: NULL argument"); return RT_ERR_ARG; }
     if (n < 1) { set_error("rt_add_cylinder: n must be >= 1"); return RT_ERR_ARG; }
+    RT_TALK_ONLY_RECT(s, "rt_add_cylinder");
     const D3 c = from(point);
     const double nn = (double)n, alpha = 2 * M_PI / nn, h2 = h / 2;
     std::vector<double> rx((size_t)n + 1), rz((size_t)n + 1);

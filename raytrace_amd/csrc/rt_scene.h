@@ -66,11 +66,12 @@ struct rt_scene {
     std::vector<rt::LightD> lights;
     std::vector<int32_t> tri_gid, rect_gid, sph_gid;
     int npoint = 0;                       // number of point lights
+    bool talk = false;                    // the rules of src/Talk.hs (rt_scene_set_dialect)
 
     // filter records, rebuilt when the camera (w, h) or the scene changes
     std::vector<rt::FilterRec> tri_rec, rect_rec, sph_rec;
     std::vector<rt::GenRec> gen_tri, gen_rect, gen_sph;   // only filled when a material reflects
-    std::vector<uint16_t> mf_rows;        // MFMA rows: (1 + npoint) x (mf_groups + 2) blocks of 32 rows x 8 bf16
+    std::vector<uint16_t> mf_rows;        // MFMA rows: (1 + npoint) x (mf_groups + 2) blocks of 32 rows x 8 halves
     std::vector<int32_t> mf_gid;          // MFMA stream position -> leaf index (-1: padding)
     std::vector<rt::FilterRec> mf_rec;    // FP32 records in MFMA stream order, per apex; c[14] = kind, c[15] = leaf index (bits)
     int mf_groups = 0;

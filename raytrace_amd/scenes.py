@@ -103,6 +103,14 @@ def talk_main2():                                    # Talk.hs:263-273 geometry,
     return world, mconcat_lights([ambient(0.1), pointLight(0.3, 0.0, (0, 0, 0)), pointLight(0.6, 0.0, (-1, 3, -3))])
 
 
+def talkhs_main2():                                  # Talk.hs:261-273 with Talk.hs's own rules (TalkDialect)
+    from .api import TalkDialect, talk_cube, talk_pointLight, talk_rectangle
+    world = talk_cube([red, green, blue, white, black], 2.0, (1, -2, -6)) + \
+        talk_rectangle(blue, (0, -5, 0), (20, 0, 0), (0, 0, -50))
+    lights = mconcat_lights([ambient(0.1), talk_pointLight(0.3, (0, 0, 0)), talk_pointLight(0.6, (-1, 3, -3))])
+    return TalkDialect(world), lights
+
+
 def spheres():                                       # Main.hs:670-690
     mirror = black.replace(reflectivity=0.9, specular=(255, 255, 255), specularity=100)
     world = mconcat([
@@ -136,7 +144,7 @@ def mirror_room():
 REFERENCE_SCENES = {
     "default": default_scene, "planes": planes, "axes": axes, "cubes": cubes, "stacked_cubes": stacked_cubes,
     "triangle_example": triangle_example, "spec_test": spec_test, "intersection": intersection,
-    "cylinder_axes": cylinder_axes, "talk_main2": talk_main2, "mirror_room": mirror_room, "spheres": spheres,
+    "cylinder_axes": cylinder_axes, "talk_main2": talk_main2, "talkhs_main2": talkhs_main2, "mirror_room": mirror_room, "spheres": spheres,
 }
 
 

@@ -21,7 +21,7 @@ from raytrace_amd import scenes  # noqa: E402
 
 SIZES = {"default": (96, 96), "planes": (80, 60), "axes": (64, 64), "cubes": (96, 54), "stacked_cubes": (96, 96),
          "triangle_example": (90, 50), "spec_test": (64, 64), "intersection": (96, 96), "cylinder_axes": (80, 64),
-         "talk_main2": (64, 64), "mirror_room": (96, 72), "spheres": (96, 96)}
+         "talk_main2": (64, 64), "talkhs_main2": (96, 96), "mirror_room": (96, 72), "spheres": (96, 96)}
 
 
 def main():

@@ -29,6 +29,7 @@ def lib():
         L = C.CDLL(LIB_PATH)
         L.orc_scene_new.restype = C.c_void_p
         L.orc_scene_free.argtypes = [C.c_void_p]
+        L.orc_scene_set_talk.argtypes = [C.c_void_p, C.c_int]
         L.orc_mempty.argtypes = [C.c_void_p]
         L.orc_mappend.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.orc_mconcat.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_int]
@@ -72,6 +73,9 @@ class OracleScene:
     def __init__(self, world, lights):
         self.L = lib()
         self.h = C.c_void_p(self.L.orc_scene_new())
+        if isinstance(world, api.TalkDialect):        # src/Talk.hs rules
+            assert self.L.orc_scene_set_talk(self.h, 1) == 0
+            world = world.child
         self.root = self._node(world)
         for l in lights:
             if isinstance(l, api.PointLight):

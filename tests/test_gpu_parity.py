@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 SIZES = {"default": (256, 256), "planes": (160, 120), "axes": (200, 200), "cubes": (256, 144),
          "stacked_cubes": (256, 256), "triangle_example": (250, 130), "spec_test": (192, 192),
-         "intersection": (256, 256), "cylinder_axes": (200, 160), "talk_main2": (128, 128), "mirror_room": (256, 192), "spheres": (256, 256)}
+         "intersection": (256, 256), "cylinder_axes": (200, 160), "talk_main2": (128, 128), "talkhs_main2": (512, 512), "mirror_room": (256, 192), "spheres": (256, 256)}
 
 
 def compare(world, lights, w, h, depth=4, label=""):

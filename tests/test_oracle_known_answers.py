@@ -129,3 +129,20 @@ def test_row_bands_and_threads_do_not_change_the_image():
     parts = [s.render(40, 30, row0=r0, nrows=n, nthreads=3) for r0, n in [(0, 7), (7, 13), (20, 10)]]
     assert (np.concatenate([p["rgb"] for p in parts]) == full["rgb"]).all()
     assert (np.concatenate([p["hit_id"] for p in parts]) == full["hit_id"]).all()
+
+
+def test_talk_dialect_main2():
+    """src/Talk.hs main2 (Talk.hs:261-277) under Talk.hs's own rules, 512x512 as in the talk.
+    Known by hand: the centre ray (0,0,-1) has its x and y clamped to eps by mkray (Talk.hs:35), so for the floor
+    (normal (0,1,0)) frac = eps / -1 and planeLineIsect culls it (Talk.hs:106): black, no hit.  Pixel (128, 400) sees
+    only the blue floor (leaf 6: six cube faces come first): red = green = 0, and blue is at least the ambient term
+    round(0.1 * 255) = 26 (round half even of 25.5)."""
+    import oracle_binding as ob
+    from raytrace_amd import scenes
+    world, lights = scenes.talkhs_main2()
+    o = ob.OracleScene(world, lights).render(512, 512)
+    assert o["hit_id"][256, 256] == -1 and (o["rgb"][256, 256] == 0).all()
+    assert o["hit_id"][400, 128] == 6
+    r, g, b = (int(v) for v in o["rgb"][400, 128])
+    assert r == 0 and g == 0 and 26 <= b <= 255
+    assert set(np.unique(o["hit_id"])) <= {-1, 0, 1, 2, 3, 4, 5, 6}
