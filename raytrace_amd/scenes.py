@@ -209,3 +209,41 @@ def synthetic_cylinders(ncyl=200, ncuboid=500, seed=SYNTH_SEED + 1, specularitie
                              [(-6.0, 10.0, -10.0), (6.0, 10.0, -10.0), (-6.0, 10.0, -26.0), (6.0, 10.0, -26.0)]]
                             + [ambient(0.1)])
     return mconcat(shapes), lights
+
+
+def adversarial(seed=7):
+    """Not a reference scene: leaves and lights placed where a conservative filter is most likely to be wrong —
+    a huge floor under the eye, a parallelogram whose edge vectors are not orthogonal (Main.hs:238-241 accepts the
+    dual parallelogram), slivers, tiny far triangles, leaves that cross the viewport plane z = 0 and the eye plane
+    z = 0.5, a zero-area triangle and a zero-width rectangle (NaN normals: never hit), lights just above a leaf,
+    in the plane of a leaf, at a vertex of a leaf and inside a cuboid, a mirror and a sphere.  GPU parity tests
+    compare it with the oracle and the two first-stage filters with each other."""
+    rng = np.random.default_rng(seed)
+    mirror = black.replace(reflectivity=0.7, specular=(255, 255, 255), specularity=50)
+    shapes = [
+        rectangle(orange, (0, -4, -500), (1000, 0, 0), (0, 0, -1000)),                  # huge floor, passes under the eye
+        rectangle(green, (-3, 0, -12), (4, 0, 1), (1.5, 3, 0.5)),                       # non-orthogonal edges
+        rectangle(cyan.replace(specularity=40), (3, 1, -9), (0.02, 0, 0), (0, 4, 0.3)), # sliver rectangle
+        triangle(red, (-6, -3, -20), (6, -2.999, -20), (0, -3.0005, -19.99)),           # sliver triangle
+        triangle(yellow, (-1, -1, 0.3), (1, -1, -3), (0, 2, -1)),                       # crosses z = 0 (the ray origins)
+        triangle(magenta, (-2, 0.5, 2), (2, 0.5, 2), (0, 1.5, -6)),                     # crosses the eye plane z = 0.5
+        triangle(white, (1, 1, -5), (1, 1, -5), (2, 2, -5)),                            # zero area: NaN normal
+        rectangle(white, (0, 0, -6), (0, 0, 0), (0, 1, 0)),                             # zero width: NaN normal
+        rectangle(mirror, (5, 0, -14), (0, 0, 6), (0, 6, 0)),                           # a mirror facing -x ... +x
+        sphere(blue.replace(specularity=80), (-4, -2.5, -11), 1.5),
+        colorcuboid([red, green, blue], (0, -2, -10), 2.0, 2.0, 2.0),                   # holds a light
+        colorcuboid([aquamarine], (2.5, -3.5, -6), 1.0, 1.0, 1.0),
+        triangle(orchid, (-5, 3, -15), (-4, 3, -15), (-4.5, 4, -15)),                   # a light sits at its first vertex
+    ]
+    for _ in range(40):                                                                 # tiny far triangles
+        c = np.array([rng.uniform(-20, 20), rng.uniform(-3, 12), rng.uniform(-90, -40)])
+        a, b = _unit(rng) * 0.02, _unit(rng) * 0.02
+        shapes.append(triangle(COLOURS[int(rng.integers(1, len(COLOURS)))], tuple(map(float, c)), tuple(map(float, c + a)), tuple(map(float, c + b))))
+    lights = mconcat_lights([
+        pointLight(0.4, 0.3, (0.0, -3.999, -8.0)),         # 1e-3 above the floor
+        pointLight(0.3, 0.2, (3.0, -4.0, -5.0)),           # in the plane of the floor
+        pointLight(0.3, 0.2, (0.0, -2.0, -10.0)),          # inside the cuboid
+        pointLight(0.3, 0.4, (-5.0, 3.0, -15.0)),          # at a vertex of the orchid triangle
+        pointLight(0.5, 0.5, (4.0, 9.0, 1.0)),             # behind the viewport plane
+        ambient(0.15)])
+    return mconcat(shapes), lights

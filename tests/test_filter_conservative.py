@@ -257,3 +257,46 @@ def test_light_filter_accepts_every_occluder():
                     checked += 1
     assert checked > 200
     sc.close()
+
+
+def test_cone_rows_random_leaves_and_apexes():
+    """make_cone_row on random geometry: for random triangles and (also non-orthogonal) rectangles seen from random
+    apexes at distances from 1e-3 to 1e3 leaf sizes, every direction from the apex to a point of the accepted polygon
+    (corners, edges and interior) passes the FP16 cone form — also when scaled to any length."""
+    rng = np.random.default_rng(11)
+    L = _lib.lib()
+    checked = always = 0
+    for case in range(250):
+        size = 10.0 ** rng.uniform(-2, 2)
+        c = rng.uniform(-50, 50, 3)
+        e1, e2 = rng.normal(size=3) * size, rng.normal(size=3) * size
+        tri = case % 2 == 0
+        if tri:
+            world = api.triangle(api.red, tuple(c), tuple(c + e1), tuple(c + e2))
+            corners = np.array([c, c + e1, c + e2])
+        else:
+            world = api.rectangle(api.red, tuple(c), tuple(e1), tuple(e2))
+            ww, hh, wh = e1 @ e1, e2 @ e2, e1 @ e2
+            p0 = c - 0.5 * e1 - 0.5 * e2
+            det = ww * hh - wh * wh
+            corners = np.array([p0 + ((s * hh - t * wh) / det) * e1 + ((t * ww - s * wh) / det) * e2
+                                for s, t in ((0, 0), (ww, 0), (ww, hh), (0, hh))])
+        centre = corners.mean(axis=0)
+        apex = centre + rng.normal(size=3) * size * 10.0 ** rng.uniform(-3, 3)
+        sc = api.Scene(world, api.pointLight(0.5, 0.5, tuple(apex)))
+        assert L.rt_scene_prepare_host(sc.handle, 64, 64) >= 0
+        out = (C.c_uint16 * 8)()
+        assert L.rt_scene_get_mfma_row(sc.handle, 1, 0, out) >= 0
+        row = np.frombuffer(out, np.float16).astype(np.float64)
+        sc.close()
+        if not row[:6].any():
+            always += 1
+            assert row[6] > 0          # a constant row must be "always a candidate" for a leaf that can be hit
+            continue
+        wts = rng.dirichlet(np.ones(len(corners)) * 0.3, size=200)          # concentrated near corners and edges
+        pts = np.concatenate([corners, wts @ corners])
+        D = (pts - apex) * (10.0 ** rng.uniform(-3, 3, (len(pts), 1)))
+        f = cone_form(row, D.astype(np.float32))
+        assert (f > 0).all(), f"case {case}: min form {f.min()} ({'triangle' if tri else 'rectangle'})"
+        checked += len(pts)
+    assert checked > 20000 and always < 120

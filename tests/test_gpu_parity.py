@@ -212,7 +212,8 @@ def test_matrix_core_and_valu_filters_agree_full_size(gpu_lib):
     (bounding cones on the matrix cores; per-leaf linear forms on the vector ALU, RT_FILTER=valu), and the exact
     FP64 stage decides — so whole frames must agree bit for bit, hit IDs and colours."""
     from raytrace_amd import _lib
-    cases = [(scenes.synthetic(), 3840, 2160, 1), (scenes.synthetic_cylinders(), 1920, 1080, 4), (scenes.default_scene(), 3840, 2160, 1)]
+    cases = [(scenes.synthetic(), 3840, 2160, 1), (scenes.synthetic_cylinders(), 1920, 1080, 4), (scenes.default_scene(), 3840, 2160, 1),
+             (scenes.adversarial(), 2048, 1536, 1)]
     try:
         for (world, lights), w, h, spp in cases:
             out = {}
@@ -227,3 +228,18 @@ def test_matrix_core_and_valu_filters_agree_full_size(gpu_lib):
     finally:
         os.environ.pop("RT_FILTER", None)
         _lib.check(_lib.lib().rt_init(0), "rt_init")
+
+
+def test_adversarial_scene(gpu_lib):
+    """scenes.adversarial: leaves and lights where a conservative filter is most likely to lose a hit (huge, sliver,
+    tiny, degenerate and non-orthogonal leaves; leaves crossing the viewport and eye planes; lights on, in and inside
+    leaves; a mirror and a sphere).  Whole images against the oracle, also supersampled."""
+    world, lights = scenes.adversarial()
+    compare(world, lights, 640, 480, label="adversarial")
+    compare(world, lights, 333, 517, depth=2, label="adversarial-odd-size")
+    osc = ob.OracleScene(world, lights)
+    sc = api.Scene(world, lights)
+    ref = osc.render(400, 300, spp=4, seed=3)
+    rgba, hit = sc.render(400, 300, spp=4, seed=3)
+    sc.close()
+    assert (hit == ref["hit_id"]).all() and (rgba[:, :, :3] == ref["rgb"]).all()
