@@ -220,23 +220,53 @@ __device__ __forceinline__ bool leaf_isect(const LeafD &L, const RayD &r, double
     }
 }
 
-// intersectBB — Main.hs:152-174 — for every mappend node above the leaf (Main.hs:209)
+// intersectBB — Main.hs:152-174 — for every mappend node above the leaf (Main.hs:209).
+// The reference ORs six face tests; the result does not depend on their order.  A ray that meets a box leaves it
+// through one of the three faces it points at, with t >= 0, so those are tried first, and the remaining tests are
+// skipped once every active lane of the wave has found a face (wave-uniform branches): about two face tests per
+// box instead of six, the same six when in doubt.
+#ifndef RT_GUARD_EARLY
+#define RT_GUARD_EARLY 1
+#endif
+__device__ __forceinline__ bool face_xy(const GuardD &B, double zf, const RayD &r) {       // isectXY
+    const double t = (zf - r.pz) * r.rz;
+    const double a = r.px + t * r.dx, c = r.py + t * r.dy;
+    return t >= 0 && B.x0 <= a && a <= B.x1 && B.y0 <= c && c <= B.y1;
+}
+__device__ __forceinline__ bool face_xz(const GuardD &B, double yf, const RayD &r) {       // isectXZ
+    const double t = (yf - r.py) * r.ry;
+    const double a = r.px + t * r.dx, c = r.pz + t * r.dz;
+    return t >= 0 && B.x0 <= a && a <= B.x1 && B.z0 <= c && c <= B.z1;
+}
+__device__ __forceinline__ bool face_yz(const GuardD &B, double xf, const RayD &r) {       // isectYZ
+    const double t = (xf - r.px) * r.rx;
+    const double a = r.py + t * r.dy, c = r.pz + t * r.dz;
+    return t >= 0 && B.y0 <= a && a <= B.y1 && B.z0 <= c && c <= B.z1;
+}
 __device__ __forceinline__ bool guards_ok(const GuardD *__restrict__ G, int g, const RayD &r) {
+    // the faces the ray points at: it leaves the box through one of these three
+    const bool nz = r.dz < 0, ny = r.dy < 0, nx = r.dx < 0;
+    (void)nz; (void)ny; (void)nx;
     while (g >= 0) {
         const GuardD B = G[g];
-        bool any = false;
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            double t = ((k ? B.z1 : B.z0) - r.pz) * r.rz;
-            double a = r.px + t * r.dx, c = r.py + t * r.dy;
-            any |= t >= 0 && B.x0 <= a && a <= B.x1 && B.y0 <= c && c <= B.y1;          // isectXY
-            t = ((k ? B.y1 : B.y0) - r.py) * r.ry;
-            a = r.px + t * r.dx; c = r.pz + t * r.dz;
-            any |= t >= 0 && B.x0 <= a && a <= B.x1 && B.z0 <= c && c <= B.z1;          // isectXZ
-            t = ((k ? B.x1 : B.x0) - r.px) * r.rx;
-            a = r.py + t * r.dy; c = r.pz + t * r.dz;
-            any |= t >= 0 && B.y0 <= a && a <= B.y1 && B.z0 <= c && c <= B.z1;          // isectYZ
+#if RT_GUARD_EARLY
+        bool any = face_xy(B, nz ? B.z0 : B.z1, r);
+        if (__builtin_amdgcn_ballot_w64(!any)) {
+            any |= face_xz(B, ny ? B.y0 : B.y1, r);
+            if (__builtin_amdgcn_ballot_w64(!any)) {
+                any |= face_yz(B, nx ? B.x0 : B.x1, r);
+                if (__builtin_amdgcn_ballot_w64(!any)) {
+                    any |= face_xy(B, nz ? B.z1 : B.z0, r);
+                    any |= face_xz(B, ny ? B.y1 : B.y0, r);
+                    any |= face_yz(B, nx ? B.x1 : B.x0, r);
+                }
+            }
         }
+#else
+        bool any = false;
+        any |= face_xy(B, B.z0, r); any |= face_xz(B, B.y0, r); any |= face_yz(B, B.x0, r);
+        any |= face_xy(B, B.z1, r); any |= face_xz(B, B.y1, r); any |= face_yz(B, B.x1, r);
+#endif
         if (!any) return false;
         g = B.parent;
     }
