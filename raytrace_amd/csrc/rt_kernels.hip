@@ -243,14 +243,16 @@ __device__ __forceinline__ bool face_yz(const GuardD &B, double xf, const RayD &
     const double a = r.py + t * r.dy, c = r.pz + t * r.dz;
     return t >= 0 && B.y0 <= a && a <= B.y1 && B.z0 <= c && c <= B.z1;
 }
+template <bool EARLY = (RT_GUARD_EARLY != 0)>
 __device__ __forceinline__ bool guards_ok(const GuardD *__restrict__ G, int g, const RayD &r) {
     // the faces the ray points at: it leaves the box through one of these three
     const bool nz = r.dz < 0, ny = r.dy < 0, nx = r.dx < 0;
     (void)nz; (void)ny; (void)nx;
     while (g >= 0) {
         const GuardD B = G[g];
-#if RT_GUARD_EARLY
-        bool any = face_xy(B, nz ? B.z0 : B.z1, r);
+        bool any;
+        if (EARLY) {
+        any = face_xy(B, nz ? B.z0 : B.z1, r);
         if (__builtin_amdgcn_ballot_w64(!any)) {
             any |= face_xz(B, ny ? B.y0 : B.y1, r);
             if (__builtin_amdgcn_ballot_w64(!any)) {
@@ -262,11 +264,10 @@ __device__ __forceinline__ bool guards_ok(const GuardD *__restrict__ G, int g, c
                 }
             }
         }
-#else
-        bool any = false;
-        any |= face_xy(B, B.z0, r); any |= face_xz(B, B.y0, r); any |= face_yz(B, B.x0, r);
-        any |= face_xy(B, B.z1, r); any |= face_xz(B, B.y1, r); any |= face_yz(B, B.x1, r);
-#endif
+        } else {
+            any = face_xy(B, B.z0, r); any |= face_xz(B, B.y0, r); any |= face_yz(B, B.x0, r);
+            any |= face_xy(B, B.z1, r); any |= face_xz(B, B.y1, r); any |= face_yz(B, B.x1, r);
+        }
         if (!any) return false;
         g = B.parent;
     }
@@ -411,7 +412,7 @@ __device__ __forceinline__ void primary_loop(const RenderParams &P, CRecPtr recs
                     const RayD ray = camera_ray(P, xr, y);
                     double ix, iy, iz, t;
                     ++nexact;
-                    if (leaf_isect<KIND>(L, ray, ix, iy, iz, t, P.talk) && guards_ok(P.guards, L.guard, ray)) {
+                    if (leaf_isect<KIND>(L, ray, ix, iy, iz, t, P.talk) && guards_ok<false>(P.guards, L.guard, ray)) {
                         // nearest wins; equal t -> the left-most leaf of the tree (Main.hs:213-214)
                         if (t < bt[r] || (t == bt[r] && gid < bid[r]) || bid[r] < 0) { bt[r] = t; bid[r] = gid; }
                     }
@@ -462,7 +463,7 @@ __device__ __forceinline__ void primary_sphere_loop(const RenderParams &P, const
                     const RayD ray = camera_ray(P, xr, y);
                     double ix, iy, iz, t;
                     ++nexact;
-                    if (leaf_isect<LEAF_SPHERE>(L, ray, ix, iy, iz, t, P.talk) && guards_ok(P.guards, L.guard, ray)) {
+                    if (leaf_isect<LEAF_SPHERE>(L, ray, ix, iy, iz, t, P.talk) && guards_ok<false>(P.guards, L.guard, ray)) {
                         if (t < bt[r] || (t == bt[r] && gid < bid[r]) || bid[r] < 0) { bt[r] = t; bid[r] = gid; }
                     }
                 }
@@ -654,7 +655,7 @@ __device__ __forceinline__ void shadow_loop(const RenderParams &P, CRecPtr recs,
                                                tx, ty, tz, P.eps);                     // Main.hs:472
                         double ix, iy, iz, t;
                         ++nexact;
-                        if (leaf_isect<KIND>(L, ray, ix, iy, iz, t, P.talk) && guards_ok(P.guards, L.guard, ray)) {
+                        if (leaf_isect<KIND>(L, ray, ix, iy, iz, t, P.talk) && guards_ok<false>(P.guards, L.guard, ray)) {
                             const double tl = (Lt.pz - ray.pz) * ray.rz;               // rayDistance ray lpos
                             const bool occ = P.talk ? ((Lt.px - ix) * tx + (Lt.py - iy) * ty + (Lt.pz - iz) * tz >= 0)   // Talk.hs:242
                                                     : (t <= tl);                        // Main.hs:474
@@ -703,7 +704,7 @@ __device__ __forceinline__ void shadow_sphere_loop(const RenderParams &P, CRecPt
                     const RayD ray = mkray(H.px + 0.00001 * tx, H.py + 0.00001 * ty, H.pz + 0.00001 * tz, tx, ty, tz, P.eps);
                     double ix, iy, iz, t;
                     ++nexact;
-                    if (leaf_isect<LEAF_SPHERE>(L, ray, ix, iy, iz, t, P.talk) && guards_ok(P.guards, L.guard, ray)) {
+                    if (leaf_isect<LEAF_SPHERE>(L, ray, ix, iy, iz, t, P.talk) && guards_ok<false>(P.guards, L.guard, ray)) {
                         const double tl = (Lt.pz - ray.pz) * ray.rz;
                         if (t <= tl) need[r] = false;
                     }
