@@ -243,3 +243,21 @@ def test_adversarial_scene(gpu_lib):
     rgba, hit = sc.render(400, 300, spp=4, seed=3)
     sc.close()
     assert (hit == ref["hit_id"]).all() and (rgba[:, :, :3] == ref["rgb"]).all()
+
+
+def test_16k_image_row_bands_against_oracle(gpu_lib):
+    """configs[3]: the synthetic scene at 16384 x 16384, the size that is split into row bands across GPUs.  Bands of
+    the image (not the whole 1 GB frame) are rendered exactly as a rank would render them and single rows are checked
+    against the oracle; overlapping bands must agree where they overlap."""
+    world, lights = scenes.synthetic()
+    w = h = 16384
+    sc = api.Scene(world, lights)
+    a_rgba, a_hit = sc.render(w, h, row0=8000, nrows=200)
+    b_rgba, b_hit = sc.render(w, h, row0=8100, nrows=61)            # ragged band: 61 rows is no multiple of the tile height
+    sc.close()
+    assert (a_hit[100:161] == b_hit).all() and (a_rgba[100:161] == b_rgba).all()
+    osc = ob.OracleScene(world, lights)
+    for r0 in (8000, 8160):
+        ref = osc.render(w, h, row0=r0, nrows=1, nthreads=16)
+        assert (a_hit[r0 - 8000] == ref["hit_id"][0]).all(), f"row {r0}"
+        assert (a_rgba[r0 - 8000, :, :3] == ref["rgb"][0]).all(), f"row {r0}"
