@@ -130,7 +130,7 @@ int  rt_scene_prepare_host(rt_scene *, int w, int h);
  * rt_scene_prepare_host: out[0..15] as laid out in raytrace_amd/csrc/rt_types.h (FilterRec). */
 int  rt_scene_get_filter_record(const rt_scene *, int apex, int leaf, float out[16]);
 /* First-stage row of `leaf` (matrix-core kernels) for apex 0 / 1 + k, after rt_scene_prepare_host: 8 IEEE halves
- * = 2^7 (a_x, a_y, a_z, margin - cos theta) of the leaf's bounding cone as hi/mid pairs (rt_types.h).  Returns
+ * = 2^10 (a_x, a_y, a_z, margin - cos theta) of the leaf's bounding cone as hi/mid pairs (rt_types.h).  Returns
  * the leaf's position in the stream. */
 int  rt_scene_get_mfma_row(const rt_scene *, int apex, int leaf, uint16_t out[8]);
 /* Guard chain of `leaf`: writes up to cap boxes {x0,y0,z0,x1,y1,z1}, innermost first; returns the count. */

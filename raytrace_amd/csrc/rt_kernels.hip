@@ -769,7 +769,7 @@ __global__ void RT_HOT(RT_WAVES_EU_SHADOW) k_shadow(const RenderParams P) {
 // First stage: every ray against the bounding cone of every planar leaf, ONE linear form per pair,
 //     a . D^ - cos(theta) + margin > 0        (rt_scene.cpp: make_cone_row),
 // which is a matrix product (leaves x 4) x (4 x rays) and runs on v_mfma_f32_32x32x16_f16: the A operand is a block
-// of 32 leaves (rows = 2^7 (a, margin - cos theta) as FP16 hi + mid pairs), the B operand is 32 rays (2^7 (D^, 1)
+// of 32 leaves (rows = 2^10 (a, margin - cos theta) as FP16 hi + mid pairs), the B operand is 32 rays (2^10 (D^, 1)
 // split the same way: lanes 0-31 hold the hi parts, lanes 32-63 the mid parts), and the K = 16 products of a row and
 // a column are exactly (a_hi + a_mid)(D_hi + D_mid) over x, y, z plus the constant.  A lane then owns one ray
 // (column) and 16 leaves (registers): 8 v_max3_f32 per 32 rays x 32 leaves, beside a 32-cycle MFMA.
@@ -780,12 +780,12 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((__vector_size__(16 * sizeof(float)))) float f32x16;
 typedef __attribute__((__vector_size__(4 * sizeof(int)))) int i32x4;
 
-// B fragment of one ray for lane half h: 2^7 D^ = v: h = 0 -> (x_hi, x_hi, y_hi, y_hi, z_hi, z_hi, w, w) with w = 2^7,
+// B fragment of one ray for lane half h: 2^10 D^ = v: h = 0 -> (x_hi, x_hi, y_hi, y_hi, z_hi, z_hi, w, w) with w = 2^10,
 // h = 1 -> the mid parts and w = 0.  An inactive ray is all zero: every form is then 0, which is not > 0.
 __device__ __forceinline__ f16x8 ray_fragment(float x, float y, float z, bool active, int h) {
-    const float s = 128.f * __builtin_amdgcn_rsqf(__builtin_fmaf(x, x, __builtin_fmaf(y, y, z * z)));
+    const float s = 1024.f * __builtin_amdgcn_rsqf(__builtin_fmaf(x, x, __builtin_fmaf(y, y, z * z)));
     const float vx = x * s, vy = y * s, vz = z * s;
-    _Float16 hx = (_Float16)vx, hy = (_Float16)vy, hz = (_Float16)vz, hw = (_Float16)128.f;
+    _Float16 hx = (_Float16)vx, hy = (_Float16)vy, hz = (_Float16)vz, hw = (_Float16)1024.f;
     if (h) {
         hx = (_Float16)(vx - (float)hx);
         hy = (_Float16)(vy - (float)hy);

@@ -307,10 +307,12 @@ static FilterRec make_rec(const LeafD &L, const double A[3], const double dmax[3
 // spherical polygon.  If it lies inside a cap  { u : a.u >= cos(theta) }  around a unit axis a (theta < 90 deg:
 // the angular distance to a is then largest at a vertex), a ray  A + u D (u > 0)  can only meet the leaf if
 //     a . D^ - cos(theta) >= 0          with D^ = D / |D|.
-// The kernels normalise D in FP32 and split 2^7 D^ into FP16 hi + mid (hi = fp16(v), mid = fp16(v - hi): 22
-// significant bits; the factor 2^7 keeps every mid part a normal number, whether or not the matrix core flushes
-// FP16 denormals); a row holds 2^7 (a_x, a_y, a_z, M - cos(theta)) split the same way, and the 16 products of one
-// row x column are exactly (a_hi + a_mid)(D_hi + D_mid) over x, y, z plus the constant times w = 2^7.
+// The kernels normalise D in FP32 and split 2^10 D^ into FP16 hi + mid (hi = fp16(v), mid = fp16(v - hi): 22
+// significant bits).  The factor 2^10 is there in case the matrix core flushes FP16 denormals: a mid part below
+// 2^-14 belongs to a component below 2^-3, i.e. |D^_i| < 2^-13, and losing it costs at most 2^-11 2^-3 2^10 = 2^-4
+// of 2^20 per product: 2^-24 in unscaled units.  A row holds 2^10 (a_x, a_y, a_z, M - cos(theta)) split the same
+// way, and the 16 products of one row x column are exactly (a_hi + a_mid)(D_hi + D_mid) over x, y, z plus the
+// constant times w = 2^10 (|values| <= 2^10 << 65504; products are exact in FP32, sums stay below 2^22).
 // Error budget (unscaled units, |a| = 1, |D^| <= 1 + 2^-22): splits 2 * 2^-22, constant 2^-22, D^ 2^-21,
 // FP32 accumulation of 16 products of magnitude <= 2: 2^-19.  The margin M = 2^-17 is more than 4 times their sum.
 // The exact shape (the FP32 record of the leaf, then the FP64 evaluation) is tested on the candidates only.
@@ -343,13 +345,13 @@ static inline float f16_val(uint16_t hbits) {
     std::memcpy(&f, &u, 4);
     return f;
 }
-static void split_f16(double v, uint16_t &hi, uint16_t &mid) {             // |v| <= 2^8
+static void split_f16(double v, uint16_t &hi, uint16_t &mid) {             // |v| <= 2^11
     hi = f16_rne((float)v);
     mid = f16_rne((float)(v - (double)f16_val(hi)));
 }
-static constexpr double MF_SCALE = 128.0;                                  // 2^7, on both operands
+static constexpr double MF_SCALE = 1024.0;                                 // 2^10, on both operands
 static constexpr double MF_MARGIN = 1.0 / 131072.0;                        // 2^-17
-static void const_row(uint16_t row[8], float w) {                          // form = w * 2^14: never (< 0) or always (> 0) a candidate
+static void const_row(uint16_t row[8], float w) {                          // form = w * 2^20: never (< 0) or always (> 0) a candidate
     for (int j = 0; j < 8; ++j) row[j] = 0;
     row[6] = f16_rne(w * (float)MF_SCALE);
 }

@@ -63,7 +63,7 @@ struct FilterRec { float c[16]; };
 // MFMA stream (v_mfma_f32_32x32x16_f16): blocks of 32 rows x 8 halves (512 bytes), one row per planar leaf in tree
 // order (leaf at stream position k = row k % 32 of block k / 32).  Row r of a block is the A-operand fragment of
 // lanes r and r + 32; the D tile puts row (q & 3) + 8 (q >> 2) + 4 hh into accumulator register q of lane half hh.
-// Row = 2^7 (a_x, a_y, a_z, margin - cos theta) as FP16 hi/mid pairs: the bounding cone of the leaf seen from the
+// Row = 2^10 (a_x, a_y, a_z, margin - cos theta) as FP16 hi/mid pairs: the bounding cone of the leaf seen from the
 // apex (rt_scene.cpp: make_cone_row).
 constexpr int MF_LEAVES = 32;
 

@@ -41,14 +41,14 @@ def cone_rows(sc, apex, w, h):
 
 def cone_form(row, D):
     """ray_fragment + one row x column of v_mfma_f32_32x32x16_f16 (rt_kernels.hip), for float32 directions D[n, 3]:
-    2^7 D^ split into FP16 hi + mid, 16 exact products, summed here in float32 one after the other."""
+    2^10 D^ split into FP16 hi + mid, 16 exact products, summed here in float32 one after the other."""
     D = D.astype(np.float32)
-    s = np.float32(128.0) * (np.float32(1.0) / np.sqrt(fma32(D[:, 0], D[:, 0], fma32(D[:, 1], D[:, 1], D[:, 2] * D[:, 2]))))
+    s = np.float32(1024.0) * (np.float32(1.0) / np.sqrt(fma32(D[:, 0], D[:, 0], fma32(D[:, 1], D[:, 1], D[:, 2] * D[:, 2]))))
     v = (D * s[:, None]).astype(np.float32)
     hi = v.astype(np.float16)
     mid = (v - hi.astype(np.float32)).astype(np.float16)
     acc = np.zeros(len(D), np.float32)
-    for part, wv in ((hi, 128.0), (mid, 0.0)):
+    for part, wv in ((hi, 1024.0), (mid, 0.0)):
         for i in range(3):
             for j in range(2):
                 acc = (acc + (row[2 * i + j] * part[:, i].astype(np.float64)).astype(np.float32)).astype(np.float32)
