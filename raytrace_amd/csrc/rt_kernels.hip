@@ -1700,6 +1700,7 @@ int rt_render(rt_scene *s, int w, int h, int depth, int spp, uint64_t seed, int 
               uint8_t *rgba_out, int32_t *hit_id_out) {
     if (!s) { set_error("rt_render: scene is NULL"); return RT_ERR_ARG; }
     if (w <= 0 || h <= 0 || nrows < 0 || row0 < 0 || row0 + nrows > h) { set_error("rt_render: bad image size or row band"); return RT_ERR_ARG; }
+    if (s->npoint > 32) { set_error("rt_render: more than 32 point lights are not supported yet"); return RT_ERR_UNSUPPORTED; }
     int rc;
     if ((rc = ensure_init())) return rc;
     const size_t npix = (size_t)w * (size_t)nrows;

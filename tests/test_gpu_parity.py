@@ -261,3 +261,12 @@ def test_16k_image_row_bands_against_oracle(gpu_lib):
         ref = osc.render(w, h, row0=r0, nrows=1, nthreads=16)
         assert (a_hit[r0 - 8000] == ref["hit_id"][0]).all(), f"row {r0}"
         assert (a_rgba[r0 - 8000, :, :3] == ref["rgb"][0]).all(), f"row {r0}"
+
+
+def test_32_point_lights(gpu_lib):
+    """The most point lights one render takes (one bit each in the per-pixel lit mask)."""
+    world, _ = scenes.stacked_cubes()
+    rng = np.random.default_rng(5)
+    lights = api.mconcat_lights([api.pointLight(0.06, 0.05, tuple(map(float, rng.uniform((-8, 2, -12), (8, 9, 2))))) for _ in range(32)]
+                                + [api.ambient(0.05)])
+    compare(world, lights, 160, 120, label="32-lights")

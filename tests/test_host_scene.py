@@ -172,3 +172,27 @@ def test_cpp_host_mirror_builds_and_fails_loudly_without_gpu(tmp_path):
         pytest.skip("a GPU is present: the GPU test runs the binary")
     r = subprocess.run([exe, "32", "32", str(tmp_path / "t.bmp")], capture_output=True, text=True)
     assert r.returncode == 1 and "no HIP device" in r.stderr
+
+
+def test_limits_and_dialect_errors():
+    """More than 32 point lights and misuse of the Talk.hs dialect are reported as errors before any device work."""
+    L = _lib.lib()
+    world, _ = scenes.planes()
+    lights = api.mconcat_lights([api.pointLight(0.1, 0.1, (float(k), 5.0, -3.0)) for k in range(33)])
+    sc = api.Scene(world, lights)
+    with pytest.raises(RuntimeError, match="32 point lights"):
+        sc.render(16, 16)
+    sc.close()
+    h = C.c_void_p()
+    assert L.rt_scene_create(C.byref(h)) == 0
+    assert L.rt_scene_set_dialect(h, 7) == -1
+    assert L.rt_scene_set_dialect(h, 1) == 0
+    m = _lib.rt_material()
+    assert L.rt_add_triangle(h, C.byref(m), _lib.vec3((0, 0, -1)), _lib.vec3((1, 0, -1)), _lib.vec3((0, 1, -1))) == -3   # RT_ERR_UNSUPPORTED
+    assert b"rectangles only" in L.rt_last_error()
+    assert L.rt_add_rectangle(h, C.byref(m), _lib.vec3((0, 0, -1)), _lib.vec3((1, 0, 0)), _lib.vec3((0, 1, 0))) == 0
+    assert L.rt_scene_set_dialect(h, 0) == -1 and b"before the first shape" in L.rt_last_error()
+    # Talk.hs:185-194: no bounding boxes -> no guard chain
+    assert L.rt_scene_prepare_host(h, 16, 16) == 0
+    assert L.rt_scene_get_guards(h, 0, None, 0) == 0
+    L.rt_scene_destroy(h)
