@@ -52,6 +52,13 @@ typedef const int32_t RT_CONST *CIntPtr;
 #endif
 #define RT_HOT(n) __attribute__((amdgpu_waves_per_eu(n, 8))) __launch_bounds__(RT_WAVES_PER_BLOCK * 64)
 
+// RT_TALK(P): is the scene in the Talk.hs dialect?  (-DRT_NO_TALK compiles the dialect out: measurement only.)
+#ifdef RT_NO_TALK
+#define RT_TALK(P) false
+#else
+#define RT_TALK(P) ((P).talk != 0)
+#endif
+
 namespace {
 
 struct HitRec;
@@ -141,13 +148,14 @@ __device__ __forceinline__ void sample_offset(const RenderParams &P, int x, int 
 }
 
 // cast camera x y — Main.hs:528-533
+template <bool MAY_TALK = true>
 __device__ __forceinline__ RayD camera_ray(const RenderParams &P, int x, int y) {
     double ox, oy;
     sample_offset(P, x, y, ox, oy);
     const double posX = P.cam.scaleX * ((double)x + ox) + P.cam.dX;
     const double posY = P.cam.scaleY * ((double)y + oy) + P.cam.dY;
     const double n = sqrt(posX * posX + posY * posY + P.cam.d * P.cam.d);
-    if (P.talk) {                                   // Talk.hs:66-67, 152: scalar (recip (norm v)) v
+    if (MAY_TALK && RT_TALK(P)) {                       // Talk.hs:66-67, 152: scalar (recip (norm v)) v
         const double rn = 1.0 / n;
         return mkray(posX, posY, 0.0, rn * posX, rn * posY, rn * P.cam.d, P.eps);
     }
@@ -409,10 +417,10 @@ __device__ __forceinline__ void primary_loop(const RenderParams &P, CRecPtr recs
                 if ((z[r] >= negm) & act[r]) {
                     int xr = x0 + r;
                     asm volatile("" : "+v"(xr));   // keep the exact-path ray set-up inside this rare branch
-                    const RayD ray = camera_ray(P, xr, y);
+                    const RayD ray = camera_ray<false>(P, xr, y);
                     double ix, iy, iz, t;
                     ++nexact;
-                    if (leaf_isect<KIND>(L, ray, ix, iy, iz, t, P.talk) && guards_ok<false>(P.guards, L.guard, ray)) {
+                    if (leaf_isect<KIND>(L, ray, ix, iy, iz, t, false) && guards_ok<false>(P.guards, L.guard, ray)) {
                         // nearest wins; equal t -> the left-most leaf of the tree (Main.hs:213-214)
                         if (t < bt[r] || (t == bt[r] && gid < bid[r]) || bid[r] < 0) { bt[r] = t; bid[r] = gid; }
                     }
@@ -460,10 +468,10 @@ __device__ __forceinline__ void primary_sphere_loop(const RenderParams &P, const
                 if ((z[r] >= cur.c[9]) & act[r]) {
                     int xr = x0 + r;
                     asm volatile("" : "+v"(xr));
-                    const RayD ray = camera_ray(P, xr, y);
+                    const RayD ray = camera_ray<false>(P, xr, y);
                     double ix, iy, iz, t;
                     ++nexact;
-                    if (leaf_isect<LEAF_SPHERE>(L, ray, ix, iy, iz, t, P.talk) && guards_ok<false>(P.guards, L.guard, ray)) {
+                    if (leaf_isect<LEAF_SPHERE>(L, ray, ix, iy, iz, t, false) && guards_ok<false>(P.guards, L.guard, ray)) {
                         if (t < bt[r] || (t == bt[r] && gid < bid[r]) || bid[r] < 0) { bt[r] = t; bid[r] = gid; }
                     }
                 }
@@ -536,9 +544,9 @@ __global__ void __launch_bounds__(RT_SETUP_THREADS) k_setup(const RenderParams P
         const LeafD L = P.leaves[id];
         const RayD ray = slot_ray(P, pix);
         double ix = 0, iy = 0, iz = 0, t;
-        if (L.kind == LEAF_RECT) leaf_isect<LEAF_RECT>(L, ray, ix, iy, iz, t, P.talk);
-        else if (L.kind == LEAF_TRI) leaf_isect<LEAF_TRI>(L, ray, ix, iy, iz, t, P.talk);
-        else leaf_isect<LEAF_SPHERE>(L, ray, ix, iy, iz, t, P.talk);
+        if (L.kind == LEAF_RECT) leaf_isect<LEAF_RECT>(L, ray, ix, iy, iz, t, RT_TALK(P));
+        else if (L.kind == LEAF_TRI) leaf_isect<LEAF_TRI>(L, ray, ix, iy, iz, t, RT_TALK(P));
+        else leaf_isect<LEAF_SPHERE>(L, ray, ix, iy, iz, t, RT_TALK(P));
         double nx = L.nx, ny = L.ny, nz = L.nz;
         if (L.kind == LEAF_SPHERE) {                                                   // scalar (recip radius) (isect - center), :410
             const double rr = 1.0 / L.c0;
@@ -575,7 +583,7 @@ __global__ void __launch_bounds__(RT_SETUP_THREADS) k_setup(const RenderParams P
         bool need = false;
         if (id >= 0) {
             double tx, ty, tz;
-            to_light(P.talk, Lt, H.px, H.py, H.pz, tx, ty, tz);
+            to_light(RT_TALK(P), Lt, H.px, H.py, H.pz, tx, ty, tz);
             const double lndot = tx * H.nx + ty * H.ny + tz * H.nz;                    // Main.hs:476
             need = !(lndot <= 0);
         }
@@ -650,14 +658,14 @@ __device__ __forceinline__ void shadow_loop(const RenderParams &P, CRecPtr recs,
                         asm volatile("" : "+v"(pr));   // keep the exact-path ray set-up inside this rare branch
                         const HitRec H = P.hitrec[pr];
                         double tx, ty, tz;
-                        to_light(P.talk, Lt, H.px, H.py, H.pz, tx, ty, tz);
+                        to_light(false, Lt, H.px, H.py, H.pz, tx, ty, tz);
                         const RayD ray = mkray(H.px + 0.00001 * tx, H.py + 0.00001 * ty, H.pz + 0.00001 * tz,
                                                tx, ty, tz, P.eps);                     // Main.hs:472
                         double ix, iy, iz, t;
                         ++nexact;
-                        if (leaf_isect<KIND>(L, ray, ix, iy, iz, t, P.talk) && guards_ok<false>(P.guards, L.guard, ray)) {
+                        if (leaf_isect<KIND>(L, ray, ix, iy, iz, t, false) && guards_ok<false>(P.guards, L.guard, ray)) {
                             const double tl = (Lt.pz - ray.pz) * ray.rz;               // rayDistance ray lpos
-                            const bool occ = P.talk ? ((Lt.px - ix) * tx + (Lt.py - iy) * ty + (Lt.pz - iz) * tz >= 0)   // Talk.hs:242
+                            const bool occ = false ? ((Lt.px - ix) * tx + (Lt.py - iy) * ty + (Lt.pz - iz) * tz >= 0)   // Talk.hs:242
                                                     : (t <= tl);                        // Main.hs:474
                             if (occ) need[r] = false;                                  // -> black
                         }
@@ -700,11 +708,11 @@ __device__ __forceinline__ void shadow_sphere_loop(const RenderParams &P, CRecPt
                     asm volatile("" : "+v"(pr));
                     const HitRec H = P.hitrec[pr];
                     double tx, ty, tz;
-                    to_light(P.talk, Lt, H.px, H.py, H.pz, tx, ty, tz);
+                    to_light(false, Lt, H.px, H.py, H.pz, tx, ty, tz);
                     const RayD ray = mkray(H.px + 0.00001 * tx, H.py + 0.00001 * ty, H.pz + 0.00001 * tz, tx, ty, tz, P.eps);
                     double ix, iy, iz, t;
                     ++nexact;
-                    if (leaf_isect<LEAF_SPHERE>(L, ray, ix, iy, iz, t, P.talk) && guards_ok<false>(P.guards, L.guard, ray)) {
+                    if (leaf_isect<LEAF_SPHERE>(L, ray, ix, iy, iz, t, false) && guards_ok<false>(P.guards, L.guard, ray)) {
                         const double tl = (Lt.pz - ray.pz) * ray.rz;
                         if (t <= tl) need[r] = false;
                     }
@@ -737,7 +745,7 @@ __global__ void RT_HOT(RT_WAVES_EU_SHADOW) k_shadow(const RenderParams P) {
         if (need[r]) {
             const HitRec H = P.hitrec[pix[r]];
             double tx, ty, tz;
-            to_light(P.talk, Lt, H.px, H.py, H.pz, tx, ty, tz);
+            to_light(false, Lt, H.px, H.py, H.pz, tx, ty, tz);
             ddx[r] = (float)((H.px + 0.00001 * tx) - Lt.px);
             ddy[r] = (float)((H.py + 0.00001 * ty) - Lt.py);
             ddz[r] = (float)((H.pz + 0.00001 * tz) - Lt.pz);
@@ -965,7 +973,7 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_shadow_mfma(const RenderParams P) {
             pix = q[j];
             const HitRec H = P.hitrec[pix];
             double tx, ty, tz;
-            to_light(P.talk, Lt, H.px, H.py, H.pz, tx, ty, tz);
+            to_light(RT_TALK(P), Lt, H.px, H.py, H.pz, tx, ty, tz);
             dx = (float)((H.px + 0.00001 * tx) - Lt.px);
             dy = (float)((H.py + 0.00001 * ty) - Lt.py);
             dz = (float)((H.pz + 0.00001 * tz) - Lt.pz);
@@ -1006,14 +1014,14 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_shadow_mfma(const RenderParams P) {
             const LeafD &L = P.leaves[gid];
             const HitRec H = P.hitrec[s_pix[wv][e]];
             double tx, ty, tz;
-            to_light(P.talk, Lt, H.px, H.py, H.pz, tx, ty, tz);
+            to_light(RT_TALK(P), Lt, H.px, H.py, H.pz, tx, ty, tz);
             const RayD ray = mkray(H.px + 0.00001 * tx, H.py + 0.00001 * ty, H.pz + 0.00001 * tz, tx, ty, tz, P.eps);   // Main.hs:472
             double ix, iy, iz, tt;
             ++nexact;
-            const bool hit = kind == LEAF_TRI ? leaf_isect<LEAF_TRI>(L, ray, ix, iy, iz, tt, P.talk) : leaf_isect<LEAF_RECT>(L, ray, ix, iy, iz, tt, P.talk);
+            const bool hit = kind == LEAF_TRI ? leaf_isect<LEAF_TRI>(L, ray, ix, iy, iz, tt, RT_TALK(P)) : leaf_isect<LEAF_RECT>(L, ray, ix, iy, iz, tt, RT_TALK(P));
             if (hit && guards_ok(P.guards, L.guard, ray)) {
                 const double tl = (Lt.pz - ray.pz) * ray.rz;                       // rayDistance ray lpos
-                const bool occ = P.talk ? ((Lt.px - ix) * tx + (Lt.py - iy) * ty + (Lt.pz - iz) * tz >= 0)   // Talk.hs:242
+                const bool occ = RT_TALK(P) ? ((Lt.px - ix) * tx + (Lt.py - iy) * ty + (Lt.pz - iz) * tz >= 0)   // Talk.hs:242
                                         : (tt <= tl);                               // Main.hs:474
                 if (occ) s_occ[wv][e] = 1u;                                        // -> black
             }
@@ -1098,7 +1106,7 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_primary_mfma(const RenderParams P) {
             const RayD ray = camera_ray(P, x0 + (e & 31), P.row0 + ly0 + (e >> 5));
             double ix, iy, iz, tt;
             ++nexact;
-            const bool hit = (kind == LEAF_TRI ? leaf_isect<LEAF_TRI>(L, ray, ix, iy, iz, tt, P.talk) : leaf_isect<LEAF_RECT>(L, ray, ix, iy, iz, tt, P.talk))
+            const bool hit = (kind == LEAF_TRI ? leaf_isect<LEAF_TRI>(L, ray, ix, iy, iz, tt, RT_TALK(P)) : leaf_isect<LEAF_RECT>(L, ray, ix, iy, iz, tt, RT_TALK(P)))
                              && guards_ok(P.guards, L.guard, ray);
             // Nearest wins; equal t -> the left-most leaf of the tree (Main.hs:213-214).  Several lanes may hold hits of
             // the same pixel: the wave runs in lockstep and its LDS operations complete in order, so (1) all read the
@@ -1152,7 +1160,7 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_primary_mfma(const RenderParams P) {
                         const RayD ray = camera_ray(P, x, yr);
                         double ix, iy, iz, tt;
                         ++nexact;
-                        if (leaf_isect<LEAF_SPHERE>(L, ray, ix, iy, iz, tt, P.talk) && guards_ok(P.guards, L.guard, ray)) {
+                        if (leaf_isect<LEAF_SPHERE>(L, ray, ix, iy, iz, tt, RT_TALK(P)) && guards_ok(P.guards, L.guard, ray)) {
                             if (tt < mt[r] || (tt == mt[r] && gid < mid[r]) || mid[r] < 0) { mt[r] = tt; mid[r] = gid; }
                         }
                     }
@@ -1200,9 +1208,9 @@ __global__ void __launch_bounds__(256) k_final(const RenderParams P) {
                 cb = min(255, cb + round8(Lt.f * (double)M.diffuse[2]));
                 continue;
             }
-            if (((lit >> pl) & 1u) && P.talk) {                                        // Talk.hs:244-248
+            if (((lit >> pl) & 1u) && RT_TALK(P)) {                                        // Talk.hs:244-248
                 double tx, ty, tz;
-                to_light(P.talk, Lt, H.px, H.py, H.pz, tx, ty, tz);
+                to_light(RT_TALK(P), Lt, H.px, H.py, H.pz, tx, ty, tz);
                 const double v = hs_max0(tx * H.nx + ty * H.ny + tz * H.nz) * Lt.diffuse;
                 const double f = (1.0 <= v) ? 1.0 : v;                                 // min 1 v
                 cr = min(255, cr + round8(f * (double)M.diffuse[0]));
@@ -1210,7 +1218,7 @@ __global__ void __launch_bounds__(256) k_final(const RenderParams P) {
                 cb = min(255, cb + round8(f * (double)M.diffuse[2]));
             } else if ((lit >> pl) & 1u) {                                             // lit: Main.hs:476-487
                 double tx, ty, tz;
-                to_light(P.talk, Lt, H.px, H.py, H.pz, tx, ty, tz);
+                to_light(RT_TALK(P), Lt, H.px, H.py, H.pz, tx, ty, tz);
                 const double lndot = tx * H.nx + ty * H.ny + tz * H.nz;
                 const double k2 = 2 * lndot;
                 const double rx = tx - k2 * H.nx, ry = ty - k2 * H.ny, rz = tz - k2 * H.nz;
@@ -1313,7 +1321,7 @@ __device__ __forceinline__ void general_loop(const RenderParams &P, CGenPtr recs
                     const RayD ray = slot_ray(P, (int)sr);
                     double ix, iy, iz, t;
                     ++nexact;
-                    if (leaf_isect<KIND>(L, ray, ix, iy, iz, t, P.talk) && guards_ok(P.guards, L.guard, ray)) {
+                    if (leaf_isect<KIND>(L, ray, ix, iy, iz, t, RT_TALK(P)) && guards_ok(P.guards, L.guard, ray)) {
                         if (t < bt[r] || (t == bt[r] && gid < bid[r]) || bid[r] < 0) { bt[r] = t; bid[r] = gid; }
                     }
                 }
@@ -1349,7 +1357,7 @@ __device__ __forceinline__ void general_sphere_loop(const RenderParams &P, const
                     const RayD ray = slot_ray(P, (int)sr);
                     double ix, iy, iz, t;
                     ++nexact;
-                    if (leaf_isect<LEAF_SPHERE>(L, ray, ix, iy, iz, t, P.talk) && guards_ok(P.guards, L.guard, ray)) {
+                    if (leaf_isect<LEAF_SPHERE>(L, ray, ix, iy, iz, t, RT_TALK(P)) && guards_ok(P.guards, L.guard, ray)) {
                         if (t < bt[r] || (t == bt[r] && gid < bid[r]) || bid[r] < 0) { bt[r] = t; bid[r] = gid; }
                     }
                 }
@@ -1603,6 +1611,8 @@ int rt_render_device(rt_scene *s, int w, int h, int depth, int spp, uint64_t see
     }
     HIP_TRY(hipMemsetAsync(s->dev.counters, 0, 8 * sizeof(unsigned long long), st));
 
+    // the vector-ALU kernels are compiled for Main.hs only: a Talk.hs scene always takes the matrix-core kernels
+    const bool use_mfma = g_use_mfma || s->talk;
     RenderParams P{};
     P.leaves = s->dev.leaves; P.aux = s->dev.aux; P.guards = s->dev.guards; P.mats = s->dev.mats; P.lights = s->dev.lights;
     P.tri_rec = s->dev.tri_rec; P.rect_rec = s->dev.rect_rec;
@@ -1640,7 +1650,7 @@ int rt_render_device(rt_scene *s, int w, int h, int depth, int spp, uint64_t see
             if (depth == 0) {      // trace 0 = black (Main.hs:542): every pixel misses
                 HIP_TRY(hipMemsetAsync(P.hit_id + P.out_off, 0xff, (size_t)P.qcap * sizeof(int32_t), st));
             } else {
-                if (g_use_mfma) hipLaunchKernelGGL(k_primary_mfma, dim3(tblocks), dim3(RT_WAVES_PER_BLOCK * 64), 0, st, P);
+                if (use_mfma) hipLaunchKernelGGL(k_primary_mfma, dim3(tblocks), dim3(RT_WAVES_PER_BLOCK * 64), 0, st, P);
                 else if (spp == 1) hipLaunchKernelGGL(k_primary<true>, dim3(tblocks), dim3(RT_WAVES_PER_BLOCK * 64), 0, st, P);
                 else hipLaunchKernelGGL(k_primary<false>, dim3(tblocks), dim3(RT_WAVES_PER_BLOCK * 64), 0, st, P);
             }
@@ -1667,7 +1677,7 @@ int rt_render_device(rt_scene *s, int w, int h, int depth, int spp, uint64_t see
                 hipLaunchKernelGGL(k_setup, dim3((unsigned)(((size_t)P.qcap + RT_SETUP_THREADS - 1) / RT_SETUP_THREADS)), dim3(RT_SETUP_THREADS), 0, st, P);
                 if ((rc = next_event(*s, st, 2))) return rc;
                 if (s->npoint > 0) {
-                    if (g_use_mfma) hipLaunchKernelGGL(k_shadow_mfma, dim3(sblocks, (unsigned)s->npoint), dim3(RT_WAVES_PER_BLOCK * 64), 0, st, P);
+                    if (use_mfma) hipLaunchKernelGGL(k_shadow_mfma, dim3(sblocks, (unsigned)s->npoint), dim3(RT_WAVES_PER_BLOCK * 64), 0, st, P);
                     else hipLaunchKernelGGL(k_shadow, dim3(sblocks, (unsigned)s->npoint), dim3(RT_WAVES_PER_BLOCK * 64), 0, st, P);
                 }
                 if ((rc = next_event(*s, st, 3))) return rc;
