@@ -531,6 +531,38 @@ __device__ __forceinline__ void to_light(bool talk, const LightD &Lt, double hx,
     tx = lx / ln; ty = ly / ln; tz = lz / ln;
 }
 
+// Haskell `round` (half-even) then fromInteger to Word8 (wraps) — Main.hs:451-456
+__device__ __forceinline__ int round8(double v) {
+    const double r = __builtin_rint(v);
+    if (!(fabs(r) < 9.0e18)) return 0;
+    return (int)((long long)r & 0xff);
+}
+__device__ __forceinline__ double hs_max0(double v) { return 0.0 <= v ? v : 0.0; }    // max 0 v
+
+// What a point light adds to a pixel it reaches: pointLight (Main.hs:476-487) or Talk.hs's pointLight (Talk.hs:244-248).
+// k_final adds it for the lights that reach the pixel; k_setup evaluates the same function first and casts no shadow
+// ray where it is (0, 0, 0) — a black material, a grazing light: the shadow test could not change the pixel.
+__device__ __forceinline__ void light_terms(const RenderParams &P, const LightD &Lt, const MaterialD &M, const HitRec &H,
+                                            const RayD &ray, int &r, int &g, int &b) {
+    double tx, ty, tz;
+    to_light(RT_TALK(P), Lt, H.px, H.py, H.pz, tx, ty, tz);
+    const double lndot = tx * H.nx + ty * H.ny + tz * H.nz;
+    if (RT_TALK(P)) {                                                                  // Talk.hs:244-248
+        const double v = hs_max0(lndot) * Lt.diffuse;
+        const double f = (1.0 <= v) ? 1.0 : v;                                         // min 1 v
+        r = round8(f * (double)M.diffuse[0]); g = round8(f * (double)M.diffuse[1]); b = round8(f * (double)M.diffuse[2]);
+        return;
+    }
+    const double k2 = 2 * lndot;
+    const double rx = tx - k2 * H.nx, ry = ty - k2 * H.ny, rz = tz - k2 * H.nz;
+    const double fDiffuse = Lt.diffuse * hs_max0(lndot);
+    const double fSpecular = (lndot <= 0) ? 0.0
+        : Lt.specular * pow(hs_max0(rx * ray.dx + ry * ray.dy + rz * ray.dz), M.specularity);
+    r = min(255, round8(fDiffuse * (double)M.diffuse[0]) + round8(fSpecular * (double)M.specular[0]));
+    g = min(255, round8(fDiffuse * (double)M.diffuse[1]) + round8(fSpecular * (double)M.specular[1]));
+    b = min(255, round8(fDiffuse * (double)M.diffuse[2]) + round8(fSpecular * (double)M.specular[2]));
+}
+
 #define RT_SETUP_THREADS 1024
 __global__ void __launch_bounds__(RT_SETUP_THREADS) k_setup(const RenderParams P) {
     // shadow jobs of the block per light: per-wave counts, then ONE returning atomic per (block, light)
@@ -540,9 +572,12 @@ __global__ void __launch_bounds__(RT_SETUP_THREADS) k_setup(const RenderParams P
     const bool act = (unsigned)pix < num_slots(P);
     const int id = act ? P.hit_id[P.out_off + pix] : -1;
     HitRec H = {0, 0, 0, 0, 0, 0};
+    RayD ray = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int mat = 0;
     if (id >= 0) {
         const LeafD L = P.leaves[id];
-        const RayD ray = slot_ray(P, pix);
+        ray = slot_ray(P, pix);
+        mat = L.mat;
         double ix = 0, iy = 0, iz = 0, t;
         if (L.kind == LEAF_RECT) leaf_isect<LEAF_RECT>(L, ray, ix, iy, iz, t, RT_TALK(P));
         else if (L.kind == LEAF_TRI) leaf_isect<LEAF_TRI>(L, ray, ix, iy, iz, t, RT_TALK(P));
@@ -585,7 +620,18 @@ __global__ void __launch_bounds__(RT_SETUP_THREADS) k_setup(const RenderParams P
             double tx, ty, tz;
             to_light(RT_TALK(P), Lt, H.px, H.py, H.pz, tx, ty, tz);
             const double lndot = tx * H.nx + ty * H.ny + tz * H.nz;                    // Main.hs:476
-            need = !(lndot <= 0);
+            if (!(lndot <= 0)) {        // ... and only where the light would add something to the pixel (light_terms != 0):
+                const MaterialD M = P.mats[mat];
+                const double fd = RT_TALK(P) ? ((1.0 <= hs_max0(lndot) * Lt.diffuse) ? 1.0 : hs_max0(lndot) * Lt.diffuse)
+                                             : Lt.diffuse * hs_max0(lndot);
+                // the diffuse term decides almost always; the specular term (a pow) is looked at only behind a zero one
+                need = (round8(fd * (double)M.diffuse[0]) | round8(fd * (double)M.diffuse[1]) | round8(fd * (double)M.diffuse[2])) != 0;
+                if (!need && !RT_TALK(P) && (M.specular[0] | M.specular[1] | M.specular[2]) != 0) {
+                    int r, g, b;
+                    light_terms(P, Lt, M, H, ray, r, g, b);
+                    need = (r | g | b) != 0;
+                }
+            }
         }
         if (need) needmask |= 1u << pl;
         const unsigned long long m = __ballot(need);
@@ -1179,14 +1225,6 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_primary_mfma(const RenderParams P) {
 // Kernel 4: `light lights hit ray` (Main.hs:545, 436-441) = pointLight (467-487) + ambient (490-492),
 //   saturating 8-bit sums, coalesced RGBA8 store.
 
-// Haskell `round` (half-even) then fromInteger to Word8 (wraps) — Main.hs:451-456
-__device__ __forceinline__ int round8(double v) {
-    const double r = __builtin_rint(v);
-    if (!(fabs(r) < 9.0e18)) return 0;
-    return (int)((long long)r & 0xff);
-}
-__device__ __forceinline__ double hs_max0(double v) { return 0.0 <= v ? v : 0.0; }    // max 0 v
-
 __global__ void __launch_bounds__(256) k_final(const RenderParams P) {
     const int pix = (int)(blockIdx.x * 256 + threadIdx.x);
     const bool act = (unsigned)pix < num_slots(P);
@@ -1208,26 +1246,10 @@ __global__ void __launch_bounds__(256) k_final(const RenderParams P) {
                 cb = min(255, cb + round8(Lt.f * (double)M.diffuse[2]));
                 continue;
             }
-            if (((lit >> pl) & 1u) && RT_TALK(P)) {                                        // Talk.hs:244-248
-                double tx, ty, tz;
-                to_light(RT_TALK(P), Lt, H.px, H.py, H.pz, tx, ty, tz);
-                const double v = hs_max0(tx * H.nx + ty * H.ny + tz * H.nz) * Lt.diffuse;
-                const double f = (1.0 <= v) ? 1.0 : v;                                 // min 1 v
-                cr = min(255, cr + round8(f * (double)M.diffuse[0]));
-                cg = min(255, cg + round8(f * (double)M.diffuse[1]));
-                cb = min(255, cb + round8(f * (double)M.diffuse[2]));
-            } else if ((lit >> pl) & 1u) {                                             // lit: Main.hs:476-487
-                double tx, ty, tz;
-                to_light(RT_TALK(P), Lt, H.px, H.py, H.pz, tx, ty, tz);
-                const double lndot = tx * H.nx + ty * H.ny + tz * H.nz;
-                const double k2 = 2 * lndot;
-                const double rx = tx - k2 * H.nx, ry = ty - k2 * H.ny, rz = tz - k2 * H.nz;
-                const double fDiffuse = Lt.diffuse * hs_max0(lndot);
-                const double fSpecular = (lndot <= 0) ? 0.0
-                    : Lt.specular * pow(hs_max0(rx * ray.dx + ry * ray.dy + rz * ray.dz), M.specularity);
-                cr = min(255, cr + min(255, round8(fDiffuse * (double)M.diffuse[0]) + round8(fSpecular * (double)M.specular[0])));
-                cg = min(255, cg + min(255, round8(fDiffuse * (double)M.diffuse[1]) + round8(fSpecular * (double)M.specular[1])));
-                cb = min(255, cb + min(255, round8(fDiffuse * (double)M.diffuse[2]) + round8(fSpecular * (double)M.specular[2])));
+            if ((lit >> pl) & 1u) {                                                    // lit: Main.hs:476-487 / Talk.hs:244-248
+                int r, g, b;
+                light_terms(P, Lt, M, H, ray, r, g, b);
+                cr = min(255, cr + r); cg = min(255, cg + g); cb = min(255, cb + b);
             }
             ++pl;
         }
