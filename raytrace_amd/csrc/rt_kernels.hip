@@ -563,7 +563,9 @@ __device__ __forceinline__ void light_terms(const RenderParams &P, const LightD 
     b = min(255, round8(fDiffuse * (double)M.diffuse[2]) + round8(fSpecular * (double)M.specular[2]));
 }
 
-#define RT_SETUP_THREADS 1024
+#ifndef RT_SETUP_THREADS
+#define RT_SETUP_THREADS 512
+#endif
 __global__ void __launch_bounds__(RT_SETUP_THREADS) k_setup(const RenderParams P) {
     // shadow jobs of the block per light: per-wave counts, then ONE returning atomic per (block, light)
     __shared__ unsigned s_cnt[32][RT_SETUP_THREADS / 64];
