@@ -5,18 +5,20 @@
 // light lights (436-492).
 //
 // Design (DESIGN.md has the long form):
-//   * One wavefront (64 lanes) owns a 32 x 8 pixel tile; a lane owns 4 horizontally adjacent
-//     pixels, held as two float2 pairs so the O(rays x leaves) loops run on v_pk_fma_f32 /
-//     v_pk_add_f32 (packed FP32 issues at twice the FLOP rate of v_fma_f32 on gfx950).
-//   * Leaf data in those loops is wave-uniform, so it is read with scalar loads (s_load_dwordx4/8)
-//     and used as SGPR operands: no VGPRs, no LDS bandwidth, no bank conflicts.  Each FP32 test is
-//     a conservative filter (linear forms of the ray direction from a common apex, rt_scene.cpp).
-//   * (ray, leaf) pairs that pass the filter — a handful per ray — are re-evaluated in IEEE double
-//     with the reference's own expression order (planeLineIsect etc.), which decides the hit, the
-//     tie-break (left-most leaf, Main.hs:213-214) and the colour exactly.  The file is compiled with
-//     -ffp-contract=off; the FP32 loops use explicit fma builtins.
-//   * Shadow rays of one light all end at that light, so the same apex filter serves them
-//     (apex = light position, D = shadow-ray origin - light).
+//   * Brute force: every ray is tested against every leaf, through a chain of conservative filters in front of the
+//     exact test.  All rays of a pass leave a common apex (the eye; a light for shadow rays), so a leaf is seen from the
+//     apex under a bounding cone (stage 0, one linear form per pair) and its exact shape is three linear forms of the
+//     ray direction (stage 1, rt_scene.cpp).
+//   * Matrix-core kernels (k_primary_mfma, k_shadow_mfma; the default): stage 0 for 32 leaves x 32 rays is one
+//     v_mfma_f32_32x32x16_f16; survivors go through per-wave LDS queues to stage 1 (FP32) and to the exact stage, 64
+//     entries at a time.
+//   * Vector-ALU kernels (k_primary, k_shadow; RT_FILTER=valu): stage 1 for every pair.  One wavefront owns a 32 x 8
+//     pixel tile, a lane 4 pixels as two float2 pairs (v_pk_fma_f32); leaf records are wave-uniform and are read with
+//     scalar loads into SGPRs: no VGPRs, no LDS bandwidth, no bank conflicts.
+//   * (ray, leaf) pairs that pass the filters — a handful per ray — are evaluated in IEEE double with the reference's
+//     own expression order (planeLineIsect etc.), which decides the hit, the tie-break (left-most leaf,
+//     Main.hs:213-214) and the colour exactly.  The file is compiled with -ffp-contract=off; the FP32 loops use
+//     explicit fma builtins.
 #include <hip/hip_runtime.h>
 
 #include <cmath>

@@ -55,7 +55,8 @@ struct LightD {                // kind 0: pointLight (Main.hs:467), kind 1: ambi
 // 16 floats (one 64-byte line).  c[0..8]: three linear forms of the ray direction D from the apex —
 // triangle U, V, W (= N - U - V); rectangle A, B, N.  c[9] = negm (= -margin): the loops keep c[0..9] in SGPRs.
 // c[10] = Kq, c[11..13] = N xyz (the sign-normalised plane normal: N.D >= Kq  <=>  the plane is met between the
-// apex and A + D): read from memory by the shadow kernel's candidate path only.  c[14..15] spare.
+// apex and A + D): read from memory by the shadow kernel's candidate path only.  c[14..15]: spare in the per-type
+// arrays of the vector-ALU kernels; leaf kind and leaf index (bit patterns) in the stream-ordered copy (mf_rec).
 struct FilterRec { float c[16]; };
 // Sphere, apex form: oc xyz (apex - centre), cs = |oc|^2 - r^2, ..., c[9] = negm: the line A + u D meets the
 // sphere iff (D.oc)^2 - |D|^2 cs >= 0.  Sphere, general form (GenRec): centre xyz, r^2, ..., c[12] = negm.
