@@ -227,13 +227,12 @@ static Forms leaf_forms(const LeafD &L, const double A[3], const double dmax[3])
         q1A = g1[0] * w[0] + g1[1] * w[1] + g1[2] * w[2];
         q2A = g2[0] * w[0] + g2[1] * w[1] + g2[2] * w[2];
     } else {
-        // a' = 2*dw/ww - 1, b' = 2*dh/hh - 1 in [-1, 1] (Main.hs:238-241), measured from the centre
-        const double c[3] = {L.p0x + 0.5 * e1[0] + 0.5 * e2[0], L.p0y + 0.5 * e1[1] + 0.5 * e2[1],
-                             L.p0z + 0.5 * e1[2] + 0.5 * e2[2]};
+        // a' = 2*dw/ww - 1, b' = 2*dh/hh - 1 in [-1, 1] with dV = p - point' (Main.hs:238-241).  Measured from point',
+        // not from the centre: when width and height are not orthogonal, a' is not 0 at the centre.
         for (int i = 0; i < 3; ++i) { g1[i] = 2.0 * e1[i] / L.c0; g2[i] = 2.0 * e2[i] / L.c1; }
-        const double w[3] = {A[0] - c[0], A[1] - c[1], A[2] - c[2]};
-        q1A = g1[0] * w[0] + g1[1] * w[1] + g1[2] * w[2];
-        q2A = g2[0] * w[0] + g2[1] * w[1] + g2[2] * w[2];
+        const double w[3] = {A[0] - L.p0x, A[1] - L.p0y, A[2] - L.p0z};
+        q1A = g1[0] * w[0] + g1[1] * w[1] + g1[2] * w[2] - 1.0;
+        q2A = g2[0] * w[0] + g2[1] * w[1] + g2[2] * w[2] - 1.0;
     }
     double K = -(L.d + (n[0] * A[0] + n[1] * A[1] + n[2] * A[2]));
     double *c1 = F.c1, *c2 = F.c2, *cn = F.cn;
@@ -504,10 +503,12 @@ static GenRec make_gen_rec(const LeafD &L, const double omax[3]) {
         ref[0] = L.p0x; ref[1] = L.p0y; ref[2] = L.p0z;
     } else {
         for (int i = 0; i < 3; ++i) { g1[i] = 2.0 * e1[i] / L.c0; g2[i] = 2.0 * e2[i] / L.c1; }
-        ref[0] = L.p0x + 0.5 * e1[0] + 0.5 * e2[0]; ref[1] = L.p0y + 0.5 * e1[1] + 0.5 * e2[1]; ref[2] = L.p0z + 0.5 * e1[2] + 0.5 * e2[2];
+        ref[0] = L.p0x; ref[1] = L.p0y; ref[2] = L.p0z;
     }
-    const double c1 = -(g1[0] * ref[0] + g1[1] * ref[1] + g1[2] * ref[2]);
-    const double c2 = -(g2[0] * ref[0] + g2[1] * ref[1] + g2[2] * ref[2]);
+    // triangle: q_k(p) = g_k.(p - pa); rectangle: q_k(p) = g_k.(p - point') - 1 in [-1, 1] (also for non-orthogonal edges)
+    const double shift = L.kind == LEAF_TRI ? 0.0 : 1.0;
+    const double c1 = -(g1[0] * ref[0] + g1[1] * ref[1] + g1[2] * ref[2]) - shift;
+    const double c2 = -(g2[0] * ref[0] + g2[1] * ref[1] + g2[2] * ref[2]) - shift;
     double An = 0, Bn = std::fabs(L.d), E1 = std::fabs(c1), E2 = std::fabs(c2), F1 = 0, F2 = 0;
     for (int i = 0; i < 3; ++i) {
         An += std::fabs(n[i]); Bn += std::fabs(n[i]) * omax[i];
@@ -551,6 +552,11 @@ void build_filter_records(rt_scene &s, int w, int h) {
         for (int k = 0; k < np; ++k)
             for (int i = 0; i < 3; ++i)
                 if (std::isfinite(p[k][i])) { lo[i] = std::fmin(lo[i], p[k][i]); hi[i] = std::fmax(hi[i], p[k][i]); }
+        double v[4][3];                           // the parallelogram the inside test really accepts (non-orthogonal edges)
+        const int nv = L.kind == LEAF_RECT ? leaf_polygon(L, v) : 0;
+        for (int k = 0; k < nv; ++k)
+            for (int i = 0; i < 3; ++i)
+                if (std::isfinite(v[k][i])) { lo[i] = std::fmin(lo[i], v[k][i]); hi[i] = std::fmax(hi[i], v[k][i]); }
     }
     const CameraD cam = fixed_camera(w, h);
     // MFMA stream: the planar leaves in tree order, one row each, 32 per block (see rt_types.h), two blocks of padding

@@ -300,3 +300,49 @@ def test_cone_rows_random_leaves_and_apexes():
         assert (f > 0).all(), f"case {case}: min form {f.min()} ({'triangle' if tri else 'rectangle'})"
         checked += len(pts)
     assert checked > 20000 and always < 120
+
+
+def test_fp32_records_random_leaves_and_apexes():
+    """make_rec on random geometry (light apex): for random triangles and rectangles — also with non-orthogonal edge
+    vectors, whose accepted region is the dual parallelogram of Main.hs:238-241 — every direction from the apex through
+    a point of the accepted polygon passes the FP32 record test and, with the origin beyond the leaf, the segment clip."""
+    rng = np.random.default_rng(12)
+    L = _lib.lib()
+    checked = 0
+    for case in range(250):
+        size = 10.0 ** rng.uniform(-1.5, 1.5)
+        c = rng.uniform(-30, 30, 3)
+        e1, e2 = rng.normal(size=3) * size, rng.normal(size=3) * size
+        tri = case % 2 == 0
+        if tri:
+            world = api.triangle(api.red, tuple(c), tuple(c + e1), tuple(c + e2))
+            corners = np.array([c, c + e1, c + e2])
+        else:
+            world = api.rectangle(api.red, tuple(c), tuple(e1), tuple(e2))
+            ww, hh, wh = e1 @ e1, e2 @ e2, e1 @ e2
+            p0 = c - 0.5 * e1 - 0.5 * e2
+            det = ww * hh - wh * wh
+            corners = np.array([p0 + ((s * hh - t * wh) / det) * e1 + ((t * ww - s * wh) / det) * e2
+                                for s, t in ((0, 0), (ww, 0), (ww, hh), (0, hh))])
+        centre = corners.mean(axis=0)
+        apex = centre + rng.normal(size=3) * size * 10.0 ** rng.uniform(-1, 2)
+        # a far second leaf stretches the scene box, as other geometry would (the margins depend on |D|max)
+        far = api.triangle(api.blue, tuple(centre + 3 * (centre - apex) + 1), tuple(centre + 3 * (centre - apex) - 1), tuple(centre + 3.5 * (centre - apex)))
+        sc = api.Scene(api.mconcat([world, far]), api.pointLight(0.5, 0.5, tuple(apex)))
+        assert L.rt_scene_prepare_host(sc.handle, 64, 64) >= 0
+        out = (C.c_float * 16)()
+        assert L.rt_scene_get_filter_record(sc.handle, 1, 0, out) == 0
+        rec = np.frombuffer(out, np.float32).copy()
+        sc.close()
+        wts = rng.dirichlet(np.ones(len(corners)) * 0.3, size=100)
+        pts = np.concatenate([corners, wts @ corners])
+        D = ((pts - apex) * 1.5).astype(np.float32)                   # shadow-ray origin beyond the leaf, seen from the light
+        f = [fma32(np.full(len(D), rec[3 * j], np.float32), D[:, 0], fma32(np.full(len(D), rec[3 * j + 1], np.float32), D[:, 1],
+                                                                          (np.float32(rec[3 * j + 2]) * D[:, 2]).astype(np.float32))) for j in range(3)]
+        z = np.minimum(np.minimum(f[0], f[1]), f[2]) if tri else (f[2] - np.maximum(np.abs(f[0]), np.abs(f[1]))).astype(np.float32)
+        assert (z >= rec[9]).all(), f"case {case} ({'triangle' if tri else 'rectangle'}): min z {z.min()} < {rec[9]}"
+        nd = fma32(np.full(len(D), rec[11], np.float32), D[:, 0], fma32(np.full(len(D), rec[12], np.float32), D[:, 1],
+                                                                      (np.float32(rec[13]) * D[:, 2]).astype(np.float32)))
+        assert (nd >= rec[10]).all(), f"case {case}: segment clip rejects a leaf between light and origin"
+        checked += len(D)
+    assert checked > 20000

@@ -269,3 +269,15 @@ def test_32_point_lights(gpu_lib):
     lights = api.mconcat_lights([api.pointLight(0.06, 0.05, tuple(map(float, rng.uniform((-8, 2, -12), (8, 9, 2))))) for _ in range(32)]
                                 + [api.ambient(0.05)])
     compare(world, lights, 160, 120, label="32-lights")
+
+
+def test_fuzzed_scenes_against_oracle(gpu_lib):
+    """Differential fuzzing (tools/fuzz_parity.py): random scenes of every primitive — rectangles with arbitrary, also
+    non-orthogonal, edge vectors among them — in random mconcat/mappend trees, lights anywhere, random sizes, depths and
+    sample counts.  (A 5 000-scene campaign is logged in profiles/r01_fuzz_parity.txt.)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "150", "42"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "150 scenes (seed 42), 0 with a mismatch" in r.stdout
