@@ -497,6 +497,7 @@ static int isect_leaf(const node *n, const ray *r, hit *out, int talk) {
 
 static int isect_node(const orc_scene *s, int idx, const ray *r, hit *out, int use_bbox) {
     const node *n = &s->nodes[idx];
+    if (s->talk) use_bbox = 0;                     /* Talk.hs:185-194: the monoid has no bounding boxes */
     switch (n->kind) {
     case N_EMPTY: return 0;
     case N_RECT: case N_TRI: case N_SPHERE: case N_MANTLE: return isect_leaf(n, r, out, s->talk);

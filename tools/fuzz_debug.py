@@ -6,17 +6,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import oracle_binding as ob
 from raytrace_amd import _lib, api
-from fuzz_parity import random_scene
+from fuzz_parity import random_scene, talk_scene, extreme_scene
 
 K = int(sys.argv[1]); seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+mode = sys.argv[3] if len(sys.argv) > 3 else 'main'
+gen = {'main': random_scene, 'talk': talk_scene, 'extreme': extreme_scene}[mode]
 rng = np.random.default_rng(seed)
 for i in range(K + 1):
-    world, lights = random_scene(rng)
+    world, lights = gen(rng)
     w, h = int(rng.integers(17, 200)), int(rng.integers(9, 160))
     depth = int(rng.integers(1, 5))
     spp = int(rng.choice([1, 1, 1, 4]))
 print("scene", K, w, h, depth, spp)
-print(world if K in (8, 61, 81) else type(world))
+print(world if len(str(world)) < 3000 else type(world))
 print(lights)
 osc = ob.OracleScene(world, lights)
 ref = osc.render(w, h, depth=depth, spp=spp, seed=K, flags=(spp == 1), want_t=True)

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Differential fuzzing of the GPU path against the CPU oracle: random small scenes (triangles, rectangles with arbitrary edge
 vectors, cuboids, cylinders, spheres, mirrors; lights anywhere, also inside and on geometry), random image sizes, depths
-and sample counts.  usage: tools/fuzz_parity.py [nscenes] [seed]   (GPU box; prints one line per scene, fails on a mismatch)"""
+and sample counts.  usage: tools/fuzz_parity.py [nscenes] [seed] [mode]   (GPU box; one line per scene, fails on a mismatch)
+mode: "main" (default), "valu" (the vector-ALU kernels, RT_FILTER=valu), "talk" (Talk.hs dialect: rectangles only),
+"extreme" (scales from 1e-3 to 1e3, geometry around the eye and the viewport plane, degenerate leaves, lights on vertices)."""
 import os
 import sys
 
@@ -12,6 +14,62 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle_binding as ob  # noqa: E402
 from raytrace_amd import _lib, api  # noqa: E402
+
+
+def talk_scene(rng):
+    def pt():
+        return tuple(map(float, rng.uniform((-6, -4, -25), (6, 4, 1))))
+    shapes = []
+    for _ in range(int(rng.integers(1, 25))):
+        s = float(10 ** rng.uniform(-1, 1.2))
+        col = api.COLOURS[int(rng.integers(len(api.COLOURS)))]
+        if rng.random() < 0.3:
+            shapes.append(api.talk_cube([api.COLOURS[int(rng.integers(len(api.COLOURS)))] for _ in range(int(rng.integers(1, 7)))], s, pt()))
+        else:
+            shapes.append(api.talk_rectangle(col, pt(), tuple(map(float, rng.normal(size=3) * s)), tuple(map(float, rng.normal(size=3) * s))))
+    world = shapes[-1]
+    for sh in reversed(shapes[:-1]):
+        world = api.mappend(sh, world)                       # a <> (b <> ...), Data.Monoid's infixr
+    lights = [api.ambient(float(rng.uniform(0, 0.4)))]
+    for _ in range(int(rng.integers(0, 4))):
+        lights.append(api.talk_pointLight(float(rng.uniform(0.05, 1.5)), pt()))
+    return api.TalkDialect(world), api.mconcat_lights(lights)
+
+
+def extreme_scene(rng):
+    scale = float(10 ** rng.uniform(-3, 3))
+    def mat():
+        return api.COLOURS[int(rng.integers(len(api.COLOURS)))].replace(specularity=float(rng.choice([1, 30, 400])), reflectivity=float(rng.choice([0, 0, 0.5])))
+    def pt():
+        return rng.uniform((-3, -2, -6), (3, 2, 1.5)) * scale
+    shapes, verts = [], []
+    for _ in range(int(rng.integers(1, 30))):
+        k = int(rng.integers(5))
+        s = scale * float(10 ** rng.uniform(-3, 1))
+        p = pt()
+        if k == 0:
+            a, b = p + rng.normal(size=3) * s, p + rng.normal(size=3) * s
+            if rng.random() < 0.1:
+                b = a.copy()                                                             # zero area
+            verts += [p, a, b]
+            shapes.append(api.triangle(mat(), tuple(p), tuple(a), tuple(b)))
+        elif k == 1:
+            w, h = rng.normal(size=3) * s, rng.normal(size=3) * s
+            if rng.random() < 0.1:
+                h = w * 2.0                                                              # parallel edges: NaN normal
+            verts.append(p)
+            shapes.append(api.rectangle(mat(), tuple(p), tuple(w), tuple(h)))
+        elif k == 2:
+            shapes.append(api.colorcuboid([mat()], tuple(p), *(float(v) for v in rng.uniform(0.01, 3, 3) * scale)))
+        elif k == 3:
+            shapes.append(api.sphere(mat(), tuple(p), float(rng.uniform(0.01, 2) * scale)))
+        else:
+            shapes.append(api.cylinder(mat(), mat(), mat(), tuple(p), int(rng.integers(1, 9)), float(rng.uniform(0.05, 3) * scale), float(rng.uniform(0.05, 1.5) * scale)))
+    lights = [api.ambient(float(rng.uniform(0, 0.3)))]
+    for _ in range(int(rng.integers(0, 5))):
+        lp = verts[int(rng.integers(len(verts)))] if verts and rng.random() < 0.3 else pt() * 1.5
+        lights.append(api.pointLight(float(rng.uniform(0.05, 0.9)), float(rng.uniform(0, 0.9)), tuple(map(float, lp))))
+    return api.mconcat(shapes), api.mconcat_lights(lights)
 
 
 def random_scene(rng):
@@ -64,11 +122,15 @@ def random_scene(rng):
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    mode = sys.argv[3] if len(sys.argv) > 3 else "main"
+    if mode == "valu":
+        os.environ["RT_FILTER"] = "valu"
+    gen = {"main": random_scene, "valu": random_scene, "talk": talk_scene, "extreme": extreme_scene}[mode]
     _lib.check(_lib.lib().rt_init(0))
     rng = np.random.default_rng(seed)
     bad = 0
     for i in range(n):
-        world, lights = random_scene(rng)
+        world, lights = gen(rng)
         w, h = int(rng.integers(17, 200)), int(rng.integers(9, 160))
         depth = int(rng.integers(1, 5))
         spp = int(rng.choice([1, 1, 1, 4]))
@@ -85,7 +147,7 @@ def main():
         print(f"scene {i}: {leaves} leaves, {len(lights)} lights, {w}x{h} depth {depth} spp {spp}: hit-ID mismatches {n_id}, colour mismatches {n_rgb}", flush=True)
         if n_id or n_rgb:
             bad += 1
-    print(f"FUZZ: {n} scenes (seed {seed}), {bad} with a mismatch")
+    print(f"FUZZ: {n} scenes (seed {seed}{'' if mode == 'main' else ', ' + mode}), {bad} with a mismatch")
     sys.exit(1 if bad else 0)
 
 
