@@ -3,7 +3,8 @@
 vectors, cuboids, cylinders, spheres, mirrors; lights anywhere, also inside and on geometry), random image sizes, depths
 and sample counts.  usage: tools/fuzz_parity.py [nscenes] [seed] [mode]   (GPU box; one line per scene, fails on a mismatch)
 mode: "main" (default), "valu" (the vector-ALU kernels, RT_FILTER=valu), "talk" (Talk.hs dialect: rectangles only),
-"extreme" (scales from 1e-3 to 1e3, geometry around the eye and the viewport plane, degenerate leaves, lights on vertices)."""
+"extreme" (scales from 1e-3 to 1e3, geometry around the eye and the viewport plane, degenerate leaves, lights on vertices),
+"big" (90 to 3000 leaves in nested lists, small images).  Every mode also renders random row bands."""
 import os
 import sys
 
@@ -72,6 +73,27 @@ def extreme_scene(rng):
     return api.mconcat(shapes), api.mconcat_lights(lights)
 
 
+def big_scene(rng):
+    """Hundreds to thousands of leaves: exercises the block loop of the leaf stream (32 leaves per block, 3 per turn)."""
+    n = int(rng.integers(90, 3000))
+    def mat():
+        return api.COLOURS[int(rng.integers(len(api.COLOURS)))].replace(specularity=float(rng.choice([1, 20, 100])))
+    shapes = []
+    while sum(6 if isinstance(s_, api.Cuboid) else 1 for s_ in shapes) < n:
+        c = rng.uniform((-8, -5, -28), (8, 5, -3))
+        if rng.random() < 0.6:
+            shapes.append(api.triangle(mat(), tuple(c), tuple(c + rng.normal(size=3) * 0.4), tuple(c + rng.normal(size=3) * 0.4)))
+        elif rng.random() < 0.5:
+            shapes.append(api.colorcuboid([mat()], tuple(c), *(float(v) for v in rng.uniform(0.1, 1.0, 3))))
+        else:
+            shapes.append(api.rectangle(mat(), tuple(c), tuple(rng.normal(size=3) * 0.5), tuple(rng.normal(size=3) * 0.5)))
+    k = int(rng.integers(1, 6))                           # a few nested lists
+    cuts = sorted(set(int(v) for v in rng.integers(1, len(shapes), k)))
+    parts = [api.mconcat(shapes[a:b]) for a, b in zip([0] + cuts, cuts + [len(shapes)])]
+    lights = [api.ambient(0.1)] + [api.pointLight(0.3, 0.3, tuple(map(float, rng.uniform((-8, 4, -28), (8, 12, 0))))) for _ in range(int(rng.integers(1, 4)))]
+    return api.mconcat(parts), api.mconcat_lights(lights)
+
+
 def random_scene(rng):
     def mat():
         m = api.COLOURS[int(rng.integers(len(api.COLOURS)))]
@@ -125,18 +147,22 @@ def main():
     mode = sys.argv[3] if len(sys.argv) > 3 else "main"
     if mode == "valu":
         os.environ["RT_FILTER"] = "valu"
-    gen = {"main": random_scene, "valu": random_scene, "talk": talk_scene, "extreme": extreme_scene}[mode]
+    gen = {"main": random_scene, "valu": random_scene, "talk": talk_scene, "extreme": extreme_scene, "big": big_scene}[mode]
     _lib.check(_lib.lib().rt_init(0))
     rng = np.random.default_rng(seed)
     bad = 0
     for i in range(n):
         world, lights = gen(rng)
         w, h = int(rng.integers(17, 200)), int(rng.integers(9, 160))
+        if mode == "big":
+            w, h = int(rng.integers(17, 80)), int(rng.integers(9, 60))
         depth = int(rng.integers(1, 5))
         spp = int(rng.choice([1, 1, 1, 4]))
-        ref = ob.OracleScene(world, lights).render(w, h, depth=depth, spp=spp, seed=i, flags=(spp == 1))
+        row0 = int(rng.integers(0, h)) if rng.random() < 0.3 else 0          # sometimes a row band, as a rank renders it
+        nrows = int(rng.integers(1, h - row0 + 1)) if row0 or rng.random() < 0.2 else h
+        ref = ob.OracleScene(world, lights).render(w, h, depth=depth, spp=spp, seed=i, row0=row0, nrows=nrows, flags=(spp == 1))
         sc = api.Scene(world, lights)
-        rgba, hit = sc.render(w, h, depth=depth, spp=spp, seed=i)
+        rgba, hit = sc.render(w, h, depth=depth, spp=spp, seed=i, row0=row0, nrows=nrows)
         leaves = sc.num_leaves
         sc.close()
         d_id = hit != ref["hit_id"]
