@@ -282,3 +282,26 @@ def test_fuzzed_scenes_against_oracle(gpu_lib):
         r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), str(n), "42", mode], capture_output=True, text=True)
         assert r.returncode == 0, mode + ": " + r.stdout[-2000:] + r.stderr[-2000:]
         assert f"{n} scenes (seed 42" in r.stdout and "), 0 with a mismatch" in r.stdout
+
+
+def test_band_larger_than_one_chunk(gpu_lib):
+    """A band of more than 16 Mi pixels is rendered in chunks of rows (rt_render_device): rows on both sides of the chunk
+    boundary, and the last ragged chunk, against the oracle; a mirror scene too (its chunks are a quarter of the size)."""
+    world, lights = scenes.default_scene()
+    w, h = 16384, 4000
+    sc = api.Scene(world, lights)
+    rgba, hit = sc.render(w, h, row0=1500, nrows=1100)             # 18.0 M pixels: chunks of 1024 and 76 rows
+    sc.close()
+    osc = ob.OracleScene(world, lights)
+    for r in (1500, 2523, 2524, 2599):
+        ref = osc.render(w, h, row0=r, nrows=1, nthreads=16)
+        assert (hit[r - 1500] == ref["hit_id"][0]).all() and (rgba[r - 1500, :, :3] == ref["rgb"][0]).all(), f"row {r}"
+    world, lights = scenes.mirror_room()
+    w, h = 4096, 1100                                              # 4.5 M pixels: chunks of 1024 and 76 rows when reflective
+    sc = api.Scene(world, lights)
+    rgba, hit = sc.render(w, h, depth=3)
+    sc.close()
+    osc = ob.OracleScene(world, lights)
+    for r in (0, 1023, 1024, 1099):
+        ref = osc.render(w, h, depth=3, row0=r, nrows=1, nthreads=16)
+        assert (hit[r] == ref["hit_id"][0]).all() and (rgba[r, :, :3] == ref["rgb"][0]).all(), f"mirror row {r}"
