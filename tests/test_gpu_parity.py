@@ -278,7 +278,7 @@ def test_fuzzed_scenes_against_oracle(gpu_lib):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for mode, n in (("main", 150), ("valu", 60), ("talk", 80), ("extreme", 100), ("big", 40)):
+    for mode, n in (("main", 150), ("valu", 60), ("talk", 80), ("extreme", 100), ("big", 40), ("height", 40)):
         r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), str(n), "42", mode], capture_output=True, text=True)
         assert r.returncode == 0, mode + ": " + r.stdout[-2000:] + r.stderr[-2000:]
         assert f"{n} scenes (seed 42" in r.stdout and "), 0 with a mismatch" in r.stdout

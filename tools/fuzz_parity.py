@@ -4,7 +4,8 @@ vectors, cuboids, cylinders, spheres, mirrors; lights anywhere, also inside and 
 and sample counts.  usage: tools/fuzz_parity.py [nscenes] [seed] [mode]   (GPU box; one line per scene, fails on a mismatch)
 mode: "main" (default), "valu" (the vector-ALU kernels, RT_FILTER=valu), "talk" (Talk.hs dialect: rectangles only),
 "extreme" (scales from 1e-3 to 1e3, geometry around the eye and the viewport plane, degenerate leaves, lights on vertices),
-"big" (90 to 3000 leaves in nested lists, small images).  Every mode also renders random row bands."""
+"big" (90 to 3000 leaves in nested lists, small images), "height" (linearInterpolation height fields with the gaussian
+normals, up to 32 point lights).  Every mode also renders random row bands."""
 import os
 import sys
 
@@ -94,6 +95,23 @@ def big_scene(rng):
     return api.mconcat(parts), api.mconcat_lights(lights)
 
 
+def height_scene(rng):
+    """linearInterpolation (Main.hs:937-988) with random grid, origin and scale, with and without the gaussian fnorm,
+    plus a few more shapes and up to 32 point lights."""
+    a = float(rng.uniform(0.3, 1.5))
+    step = float(rng.choice([0.1, 0.2, 0.25, 0.5])) * a
+    origin = tuple(map(float, rng.uniform((-3, -8, -30), (3, -2, -8))))
+    world, lights = api.linearInterpolation(api.gaussian, api.GAUSSIAN_FNORM if rng.random() < 0.7 else None,
+                                            (-a, -a), (a, a), step, origin, float(rng.uniform(2, 12)))
+    extra = [api.colorcuboid([api.red, api.green], tuple(map(float, rng.uniform((-6, -6, -28), (6, 2, -6)))), 1.0, 2.0, 1.5)
+             for _ in range(int(rng.integers(0, 4)))]
+    if extra:
+        world = api.mconcat([world] + extra) if rng.random() < 0.5 else api.mappend(world, api.mconcat(extra))
+    more = [api.pointLight(float(rng.uniform(0.02, 0.3)), float(rng.uniform(0, 0.5)), tuple(map(float, rng.uniform((-20, -5, -40), (20, 60, 5)))))
+            for _ in range(int(rng.choice([0, 1, 3, 31])))]
+    return world, api.mconcat_lights([lights] + more)
+
+
 def random_scene(rng):
     def mat():
         m = api.COLOURS[int(rng.integers(len(api.COLOURS)))]
@@ -147,7 +165,7 @@ def main():
     mode = sys.argv[3] if len(sys.argv) > 3 else "main"
     if mode == "valu":
         os.environ["RT_FILTER"] = "valu"
-    gen = {"main": random_scene, "valu": random_scene, "talk": talk_scene, "extreme": extreme_scene, "big": big_scene}[mode]
+    gen = {"main": random_scene, "valu": random_scene, "talk": talk_scene, "extreme": extreme_scene, "big": big_scene, "height": height_scene}[mode]
     _lib.check(_lib.lib().rt_init(0))
     rng = np.random.default_rng(seed)
     bad = 0
