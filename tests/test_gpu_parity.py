@@ -305,3 +305,17 @@ def test_band_larger_than_one_chunk(gpu_lib):
     for r in (0, 1023, 1024, 1099):
         ref = osc.render(w, h, depth=3, row0=r, nrows=1, nthreads=16)
         assert (hit[r] == ref["hit_id"][0]).all() and (rgba[r, :, :3] == ref["rgb"][0]).all(), f"mirror row {r}"
+
+
+def test_two_live_scenes_interleaved(gpu_lib):
+    """Two scenes alive at once, rendered alternately at different sizes: each keeps its own device copy and records."""
+    a = api.Scene(*scenes.stacked_cubes())
+    b = api.Scene(*scenes.cylinder_axes())
+    ra = ob.OracleScene(*scenes.stacked_cubes())
+    rb = ob.OracleScene(*scenes.cylinder_axes())
+    for (w, h) in ((96, 64), (130, 70), (96, 64)):
+        for sc, orc in ((a, ra), (b, rb)):
+            rgba, hit = sc.render(w, h)
+            ref = orc.render(w, h)
+            assert (hit == ref["hit_id"]).all() and (rgba[:, :, :3] == ref["rgb"]).all()
+    a.close(); b.close()
