@@ -36,7 +36,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from raytrace_amd import api, scenes, _lib  # noqa: E402
-from raytrace_amd.distributed import gather_bands, split_rows  # noqa: E402
+from raytrace_amd.distributed import gather_bands, split_rows, sub_bands  # noqa: E402
 
 FLOPS_TRI, FLOPS_RECT = 52 + 1, 44 + 1
 PEAK_FP32_TFLOPS = 157.3                        # MI355X_MICROARCH.md: peak FP32 (vector), packed FMA
@@ -105,6 +105,7 @@ def main():
                     help="first stage: bounding cones on the matrix cores (default) or the FP32 vector-ALU kernels")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the measured path) or gloo (rehearsal on one GPU)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank renders on GPU 0 (gloo only)")
+    ap.add_argument("--pieces", type=int, default=4, help="N > 1: pieces per band; piece k's gather overlaps piece k+1's render")
     ap.add_argument("--verify", action="store_true", help="rank 0 re-renders the whole frame alone and compares it with the gathered one")
     args = ap.parse_args()
 
@@ -158,19 +159,37 @@ def main():
     hit = torch.empty((nrows, w), dtype=torch.int32, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
 
+    # every band is rendered in `pieces` consecutive pieces; piece k of all peers travels to GPU 0 in one group
+    # of send/recv while piece k+1 renders (the library returns once the piece is enqueued on `stream`; RCCL's
+    # own stream waits for that piece only), so only the last piece's exchange is exposed
+    pieces = max(1, args.pieces) if n > 1 else 1
+    subs = [sub_bands(b, pieces) for b in bands]
+
     def step():
-        scene.render_device(w, h, mine.data_ptr(), hit.data_ptr(), depth=args.depth, spp=args.spp, seed=20260355,
-                            row0=row0, nrows=nrows, stream=stream)
-        if n > 1 and not staged:   # row bands -> GPU 0 (ncclSend/ncclRecv in one group: every peer has a direct xGMI link)
-            gather_bands(dist, frame, mine, bands, rank)
-        elif staged:
-            torch.cuda.synchronize()
-            host_band = mine.cpu()
-            host_frame = torch.empty((h, w, 4), dtype=torch.uint8) if rank == 0 else None
-            gather_bands(dist, host_frame, host_band, bands, rank)
-            if rank == 0:
-                host_frame[row0:row0 + nrows] = host_band
-                frame.copy_(host_frame)
+        pending, host = [], []
+        host_frame = torch.empty((h, w, 4), dtype=torch.uint8) if staged and rank == 0 else None
+        for k in range(pieces):
+            r0, nr = subs[rank][k]
+            piece = mine[r0 - row0:r0 - row0 + nr]
+            if nr > 0:
+                scene.render_device(w, h, piece.data_ptr(), hit[r0 - row0:].data_ptr(), depth=args.depth, spp=args.spp,
+                                    seed=20260355, row0=r0, nrows=nr, stream=stream)
+            if n == 1:
+                continue
+            group = [s[k] for s in subs]
+            if not staged:     # ncclSend/ncclRecv in one group: every peer has a direct xGMI link to GPU 0
+                pending += gather_bands(dist, frame, piece, group, rank, wait=False)
+            else:              # gloo rehearsal: the same groups, through host memory
+                torch.cuda.synchronize()
+                host_piece = piece.cpu()
+                host.append((r0, nr, host_piece))
+                pending += gather_bands(dist, host_frame, host_piece, group, rank, wait=False)
+        for req in pending:
+            req.wait()
+        if staged and rank == 0:
+            for r0, nr, host_piece in host:
+                host_frame[r0:r0 + nr] = host_piece
+            frame.copy_(host_frame)
 
     def sync():
         torch.cuda.synchronize()
@@ -197,6 +216,17 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     stats = scene.stats()
+    if n > 1:            # untimed pass: ray counts and per-kernel times of this rank's band, summed over its pieces
+        keys = ("primary_rays", "shadow_rays", "exact_evals", "ms_shadow", "ms_primary", "ms_setup", "ms_final")
+        total = dict.fromkeys(keys, 0.0)
+        for r0, nr in subs[rank]:
+            if nr > 0:
+                scene.render_device(w, h, mine[r0 - row0:].data_ptr(), hit[r0 - row0:].data_ptr(), depth=args.depth, spp=args.spp,
+                                    seed=20260355, row0=r0, nrows=nr, stream=stream)
+                st = scene.stats()
+                for key in keys:
+                    total[key] += st[key]
+        stats = total
     counts = torch.tensor([stats["primary_rays"], stats["shadow_rays"], stats["exact_evals"]], dtype=torch.float64, device=dev)
     shade_t = torch.tensor([stats["ms_shadow"], stats["ms_primary"]], dtype=torch.float64, device=dev)
     if n > 1:
@@ -212,6 +242,7 @@ def main():
         verified = bool(torch.equal(alone, frame))
     if rank == 0:
         primary, shadow, exact = (float(c) for c in counts.tolist())
+        assert primary == float(w) * h * args.spp, (primary, w, h, args.spp)   # every pixel of the frame was traced once per sample
         ms_step = dt / args.steps * 1e3
         per_test = ntri * FLOPS_TRI + nrect * FLOPS_RECT
         ms_shade = float(np.mean(shade_ms)) if shade_ms else float(shade_t[0])
@@ -238,7 +269,7 @@ def main():
                        "arithmetic": "hits and colours decided in f64 (the reference's Double); conservative filters in front: "
                                      + ("f16 bounding cones on the matrix cores, then f32 records" if args.filter == "mfma" else "f32 records on the vector ALU"),
                        "width": w, "height": h, "leaves": ntri + nrect, "lights": nlt, "spp": args.spp,
-                       "bands": bands if n > 1 else None, "gathered_frame_equals_single_render": verified,
+                       "bands": bands if n > 1 else None, "pieces_per_band": pieces if n > 1 else None, "gathered_frame_equals_single_render": verified,
                        "shadow_rays_per_frame": shadow, "exact_fp64_evals_per_frame": exact,
                        "whole_frame_algorithmic_tflops": (primary + shadow) * per_test / (dt / args.steps) / 1e12,
                        "kernel_ms": {"k_primary": ms_prim, "k_setup": stats["ms_setup"], "k_shadow": ms_shade, "k_final": stats["ms_final"]}},

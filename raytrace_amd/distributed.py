@@ -37,12 +37,34 @@ def split_rows(cost: Sequence[float], h: int, n: int, align: int = 8) -> List[Tu
     return [(cuts[i], cuts[i + 1] - cuts[i]) for i in range(n)]
 
 
-def gather_bands(dist, frame, band, bands: Sequence[Tuple[int, int]], rank: int):
+def sub_bands(band: Tuple[int, int], parts: int, align: int = 8) -> List[Tuple[int, int]]:
+    """Cut one band (row0, nrows) into exactly `parts` consecutive pieces at multiples of `align` rows.
+
+    Every rank renders its band piece by piece and hands each finished piece to the gather while the next
+    one renders, so the exchange hides behind the render.  All ranks compute all ranks' pieces with this
+    function (piece k of every peer travels in group k); a band too short for `parts` pieces gets empty
+    ones, which are skipped by the render and send nothing.
+    """
+    if parts < 1:
+        raise ValueError("sub_bands: parts must be >= 1")
+    r0, nr = band
+    units = -(-nr // align)                       # pieces are whole tiles except the band's last rows
+    out, done = [], 0
+    for k in range(parts):
+        upto = min(nr, ((units * (k + 1)) // parts) * align) if k + 1 < parts else nr
+        out.append((r0 + done, upto - done))
+        done = upto
+    return out
+
+
+def gather_bands(dist, frame, band, bands: Sequence[Tuple[int, int]], rank: int, wait: bool = True):
     """Send every rank's band to rank 0.
 
     rank 0: `frame` is the whole [h, w, C] image (its own band already in place); the other bands are
     received straight into their rows.  other ranks: `band` is their [nrows, w, C] band.
     One ncclGroup of send/recv (batch_isend_irecv): the peers' links to GPU 0 run in parallel.
+    wait=False returns the requests instead of waiting on them (the caller overlaps the next piece's
+    render with this exchange and waits at the end of the frame).
     """
     ops = []
     if rank == 0:
@@ -51,6 +73,9 @@ def gather_bands(dist, frame, band, bands: Sequence[Tuple[int, int]], rank: int)
                 ops.append(dist.P2POp(dist.irecv, frame[r0:r0 + nr], peer))
     elif band.shape[0] > 0:
         ops.append(dist.P2POp(dist.isend, band, 0))
-    if ops:
-        for req in dist.batch_isend_irecv(ops):
-            req.wait()
+    reqs = dist.batch_isend_irecv(ops) if ops else []
+    if not wait:
+        return reqs
+    for req in reqs:
+        req.wait()
+    return []

@@ -11,7 +11,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from raytrace_amd.distributed import gather_bands, split_rows
+from raytrace_amd.distributed import gather_bands, split_rows, sub_bands
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -32,6 +32,18 @@ def test_split_rows_properties():
     assert split_rows([1.0], 16, 2) == [(0, 8), (8, 8)]
     with pytest.raises(ValueError):
         split_rows([], 10, 2)
+
+
+def test_sub_bands_properties():
+    for band, parts in [((664, 496), 4), ((0, 8), 4), ((16, 20), 3), ((0, 0), 2), ((8, 2048), 4), ((0, 1), 1), ((24, 1000), 7)]:
+        sb = sub_bands(band, parts)
+        assert len(sb) == parts and sb[0][0] == band[0] and sum(nr for _, nr in sb) == band[1]
+        for i in range(1, parts):
+            assert sb[i][0] == sb[i - 1][0] + sb[i - 1][1] and sb[i][1] >= 0
+            assert sb[i][1] == 0 or (sb[i][0] - band[0]) % 8 == 0        # pieces start on the kernels' tile rows
+    assert sub_bands((8, 2048), 4) == [(8, 512), (520, 512), (1032, 512), (1544, 512)]
+    with pytest.raises(ValueError):
+        sub_bands((0, 8), 0)
 
 
 def _worker(rank, world, port, out_path):
@@ -55,9 +67,25 @@ def _worker(rank, world, port, out_path):
         frame[r0:r0 + nr] = mine
     gather_bands(dist, frame, mine, bands, rank)
     dist.barrier()
+    # the same frame again the way bench.py does it: every band in 3 pieces, piece k of both ranks in group k,
+    # nothing waited on until the last piece has been handed over
+    piped = torch.zeros((h, w, 3), dtype=torch.uint8) if rank == 0 else None
+    subs = [sub_bands(b, 3) for b in bands]
+    pending, keep = [], []
+    for k in range(3):
+        p0, pn = subs[rank][k]
+        piece = torch.from_numpy(osc.render(w, h, row0=p0, nrows=pn, nthreads=1)["rgb"].copy()) if pn > 0 \
+            else torch.zeros((0, w, 3), dtype=torch.uint8)
+        keep.append(piece)
+        if rank == 0:
+            piped[p0:p0 + pn] = piece
+        pending += gather_bands(dist, piped, piece, [s[k] for s in subs], rank, wait=False)
+    for req in pending:
+        req.wait()
+    dist.barrier()
     if rank == 0:
         full = osc.render(w, h, nthreads=1)["rgb"]
-        np.save(out_path, np.array([int((frame.numpy() != full).sum()), len(bands)]))
+        np.save(out_path, np.array([int((frame.numpy() != full).sum()), len(bands), int((piped.numpy() != full).sum())]))
     dist.destroy_process_group()
 
 
@@ -69,4 +97,4 @@ def test_two_rank_band_render_and_gather(tmp_path):
     out = str(tmp_path / "res.npy")
     mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
     res = np.load(out)
-    assert res[0] == 0 and res[1] == 2
+    assert res[0] == 0 and res[1] == 2 and res[2] == 0
