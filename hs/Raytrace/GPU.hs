@@ -115,6 +115,8 @@ foreign import ccall unsafe "rt_set_normal_mode" c_set_normal_mode :: ScenePtr -
 foreign import ccall unsafe "rt_add_point_light" c_add_point_light :: ScenePtr -> CDouble -> CDouble -> Ptr CDouble -> IO CInt
 foreign import ccall unsafe "rt_add_ambient"     c_add_ambient     :: ScenePtr -> CDouble -> IO CInt
 -- long call: `safe`, so other Haskell threads keep running while the GPU renders
+foreign import ccall unsafe "rt_host_alloc"      c_host_alloc      :: CSize -> IO (Ptr Word8)
+foreign import ccall        "&rt_host_free"      p_host_free       :: FunPtr (Ptr Word8 -> IO ())
 foreign import ccall safe   "rt_render"          c_render          :: ScenePtr -> CInt -> CInt -> CInt -> CInt -> Word64 -> CInt -> CInt -> Ptr Word8 -> Ptr Int32 -> IO CInt
 
 check :: String -> CInt -> IO CInt
@@ -183,7 +185,11 @@ withScene (MkLight ls) world act =
 -- multi-GPU partition: one process per GPU renders one band.
 renderBand :: Int -> Int -> Int -> Light -> Shape -> Int -> Int -> IO (ForeignPtr Word8)
 renderBand w h depth lights world row0 nrows = withScene lights world $ \s -> do
-  buf <- mallocForeignPtrBytes (max 1 (w * nrows * 4))
+  -- page-locked memory from the library (freed by rt_host_free when the ForeignPtr dies): the copy back is
+  -- DMA behind the render; mallocForeignPtrBytes would work too, through the runtime's bounce buffers
+  raw <- c_host_alloc (fromIntegral (max 1 (w * nrows * 4)))
+  when (raw == nullPtr) $ c_last_error >>= peekCString >>= \m -> ioError (userError ("rt_host_alloc: " ++ m))
+  buf <- newForeignPtr p_host_free raw
   withForeignPtr buf $ \p ->
     void $ c_render s (fromIntegral w) (fromIntegral h) (fromIntegral depth) 1 0 (fromIntegral row0) (fromIntegral nrows) p nullPtr >>= check "rt_render"
   return buf

@@ -152,6 +152,12 @@ int  rt_render(rt_scene *, int w, int h, int depth, int spp, uint64_t seed,
 int  rt_render_device(rt_scene *, int w, int h, int depth, int spp, uint64_t seed,
                       int row0, int nrows, void *d_rgba, void *d_hit_id, void *stream);
 int  rt_synchronize(void);
+/* Page-locked host memory for rt_render's output buffers, in place of the reference's storable-vector
+ * allocation behind `generateImage` (Main.hs:621 builds the image rt_render now fills).  Optional: any
+ * host pointer works, but into these buffers the copy back is DMA at PCIe rate and hides behind the
+ * render.  NULL on failure (rt_last_error).  Free with rt_host_free only. */
+void *rt_host_alloc(size_t bytes);
+void  rt_host_free(void *p);
 int  rt_get_stats(rt_scene *, rt_stats *out);   /* synchronises; stats of the last render of this scene */
 
 /* ---- saveBmpImage "trace.bmp" (ImageRGB8 ...)                           Main.hs:621 ------ */

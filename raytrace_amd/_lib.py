@@ -29,6 +29,8 @@ SYMBOLS = {
     "rt_init": (C.c_int, [C.c_int]),
     "rt_last_error": (C.c_char_p, []),
     "rt_version": (C.c_char_p, []),
+    "rt_host_alloc": (C.c_void_p, [C.c_size_t]),
+    "rt_host_free": (None, [C.c_void_p]),
     "rt_scene_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "rt_scene_destroy": (None, [C.c_void_p]),
     "rt_scene_set_dialect": (C.c_int, [C.c_void_p, C.c_int]),

@@ -24,6 +24,8 @@ import math
 from dataclasses import dataclass, field
 from typing import Callable, List, Optional, Sequence, Tuple
 
+import weakref
+
 import numpy as np
 
 from . import _lib
@@ -391,11 +393,19 @@ class Scene:
         _lib.check(self._L.rt_scene_get_leaf(self._h, i, out))
         return list(out)
 
-    def render(self, w, h, depth=4, spp=1, seed=0, row0=0, nrows=None, want_rgba=True, want_hit=True):
-        """Host-buffer render (rt_render).  Returns (rgba[nrows,w,4] uint8, hit_id[nrows,w] int32)."""
+    def render(self, w, h, depth=4, spp=1, seed=0, row0=0, nrows=None, want_rgba=True, want_hit=True,
+               out_rgba=None, out_hit=None):
+        """Host-buffer render (rt_render).  Returns (rgba[nrows,w,4] uint8, hit_id[nrows,w] int32).
+
+        out_rgba / out_hit: caller-owned arrays of exactly that shape and dtype (e.g. from host_buffer(),
+        which makes the copy back DMA); by default fresh pageable numpy arrays are returned."""
         nrows = h - row0 if nrows is None else nrows
-        rgba = np.empty((nrows, w, 4), np.uint8) if want_rgba else None
-        hit = np.empty((nrows, w), np.int32) if want_hit else None
+        for out, shape, dt in ((out_rgba, (nrows, w, 4), np.uint8), (out_hit, (nrows, w), np.int32)):
+            if out is not None and (out.shape != shape or out.dtype != dt or not out.flags.c_contiguous):
+                raise ValueError(f"render: output array must be C-contiguous {shape} {np.dtype(dt).name}")
+        want_rgba, want_hit = want_rgba or out_rgba is not None, want_hit or out_hit is not None
+        rgba = (out_rgba if out_rgba is not None else np.empty((nrows, w, 4), np.uint8)) if want_rgba else None
+        hit = (out_hit if out_hit is not None else np.empty((nrows, w), np.int32)) if want_hit else None
         _lib.check(self._L.rt_render(self._h, w, h, depth, spp, seed, row0, nrows,
                                      rgba.ctypes.data if want_rgba else None,
                                      hit.ctypes.data if want_hit else None), "rt_render")
@@ -422,6 +432,21 @@ class Scene:
             self.close()
         except Exception:
             pass
+
+
+def host_buffer(shape, dtype):
+    """A numpy array in page-locked host memory (rt_host_alloc), freed with the array: pass it to
+    Scene.render(out_rgba= / out_hit=) and the copy back from the GPU is DMA hidden behind the render."""
+    dtype = np.dtype(dtype)
+    nbytes = int(np.prod(shape)) * dtype.itemsize
+    L = _lib.lib()
+    p = L.rt_host_alloc(max(nbytes, 1))
+    if not p:
+        raise RuntimeError("rt_host_alloc: " + (L.rt_last_error() or b"").decode())
+    raw = (C.c_uint8 * max(nbytes, 1)).from_address(p)
+    arr = np.frombuffer(raw, dtype=np.uint8, count=nbytes).view(dtype).reshape(shape)
+    weakref.finalize(raw, L.rt_host_free, p)       # numpy keeps `raw` alive as the array's base
+    return arr
 
 
 # ---------------------------------------------------------------------------------------------

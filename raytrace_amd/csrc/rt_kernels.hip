@@ -1470,6 +1470,10 @@ __global__ void k_resolve(const uint32_t *__restrict__ accum, uint8_t *__restric
 // Host side
 
 hipStream_t g_stream = nullptr;
+// rt_render's device-to-host copies run here, band by band, behind the render of the following bands
+hipStream_t g_copy_stream = nullptr;
+constexpr int RT_HOST_BANDS_MAX = 8;
+hipEvent_t g_band_done[RT_HOST_BANDS_MAX] = {};
 int g_device = -1;
 // RT_FILTER=valu selects the scalar-record VALU kernels (k_primary / k_shadow) instead of the matrix-core ones
 bool g_use_mfma = true;
@@ -1564,8 +1568,14 @@ int rt_init(int device) {
     }
     if (device < 0 || device >= n) { set_error("rt_init: device index out of range"); return RT_ERR_ARG; }
     HIP_TRY(hipSetDevice(device));
-    if (g_stream && g_device != device) { (void)hipStreamDestroy(g_stream); g_stream = nullptr; }
+    if (g_stream && g_device != device) {
+        (void)hipStreamDestroy(g_stream); g_stream = nullptr;
+        (void)hipStreamDestroy(g_copy_stream); g_copy_stream = nullptr;
+        for (hipEvent_t &e : g_band_done) { if (e) (void)hipEventDestroy(e); e = nullptr; }
+    }
     if (!g_stream) HIP_TRY(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+    if (!g_copy_stream) HIP_TRY(hipStreamCreateWithFlags(&g_copy_stream, hipStreamNonBlocking));
+    for (hipEvent_t &e : g_band_done) if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     g_device = device;
     const char *f = getenv("RT_FILTER");
     g_use_mfma = !(f && std::string(f) == "valu");
@@ -1587,8 +1597,10 @@ void rt_scene_destroy(rt_scene *s) {
     delete s;
 }
 
-int rt_render_device(rt_scene *s, int w, int h, int depth, int spp, uint64_t seed, int row0, int nrows,
-                     void *d_rgba, void *d_hit_id, void *stream) {
+// Enqueues the kernels of one row band.  `more` = this band continues a frame whose earlier bands were enqueued by
+// the previous call(s): events, counters and ray counts then accumulate, so rt_get_stats describes the whole frame.
+static int render_rows(rt_scene *s, int w, int h, int depth, int spp, uint64_t seed, int row0, int nrows,
+                       void *d_rgba, void *d_hit_id, void *stream, bool more) {
     if (!s) { set_error("rt_render: scene is NULL"); return RT_ERR_ARG; }
     if (w <= 0 || h <= 0 || spp < 1 || row0 < 0 || nrows < 0 || row0 + nrows > h) {
         set_error("rt_render: bad image size or row band"); return RT_ERR_ARG;
@@ -1600,8 +1612,8 @@ int rt_render_device(rt_scene *s, int w, int h, int depth, int spp, uint64_t see
     if ((rc = prepare(*s, w, h))) return rc;
     hipStream_t st = stream ? (hipStream_t)stream : g_stream;
     const size_t npix = (size_t)w * (size_t)nrows;
-    s->last_primary = (uint64_t)npix * (uint64_t)spp;
-    s->ev_used = 0;
+    if (!more) { s->last_primary = 0; s->ev_used = 0; }
+    s->last_primary += (uint64_t)npix * (uint64_t)spp;
     s->stats_pending = false;
     if (npix == 0) return RT_OK;
     // bounce levels: trace n reflects at most n - 1 times (trace 0 = black, Main.hs:542); only scenes with a
@@ -1635,7 +1647,7 @@ int rt_render_device(rt_scene *s, int w, int h, int depth, int spp, uint64_t see
         if ((rc = ensure(s->dev.accum, s->dev.accum_cap, 3 * npix))) return rc;
         HIP_TRY(hipMemsetAsync(s->dev.accum, 0, 3 * npix * sizeof(uint32_t), st));
     }
-    HIP_TRY(hipMemsetAsync(s->dev.counters, 0, 8 * sizeof(unsigned long long), st));
+    if (!more) HIP_TRY(hipMemsetAsync(s->dev.counters, 0, 8 * sizeof(unsigned long long), st));
 
     // the vector-ALU kernels are compiled for Main.hs only: a Talk.hs scene always takes the matrix-core kernels
     const bool use_mfma = g_use_mfma || s->talk;
@@ -1732,6 +1744,11 @@ int rt_render_device(rt_scene *s, int w, int h, int depth, int spp, uint64_t see
     return RT_OK;
 }
 
+int rt_render_device(rt_scene *s, int w, int h, int depth, int spp, uint64_t seed, int row0, int nrows,
+                     void *d_rgba, void *d_hit_id, void *stream) {
+    return render_rows(s, w, h, depth, spp, seed, row0, nrows, d_rgba, d_hit_id, stream, false);
+}
+
 int rt_render(rt_scene *s, int w, int h, int depth, int spp, uint64_t seed, int row0, int nrows,
               uint8_t *rgba_out, int32_t *hit_id_out) {
     if (!s) { set_error("rt_render: scene is NULL"); return RT_ERR_ARG; }
@@ -1743,13 +1760,46 @@ int rt_render(rt_scene *s, int w, int h, int depth, int spp, uint64_t seed, int 
     if (npix == 0) return RT_OK;
     if ((rc = ensure(s->dev.rgba, s->dev.rgba_cap, 4 * npix))) return rc;
     if ((rc = ensure(s->dev.hit_out, s->dev.hit_out_cap, npix))) return rc;
-    rc = rt_render_device(s, w, h, depth, spp, seed, row0, nrows, rgba_out ? s->dev.rgba : nullptr, s->dev.hit_out, g_stream);
-    if (rc == RT_OK) {
-        if (rgba_out && !hip_ok(hipMemcpyAsync(rgba_out, s->dev.rgba, 4 * npix, hipMemcpyDeviceToHost, g_stream), "hipMemcpyAsync")) rc = RT_ERR_HIP;
-        if (rc == RT_OK && hit_id_out && !hip_ok(hipMemcpyAsync(hit_id_out, s->dev.hit_out, npix * sizeof(int32_t), hipMemcpyDeviceToHost, g_stream), "hipMemcpyAsync")) rc = RT_ERR_HIP;
-        if (!hip_ok(hipStreamSynchronize(g_stream), "hipStreamSynchronize")) rc = RT_ERR_HIP;
+    // The frame is enqueued as up to RT_HOST_BANDS_MAX row bands of at least ~2 Mi pixels; band k's copy to the
+    // caller's memory runs on its own stream behind the render of band k+1, so only the last band's copy is exposed.
+    // Into rt_host_alloc'ed (page-locked) memory the copies are DMA at PCIe rate; into pageable memory they stage
+    // through the runtime's bounce buffers and block this thread, which is why every band is enqueued first.
+    int nb = (int)(npix >> 21);
+    if (const char *e = getenv("RT_HOST_BANDS")) nb = atoi(e);
+    nb = nb < 1 ? 1 : (nb > RT_HOST_BANDS_MAX ? RT_HOST_BANDS_MAX : nb);
+    int brows = (nrows + nb - 1) / nb;
+    brows = (brows + RT_TILE_H - 1) / RT_TILE_H * RT_TILE_H;
+    int used = 0;
+    for (int r = 0; r < nrows && rc == RT_OK; r += brows, ++used) {
+        const int rows = nrows - r < brows ? nrows - r : brows;
+        const size_t off = (size_t)r * (size_t)w;
+        rc = render_rows(s, w, h, depth, spp, seed, row0 + r, rows, rgba_out ? s->dev.rgba + 4 * off : nullptr,
+                         s->dev.hit_out + off, g_stream, r > 0);
+        if (rc == RT_OK && !hip_ok(hipEventRecord(g_band_done[used], g_stream), "hipEventRecord")) rc = RT_ERR_HIP;
     }
+    int band = 0;
+    for (int r = 0; r < nrows && rc == RT_OK; r += brows, ++band) {
+        const int rows = nrows - r < brows ? nrows - r : brows;
+        const size_t off = (size_t)r * (size_t)w, n = (size_t)rows * (size_t)w;
+        if (!hip_ok(hipStreamWaitEvent(g_copy_stream, g_band_done[band], 0), "hipStreamWaitEvent")) { rc = RT_ERR_HIP; break; }
+        if (rgba_out && !hip_ok(hipMemcpyAsync(rgba_out + 4 * off, s->dev.rgba + 4 * off, 4 * n, hipMemcpyDeviceToHost, g_copy_stream), "hipMemcpyAsync")) rc = RT_ERR_HIP;
+        if (rc == RT_OK && hit_id_out && !hip_ok(hipMemcpyAsync(hit_id_out + off, s->dev.hit_out + off, n * sizeof(int32_t), hipMemcpyDeviceToHost, g_copy_stream), "hipMemcpyAsync")) rc = RT_ERR_HIP;
+    }
+    // always drain both streams, also after an error: nothing may still be writing the caller's buffers on return
+    if (!hip_ok(hipStreamSynchronize(g_copy_stream), "hipStreamSynchronize") && rc == RT_OK) rc = RT_ERR_HIP;
+    if (!hip_ok(hipStreamSynchronize(g_stream), "hipStreamSynchronize") && rc == RT_OK) rc = RT_ERR_HIP;
     return rc;
+}
+
+void *rt_host_alloc(size_t bytes) {
+    if (ensure_init() != RT_OK) return nullptr;
+    void *p = nullptr;
+    if (!hip_ok(hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault), "hipHostMalloc")) return nullptr;
+    return p;
+}
+
+void rt_host_free(void *p) {
+    if (p) (void)hipHostFree(p);
 }
 
 int rt_synchronize(void) {

@@ -284,9 +284,10 @@ def test_fuzzed_scenes_against_oracle(gpu_lib):
         assert f"{n} scenes (seed 42" in r.stdout and "), 0 with a mismatch" in r.stdout
 
 
-def test_band_larger_than_one_chunk(gpu_lib):
+def test_band_larger_than_one_chunk(gpu_lib, monkeypatch):
     """A band of more than 16 Mi pixels is rendered in chunks of rows (rt_render_device): rows on both sides of the chunk
     boundary, and the last ragged chunk, against the oracle; a mirror scene too (its chunks are a quarter of the size)."""
+    monkeypatch.setenv("RT_HOST_BANDS", "1")      # rt_render would otherwise cut the frame into copy bands smaller than a chunk
     world, lights = scenes.default_scene()
     w, h = 16384, 4000
     sc = api.Scene(world, lights)
@@ -319,3 +320,51 @@ def test_two_live_scenes_interleaved(gpu_lib):
             ref = orc.render(w, h)
             assert (hit == ref["hit_id"]).all() and (rgba[:, :, :3] == ref["rgb"]).all()
     a.close(); b.close()
+
+
+def test_host_render_copy_bands_and_page_locked_buffers(gpu_lib, monkeypatch):
+    """rt_render enqueues the frame as row bands whose copies to the caller's memory overlap the next band's render:
+    every band count gives the same bytes, into pageable and into rt_host_alloc'ed memory, with either output alone,
+    with supersampling and with a reflective scene, and the statistics describe the whole frame."""
+    world, lights = scenes.synthetic(ntri=600, ncuboid=60)
+    sc = api.Scene(world, lights)
+    w, h = 1000, 531                                   # ragged: 531 rows are not a multiple of the 8-row tiles
+    monkeypatch.setenv("RT_HOST_BANDS", "1")
+    ref_rgba, ref_hit = sc.render(w, h)
+    one = sc.stats()
+    ref4_rgba, ref4_hit = sc.render(w, h, spp=4, seed=7)
+    osc = ob.OracleScene(world, lights)
+    ref = osc.render(w, h, row0=300, nrows=8, nthreads=16)
+    assert (ref_hit[300:308] == ref["hit_id"]).all() and (ref_rgba[300:308, :, :3] == ref["rgb"]).all()
+    pin_rgba, pin_hit = api.host_buffer((h, w, 4), np.uint8), api.host_buffer((h, w), np.int32)
+    for bands in ("2", "3", "5", "8", "100"):
+        monkeypatch.setenv("RT_HOST_BANDS", bands)
+        rgba, hit = sc.render(w, h)
+        st = sc.stats()
+        assert (rgba == ref_rgba).all() and (hit == ref_hit).all(), bands
+        # (the exact-evaluation count depends on which shadow rays share a wave: an occluded ray stops early)
+        assert st["primary_rays"] == w * h and st["shadow_rays"] == one["shadow_rays"]
+        assert abs(st["exact_evals"] - one["exact_evals"]) <= one["exact_evals"] // 100
+        pin_rgba[:] = 0; pin_hit[:] = 0
+        sc.render(w, h, out_rgba=pin_rgba, out_hit=pin_hit)
+        assert (pin_rgba == ref_rgba).all() and (pin_hit == ref_hit).all(), bands
+        rgba, none = sc.render(w, h, want_hit=False)
+        assert none is None and (rgba == ref_rgba).all()
+        none, hit = sc.render(w, h, want_rgba=False)
+        assert none is None and (hit == ref_hit).all()
+        rgba, hit = sc.render(w, h, spp=4, seed=7)
+        assert (rgba == ref4_rgba).all() and (hit == ref4_hit).all(), bands
+        rgba, hit = sc.render(w, h, row0=77, nrows=201)
+        assert (rgba == ref_rgba[77:278]).all() and (hit == ref_hit[77:278]).all(), bands
+    sc.close()
+    world, lights = scenes.mirror_room()
+    sc = api.Scene(world, lights)
+    monkeypatch.setenv("RT_HOST_BANDS", "1")
+    ref_rgba, ref_hit = sc.render(300, 200, depth=4)
+    monkeypatch.setenv("RT_HOST_BANDS", "4")
+    rgba, hit = sc.render(300, 200, depth=4)
+    assert (rgba == ref_rgba).all() and (hit == ref_hit).all()
+    sc.close()
+    monkeypatch.delenv("RT_HOST_BANDS")
+    with pytest.raises(ValueError):
+        api.Scene(*scenes.stacked_cubes()).render(64, 64, out_rgba=np.zeros((64, 64, 3), np.uint8))

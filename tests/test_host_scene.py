@@ -161,6 +161,19 @@ def test_render_without_a_gpu_fails_loudly():
     sc.close()
 
 
+def test_page_locked_allocator_without_a_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    L = _lib.lib()
+    assert not L.rt_host_alloc(4096) and b"no HIP device" in L.rt_last_error()
+    L.rt_host_free(None)                                   # freeing NULL is a no-op
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        api.host_buffer((4, 4), np.uint8)
+    with pytest.raises(ValueError, match="output array"):    # shape is checked before any device work
+        api.Scene(*scenes.planes()).render(16, 16, out_hit=np.zeros((16, 16), np.int64))
+
+
 def test_cpp_host_mirror_builds_and_fails_loudly_without_gpu(tmp_path):
     """include/raytrace.hpp + examples/main.cpp (the reference's `main`) compile against the C ABI."""
     import subprocess

@@ -1,16 +1,28 @@
 #!/usr/bin/env python3
-"""PCIe-inclusive timing of rt_render (host buffers) on the benchmark frame, for DESIGN.md §8 (never bench.py's value)."""
+"""PCIe-inclusive timing of rt_render (host buffers) on the benchmark frame, for DESIGN.md §8 (never bench.py's value).
+
+Usage: host_render_timing.py [bands ...]   -- RT_HOST_BANDS values to try (default: the library's own choice)
+Reports pageable (numpy) and page-locked (rt_host_alloc) destinations, buffers allocated once and reused."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
 from raytrace_amd import api, scenes, _lib
 _lib.check(_lib.lib().rt_init(0))
 world, lights = scenes.synthetic()
 sc = api.Scene(world, lights)
 w, h = 3840, 2160
-sc.render(w, h)
-ts = []
-for _ in range(5):
-    t0 = time.perf_counter(); sc.render(w, h); ts.append(time.perf_counter() - t0)
-st = sc.stats()
-print(f"rt_render host buffers {w}x{h}: min {min(ts)*1e3:.2f} ms, median {sorted(ts)[2]*1e3:.2f} ms per frame "
-      f"({w*h/min(ts)/1e6:.0f} Mrays/s); kernels {st['ms_total']:.2f} ms")
+ref_rgba, ref_hit = sc.render(w, h)
+dests = {"pageable": (np.zeros((h, w, 4), np.uint8), np.zeros((h, w), np.int32)),
+         "page-locked": (api.host_buffer((h, w, 4), np.uint8), api.host_buffer((h, w), np.int32))}
+for bands in (sys.argv[1:] or [""]):
+    if bands:
+        os.environ["RT_HOST_BANDS"] = bands
+    for name, (rgba, hit) in dests.items():
+        rgba[:] = 0; hit[:] = 0
+        ts = []
+        for _ in range(6):
+            t0 = time.perf_counter(); sc.render(w, h, out_rgba=rgba, out_hit=hit); ts.append(time.perf_counter() - t0)
+        st = sc.stats()
+        same = bool((rgba == ref_rgba).all() and (hit == ref_hit).all())
+        print(f"rt_render {w}x{h} -> {name:11s} bands={bands or 'auto'}: min {min(ts)*1e3:.2f} ms, median {sorted(ts)[3]*1e3:.2f} ms "
+              f"({w*h/min(ts)/1e6:.0f} Mrays/s); kernels {st['ms_total']:.2f} ms; primary rays {st['primary_rays']}; same as first render: {same}", flush=True)
