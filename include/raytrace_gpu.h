@@ -56,14 +56,16 @@ typedef enum {
 typedef struct {
     uint64_t primary_rays;       /* w * nrows * spp                                           */
     uint64_t shadow_rays;        /* shadow rays actually cast (hit pixel, L.N > 0), all lights */
-    uint64_t tri_tests;          /* ray x triangle  filter tests executed (brute force)        */
-    uint64_t rect_tests;         /* ray x rectangle filter tests executed                      */
+    uint64_t tri_tests;          /* ray x triangle  pairs decided (rays x triangles; most through a block's cone) */
+    uint64_t rect_tests;         /* ray x rectangle pairs decided                               */
     uint64_t exact_evals;        /* FP64 exact leaf evaluations (candidates of the filter)     */
     double   ms_primary;         /* HIP-event time of k_primary (nearest hit)                  */
     double   ms_setup;           /* ... of k_setup (exact hit records + shadow-job queues)     */
     double   ms_shadow;          /* ... of k_shadow_mfma / k_shadow (shadow rays)               */
     double   ms_final;           /* ... of k_final (Phong + RGBA8 store)                       */
     double   ms_total;           /* first launch to last kernel end                            */
+    uint64_t mfma_blocks;        /* (wave of 256 rays) x (block of 32 leaves) pairs the matrix-core kernels scanned:
+                                    8 MFMAs each; the others were skipped by the block-cone test  */
 } rt_stats;
 
 /* ---- library / device ------------------------------------------------------------------- */
@@ -133,6 +135,10 @@ int  rt_scene_get_filter_record(const rt_scene *, int apex, int leaf, float out[
  * = 2^10 (a_x, a_y, a_z, margin - cos theta) of the leaf's bounding cone as hi/mid pairs (rt_types.h).  Returns
  * the leaf's position in the stream. */
 int  rt_scene_get_mfma_row(const rt_scene *, int apex, int leaf, uint16_t out[8]);
+/* Bounding cone of block `block` (32 consecutive stream positions) of that apex's stream: {axis xyz, cos T, sin T,
+ * 0, 0, 0}; cos T = 1e30 / -1e30 with a zero axis = a block no ray / every ray has to look at.  A wave skips the
+ * block when the cone misses the bounding cone of its 256 rays.  Returns the number of blocks in the stream. */
+int  rt_scene_get_block_cone(const rt_scene *, int apex, int block, float out[8]);
 /* Guard chain of `leaf`: writes up to cap boxes {x0,y0,z0,x1,y1,z1}, innermost first; returns the count. */
 int  rt_scene_get_guards(const rt_scene *, int leaf, double *out, int cap);
 /* fixedCamera w h: out = {scaleX, scaleY, dX, dY, d}                      Main.hs:506-527 */

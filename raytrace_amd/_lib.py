@@ -19,7 +19,8 @@ class rt_material(C.Structure):
 class rt_stats(C.Structure):
     _fields_ = [("primary_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("tri_tests", C.c_uint64),
                 ("rect_tests", C.c_uint64), ("exact_evals", C.c_uint64), ("ms_primary", C.c_double),
-                ("ms_setup", C.c_double), ("ms_shadow", C.c_double), ("ms_final", C.c_double), ("ms_total", C.c_double)]
+                ("ms_setup", C.c_double), ("ms_shadow", C.c_double), ("ms_final", C.c_double), ("ms_total", C.c_double),
+                ("mfma_blocks", C.c_uint64)]
 
 
 # every symbol include/raytrace_gpu.h declares: name -> (restype, argtypes)
@@ -52,6 +53,7 @@ SYMBOLS = {
     "rt_scene_prepare_host": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "rt_scene_get_filter_record": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "rt_scene_get_mfma_row": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_uint16)]),
+    "rt_scene_get_block_cone": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "rt_scene_get_guards": (C.c_int, [C.c_void_p, C.c_int, _D3, C.c_int]),
     "rt_camera_params": (C.c_int, [C.c_int, C.c_int, _D3]),
     "rt_render": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int,

@@ -78,7 +78,8 @@ struct RenderParams {
     const GenRec *gen_sph;
     const int32_t *sph_gid;
     const uint16_t *mf_rows;        // MFMA row blocks, per apex (rt_types.h)
-    const int32_t *mf_gid;          // MFMA stream position -> leaf index
+    const int32_t *mf_gid;          // MFMA stream position -> leaf index, per apex
+    const float *mf_cone;           // bounding cone of every block of the stream, per apex (rt_scene.cpp: block_cone)
     const FilterRec *mf_rec;        // FP32 records in MFMA stream order, per apex (c[14] = kind, c[15] = leaf index)
     unsigned long long *counters;   // [0] shadow rays cast, [1] exact evals (primary), [2] exact evals (shadow)
     int32_t *hit_id;                // band-local output, indexed out_off + pix
@@ -101,6 +102,7 @@ struct RenderParams {
     double eps;
     int ntri, nrect, nsph, nlights, nleaves, npoint;
     int mf_groups;                  // blocks of MF_LEAVES planar leaves per apex (+ 2 of padding)
+    int cull;                       // 0: every wave scans every block (RT_CULL=0)
     int w, h;
     int row0, nrows;                // this chunk: first absolute image row, rows
     long long out_off;              // index of the chunk's first pixel inside the band-local outputs
@@ -572,8 +574,16 @@ __global__ void __launch_bounds__(RT_SETUP_THREADS) k_setup(const RenderParams P
     // shadow jobs of the block per light: per-wave counts, then ONE returning atomic per (block, light)
     __shared__ unsigned s_cnt[32][RT_SETUP_THREADS / 64];
     __shared__ unsigned s_base[32];
-    const int pix = (int)(blockIdx.x * RT_SETUP_THREADS + threadIdx.x);
-    const bool act = (unsigned)pix < num_slots(P);
+    // level 0: a block takes a 32 x 16 pixel tile, so that the shadow rays it queues (256 consecutive entries make one
+    // wave of k_shadow_mfma) leave from neighbouring pixels and form a narrow bundle; bounce levels: slots in order
+    int pix = (int)(blockIdx.x * RT_SETUP_THREADS + threadIdx.x);
+    bool act = (unsigned)pix < num_slots(P);
+    if (!P.rays) {
+        const int tx = (int)blockIdx.x % P.tiles_x, ty = (int)blockIdx.x / P.tiles_x;
+        const int x = tx * 32 + (int)(threadIdx.x & 31), y = ty * (RT_SETUP_THREADS / 32) + (int)(threadIdx.x >> 5);
+        act = x < P.w && y < P.nrows;
+        pix = act ? y * P.w + x : 0;
+    }
     const int id = act ? P.hit_id[P.out_off + pix] : -1;
     HitRec H = {0, 0, 0, 0, 0, 0};
     RayD ray = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -922,15 +932,18 @@ __device__ __forceinline__ void q_drain(WaveQueues &Q, unsigned keep, S1 &&stage
         if (have) exact(entry);
     }
 }
-// Scans `groups` blocks (a multiple of 3; 32 x i32x4 per block, two blocks of padding follow the last one) starting
-// at the wave-uniform address `base`.  Lane (c, h) owns ray column c and 16 of the 32 leaves of every block.
+// Scans the n blocks (a multiple of 3) whose indices are list[0..n-1]; list[n] and list[n + 1] must name a block too (the
+// prefetch runs two blocks ahead).  Blocks are 32 x i32x4 at the wave-uniform address `base`.  Lane (c, h) owns ray
+// column c and 16 of the 32 leaves of every block.
 // The A fragments live in a ring of three registers (in use, next, in flight) and the loop body is written out three
 // times, so a fragment is loaded straight into the register it is used from: no copies, two blocks of prefetch.
 template <class S1, class EX>
-__device__ __forceinline__ void mfma_scan(const i32x4 *base, int groups, const f16x8 (&B)[8], WaveQueues &Q, int c, int h,
+__device__ __forceinline__ void mfma_scan(const i32x4 *base, const uint16_t *list, int n, const f16x8 (&B)[8], WaveQueues &Q, int c, int h,
                                           S1 &&stage1, EX &&exact) {
+    auto idx = [&](int k) { return __builtin_amdgcn_readfirstlane((int)list[k]); };      // the same for every lane
     auto blk = [&](int g) { return (base + (size_t)g * 32)[c]; };      // uniform base + lane offset
-    i32x4 a0 = blk(0), a1 = blk(1), a2;
+    int g0 = idx(0), g1 = idx(1), g2;
+    i32x4 a0 = blk(g0), a1 = blk(g1), a2;
     f32x16 acc = mfma0(a0, B[0]);
     // one block: 8 steps on fragment a_use; the last step issues the first MFMA of the next block (fragment a_nxt)
     auto block = [&](const i32x4 &a_use, const i32x4 &a_nxt, int g) {
@@ -972,10 +985,52 @@ __device__ __forceinline__ void mfma_scan(const i32x4 *base, int groups, const f
             }
         }
     };
-    for (int g = 0; g < groups; g += 3) {
-        a2 = blk(g + 2); block(a0, a1, g);
-        a0 = blk(g + 3); block(a1, a2, g + 1);
-        a1 = blk(g + 4); block(a2, a0, g + 2);
+    for (int k = 0; k < n; k += 3) {
+        g2 = idx(k + 2); a2 = blk(g2); block(a0, a1, g0);
+        g0 = idx(k + 3); a0 = blk(g0); block(a1, a2, g1);
+        g1 = idx(k + 4); a1 = blk(g1); block(a2, a0, g2);
+    }
+}
+// Bounding cone of a wave's rays: unit axis and the cosine / sine of the half-angle, both already on the wide side.
+struct Bundle { float x, y, z, cr, sr; bool cull; };
+__device__ __forceinline__ Bundle make_bundle(float x, float y, float z, float cr) {
+    cr -= 1e-6f;
+    Bundle U = {x, y, z, cr, __builtin_sqrtf(__builtin_fmaxf(0.f, (1.f - cr) * (1.f + cr))), false};
+    U.cull = cr >= 0.1f;                // a NaN or a bundle wider than 84 degrees: look at every block
+    return U;
+}
+// The first stage over all `groups` blocks of one apex: every lane tests one block's bounding cone (`cones`, 8 floats
+// per block, rt_scene.cpp: block_cone) against the wave's bundle; the blocks that may hold a leaf for some ray of the
+// wave go to `list` (LDS, RT_LIST_CAP + 8 entries), which mfma_scan works off RT_LIST_CAP blocks at a time.  Block
+// `groups` is the first padding block (never rows): it fills the list up to a multiple of 3 and feeds the prefetch.
+constexpr int RT_LIST_CAP = 192;
+template <class S1, class EX>
+__device__ __forceinline__ void culled_scan(const i32x4 *base, const float *cones, int groups, const Bundle &U, uint16_t *list,
+                                            const f16x8 (&B)[8], WaveQueues &Q, int c, int h, unsigned &nblocks, S1 &&stage1, EX &&exact) {
+    const int lane = (int)(threadIdx.x & 63u);
+    int n = 0;                                                    // wave-uniform
+    for (int g0 = 0; g0 < groups; g0 += 64) {
+        const int g = g0 + lane;
+        bool pass = g < groups;
+        if (pass && U.cull) {
+            const float4 k = reinterpret_cast<const float4 *>(cones)[2 * g];
+            const float sT = cones[8 * g + 4];
+            const float thr = __builtin_fmaf(U.cr, k.w, -(U.sr * sT)) - 4e-6f;
+            pass = __builtin_fmaf(U.x, k.x, __builtin_fmaf(U.y, k.y, U.z * k.z)) >= thr;
+        }
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
+        if (pass) list[n + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = (uint16_t)g;
+        n += (int)__popcll(m);
+        if (n > RT_LIST_CAP - 64 || g0 + 64 >= groups) {
+            nblocks += (unsigned)n;
+            if (n > 0) {
+                if (lane < 5) list[n + lane] = (uint16_t)groups;  // up to a multiple of 3, then two blocks of prefetch
+                __builtin_amdgcn_wave_barrier();
+                mfma_scan(base, list, (n + 2) / 3 * 3, B, Q, c, h, stage1, exact);
+                __builtin_amdgcn_wave_barrier();
+            }
+            n = 0;
+        }
     }
     q_drain(Q, 0u, stage1, exact);
 }
@@ -1011,8 +1066,10 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_shadow_mfma(const RenderParams P) {
     __shared__ int s_own[RT_WAVES_PER_BLOCK][256];
     __shared__ uint32_t s_occ[RT_WAVES_PER_BLOCK][256];
     __shared__ uint32_t s_q1[RT_WAVES_PER_BLOCK][RT_Q1_CAP], s_q2[RT_WAVES_PER_BLOCK][RT_Q2_CAP];
+    __shared__ uint16_t s_list[RT_WAVES_PER_BLOCK][RT_LIST_CAP + 8];
     const int wv = (int)(threadIdx.x >> 6);
     f16x8 B[8];
+    float ux[8], uy[8], uz[8];              // unit directions of the lane's 8 rays (0: no ray), for the bundle cone
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
         const unsigned j = wave * 256u + (unsigned)(b * 32 + c);
@@ -1036,15 +1093,37 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_shadow_mfma(const RenderParams P) {
             s_occ[wv][e] = ok ? 0u : 1u;          // a ray that does not exist counts as occluded: never lit
         }
         B[b] = ray_fragment(dx, dy, dz, ok, h);
+        const float rn = ok ? __builtin_amdgcn_rsqf(__builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, dz * dz))) : 0.f;
+        ux[b] = dx * rn; uy[b] = dy * rn; uz[b] = dz * rn;
     }
     __builtin_amdgcn_wave_barrier();
+    // bundle cone: axis = mean direction (both lane halves hold the same rays), half-angle = the farthest ray
+    float ax = 0.f, ay = 0.f, az = 0.f;
+#pragma unroll
+    for (int b = 0; b < 8; ++b) { ax += ux[b]; ay += uy[b]; az += uz[b]; }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) { ax += __shfl_xor(ax, o); ay += __shfl_xor(ay, o); az += __shfl_xor(az, o); }
+    const float an = __builtin_amdgcn_rsqf(__builtin_fmaf(ax, ax, __builtin_fmaf(ay, ay, az * az)));
+    ax *= an; ay *= an; az *= an;
+    float cmin = 1.f;
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        const float dt = __builtin_fmaf(ax, ux[b], __builtin_fmaf(ay, uy[b], az * uz[b]));
+        const bool some = (ux[b] != 0.f) | (uy[b] != 0.f) | (uz[b] != 0.f);
+        cmin = some ? __builtin_fminf(cmin, dt) : cmin;
+        if (dt != dt) cmin = dt;                                   // a NaN direction: no culling for this wave
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) { const float t = __shfl_xor(cmin, o); cmin = (t != t || cmin != cmin) ? __builtin_nanf("") : __builtin_fminf(cmin, t); }
+    Bundle U = make_bundle(ax, ay, az, cmin);
+    U.cull = U.cull && P.cull != 0;
     const size_t ro = (size_t)__builtin_amdgcn_readfirstlane(Lt.rec_offset);
     const size_t gstride = (size_t)(P.mf_groups + 2);
     const i32x4 *blocks = reinterpret_cast<const i32x4 *>(P.mf_rows) + ro * gstride * 32;
     const FilterRec *recs = P.mf_rec + ro * gstride * MF_LEAVES;
-    unsigned nexact = 0;
+    unsigned nexact = 0, nblocks = 0;
     WaveQueues Q = {s_q1[wv], s_q2[wv], 0u, 0u};
-    mfma_scan(blocks, P.mf_groups, B, Q, c, h,
+    culled_scan(blocks, P.mf_cone + ro * gstride * 8, P.mf_groups, U, s_list[wv], B, Q, c, h, nblocks,
         [&](uint32_t entry) -> bool {           // FP32 record test of one (ray, leaf) pair
             const int e = (int)(entry & 255u);
             const FilterRec *R = recs + (entry >> 8);
@@ -1101,6 +1180,7 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_shadow_mfma(const RenderParams P) {
         if (nd[r]) atomicOr(&P.lit[pix[r]], 1u << pl);
     for (int o = 32; o > 0; o >>= 1) nexact += __shfl_down(nexact, o);
     if (lane == 0 && nexact) atomicAdd(&P.counters[2], (unsigned long long)nexact);
+    if (lane == 0) atomicAdd(&P.counters[6], (unsigned long long)nblocks);
 }
 
 // Kernel 1 on the matrix cores.  One wave = 32 x 8 pixel tile; ray block b = tile row b, column c = lane & 31.
@@ -1110,6 +1190,7 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_primary_mfma(const RenderParams P) {
     __shared__ unsigned long long s_bt[RT_WAVES_PER_BLOCK][256];
     __shared__ int s_bid[RT_WAVES_PER_BLOCK][256];
     __shared__ uint32_t s_q1[RT_WAVES_PER_BLOCK][RT_Q1_CAP], s_q2[RT_WAVES_PER_BLOCK][RT_Q2_CAP];
+    __shared__ uint16_t s_list[RT_WAVES_PER_BLOCK][RT_LIST_CAP + 8];
     const int wv = (int)(threadIdx.x >> 6);
     const int wave = (int)(blockIdx.x * RT_WAVES_PER_BLOCK) + wv;
     const int lane = (int)(threadIdx.x & 63), c = lane & 31, h = lane >> 5;
@@ -1133,9 +1214,28 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_primary_mfma(const RenderParams P) {
     }
     __builtin_amdgcn_wave_barrier();
     const i32x4 *blocks = reinterpret_cast<const i32x4 *>(P.mf_rows);          // apex 0 = the eye
-    unsigned nexact = 0;
+    // bundle cone of the tile: axis through its centre, half-angle to the farthest corner (the directions inside a cone
+    // cut the image plane in a convex region, so the corners decide); one pixel of slack all round covers the jitter
+    Bundle U;
+    {
+        const float cx = (float)(P.cam.scaleX * ((double)x0 + 15.5) + P.cam.dX);
+        const float cy = (float)(P.cam.scaleY * ((double)(P.row0 + ly0) + 3.5) + P.cam.dY);
+        const float hx = (float)(17.5 * fabs(P.cam.scaleX)), hy = (float)(5.5 * fabs(P.cam.scaleY));
+        const float cn = __builtin_amdgcn_rsqf(__builtin_fmaf(cx, cx, __builtin_fmaf(cy, cy, dzf * dzf)));
+        const float ax = cx * cn, ay = cy * cn, az = dzf * cn;
+        float cmin = 1.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float qx = cx + ((k & 1) ? hx : -hx), qy = cy + ((k & 2) ? hy : -hy);
+            const float qn = __builtin_amdgcn_rsqf(__builtin_fmaf(qx, qx, __builtin_fmaf(qy, qy, dzf * dzf)));
+            cmin = __builtin_fminf(cmin, (ax * qx + ay * qy + az * dzf) * qn);
+        }
+        U = make_bundle(ax, ay, az, cmin);
+        U.cull = U.cull && P.cull != 0;
+    }
+    unsigned nexact = 0, nblocks = 0;
     WaveQueues Q = {s_q1[wv], s_q2[wv], 0u, 0u};
-    mfma_scan(blocks, P.mf_groups, B, Q, c, h,
+    culled_scan(blocks, P.mf_cone, P.mf_groups, U, s_list[wv], B, Q, c, h, nblocks,
         [&](uint32_t entry) -> bool {           // FP32 record test of one (pixel, leaf) pair
             const int e = (int)(entry & 255u);
             const FilterRec *R = P.mf_rec + (entry >> 8);                         // apex 0 = the eye
@@ -1223,6 +1323,7 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_primary_mfma(const RenderParams P) {
         if (act[r]) P.hit_id[P.out_off + (long long)(ly0 + 4 * h + r) * P.w + x] = mid[r];
     for (int o = 32; o > 0; o >>= 1) nexact += __shfl_down(nexact, o);
     if (lane == 0 && nexact) atomicAdd(&P.counters[1], (unsigned long long)nexact);
+    if (lane == 0) atomicAdd(&P.counters[6], (unsigned long long)nblocks);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1477,6 +1578,8 @@ hipEvent_t g_band_done[RT_HOST_BANDS_MAX] = {};
 int g_device = -1;
 // RT_FILTER=valu selects the scalar-record VALU kernels (k_primary / k_shadow) instead of the matrix-core ones
 bool g_use_mfma = true;
+// RT_CULL=0: every wave scans every block of the leaf stream (the plain brute-force scan, for comparison)
+bool g_cull = true;
 
 bool hip_ok(hipError_t e, const char *what) {
     if (e == hipSuccess) return true;
@@ -1524,6 +1627,7 @@ int prepare(rt_scene &s, int w, int h) {
         if ((rc = upload(s.dev.sph_gid, s.sph_gid))) return rc;
         if ((rc = upload(s.dev.mf_rows, s.mf_rows))) return rc;
         if ((rc = upload(s.dev.mf_gid, s.mf_gid))) return rc;
+        if ((rc = upload(s.dev.mf_cone, s.mf_cone))) return rc;
         if ((rc = upload(s.dev.mf_rec, s.mf_rec))) return rc;
         if (s.reflective) {
             if ((rc = upload(s.dev.gen_sph, s.gen_sph))) return rc;
@@ -1579,6 +1683,8 @@ int rt_init(int device) {
     g_device = device;
     const char *f = getenv("RT_FILTER");
     g_use_mfma = !(f && std::string(f) == "valu");
+    const char *cl = getenv("RT_CULL");
+    g_cull = !(cl && std::string(cl) == "0");
     return RT_OK;
 }
 
@@ -1586,7 +1692,7 @@ void rt_scene_destroy(rt_scene *s) {
     if (!s) return;
     DeviceScene &d = s->dev;
     void *ptrs[] = {d.leaves, d.aux, d.guards, d.mats, d.lights, d.tri_rec, d.rect_rec, d.tri_gid, d.rect_gid,
-                    d.counters, d.qcount, d.hit_id, d.accum, d.rgba, d.hit_out, d.hitrec, d.queue, d.lit, d.gen_tri, d.gen_rect, d.sph_rec, d.gen_sph, d.sph_gid, d.mf_rows, d.mf_gid, d.mf_rec};
+                    d.counters, d.qcount, d.hit_id, d.accum, d.rgba, d.hit_out, d.hitrec, d.queue, d.lit, d.gen_tri, d.gen_rect, d.sph_rec, d.gen_sph, d.sph_gid, d.mf_rows, d.mf_gid, d.mf_rec, d.mf_cone};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (int k = 0; k < 8; ++k) {
         if (d.lvl_rays[k]) (void)hipFree(d.lvl_rays[k]);
@@ -1660,6 +1766,7 @@ static int render_rows(rt_scene *s, int w, int h, int depth, int spp, uint64_t s
     P.gen_tri = s->dev.gen_tri; P.gen_rect = s->dev.gen_rect;
     P.sph_rec = s->dev.sph_rec; P.gen_sph = s->dev.gen_sph; P.sph_gid = s->dev.sph_gid; P.nsph = (int)s->sph_gid.size();
     P.mf_rows = s->dev.mf_rows; P.mf_gid = s->dev.mf_gid; P.mf_rec = s->dev.mf_rec; P.mf_groups = s->mf_groups;
+    P.mf_cone = s->dev.mf_cone; P.cull = g_cull ? 1 : 0;
     P.cam = fixed_camera(w, h);
     P.eps = ray_eps();
     P.ntri = (int)s->tri_gid.size(); P.nrect = (int)s->rect_gid.size();
@@ -1712,7 +1819,9 @@ static int render_rows(rt_scene *s, int w, int h, int depth, int spp, uint64_t s
                 P.next_rays = (lvl + 1 < levels) ? s->dev.lvl_rays[lvl + 1] : nullptr;
                 P.next_count = lvl_count + lvl + 1;
                 P.colour = (levels > 1) ? s->dev.lvl_col[lvl] : nullptr;
-                hipLaunchKernelGGL(k_setup, dim3((unsigned)(((size_t)P.qcap + RT_SETUP_THREADS - 1) / RT_SETUP_THREADS)), dim3(RT_SETUP_THREADS), 0, st, P);
+                const unsigned ublocks = lvl == 0 ? (unsigned)P.tiles_x * (unsigned)((rows + RT_SETUP_THREADS / 32 - 1) / (RT_SETUP_THREADS / 32))
+                                                  : (unsigned)(((size_t)P.qcap + RT_SETUP_THREADS - 1) / RT_SETUP_THREADS);
+                hipLaunchKernelGGL(k_setup, dim3(ublocks), dim3(RT_SETUP_THREADS), 0, st, P);
                 if ((rc = next_event(*s, st, 2))) return rc;
                 if (s->npoint > 0) {
                     if (use_mfma) hipLaunchKernelGGL(k_shadow_mfma, dim3(sblocks, (unsigned)s->npoint), dim3(RT_WAVES_PER_BLOCK * 64), 0, st, P);
@@ -1828,6 +1937,7 @@ int rt_get_stats(rt_scene *s, rt_stats *out) {
         st.tri_tests = (st.primary_rays + st.shadow_rays) * (uint64_t)s->tri_gid.size();
         st.rect_tests = (st.primary_rays + st.shadow_rays) * (uint64_t)s->rect_gid.size();
         st.exact_evals = c[1] + c[2];
+        st.mfma_blocks = c[6];
 #ifdef RT_COUNT_EVENTS
         fprintf(stderr, "[rt] slow-path entries (wave x block) %llu, wave iterations %llu, lane passes of the first stage %llu, exact evals primary %llu shadow %llu\n", c[3], c[4], c[5], c[1], c[2]);
 #endif

@@ -10,6 +10,7 @@
 #define RT_SHADOW_CLIP 0      // must match rt_kernels.hip
 #endif
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <limits>
@@ -401,10 +402,14 @@ static int leaf_polygon(const LeafD &L, double v[4][3]) {
     }
     return 4;
 }
-static void make_cone_row(const LeafD &L, const double A[3], const double dmax[3], uint16_t row[8]) {
+// Bounding cone of a planar leaf seen from the apex: status 0 = axis and cs = cos(theta) hold, 1 = the reference never
+// hits this leaf, 2 = wide or degenerate (every ray is a candidate).
+struct LeafCone { double axis[3]; double cs; int status; };
+static LeafCone leaf_cone(const LeafD &L, const double A[3], const double dmax[3]) {
+    LeafCone C = {{0, 0, 0}, -2.0, 2};
     const Forms F = leaf_forms(L, A, dmax);
-    if (F.status == 1) { const_row(row, -1.0f); return; }        // the reference never hits this leaf (NaN constants)
-    double v[4][3], u[4][3], axis[3] = {0, 0, 0};
+    if (F.status == 1) { C.status = 1; return C; }               // NaN constants
+    double v[4][3], u[4][3];
     const int n = leaf_polygon(L, v);
     bool ok = n > 0;
     for (int k = 0; k < n && ok; ++k) {
@@ -414,10 +419,63 @@ static void make_cone_row(const LeafD &L, const double A[3], const double dmax[3
         ok = std::isfinite(len) && len > 1e-9 * (1.0 + scale);
         for (int i = 0; i < 3 && ok; ++i) u[k][i] = d[i] / len;
     }
-    const double cs = ok ? bounding_cap(u, n, axis) : -2.0;
-    if (!(cs > 0.05)) { const_row(row, 1.0f); return; }           // wide or degenerate: every ray is a candidate
-    for (int i = 0; i < 3; ++i) split_f16(MF_SCALE * axis[i], row[2 * i], row[2 * i + 1]);
-    split_f16(MF_SCALE * (MF_MARGIN - cs * (1.0 - 1e-12)), row[6], row[7]);
+    C.cs = ok ? bounding_cap(u, n, C.axis) : -2.0;
+    C.status = (C.cs > 0.05) ? 0 : 2;
+    return C;
+}
+static void make_cone_row(const LeafCone &C, uint16_t row[8]) {
+    if (C.status == 1) { const_row(row, -1.0f); return; }
+    if (C.status == 2) { const_row(row, 1.0f); return; }
+    for (int i = 0; i < 3; ++i) split_f16(MF_SCALE * C.axis[i], row[2 * i], row[2 * i + 1]);
+    split_f16(MF_SCALE * (MF_MARGIN - C.cs * (1.0 - 1e-12)), row[6], row[7]);
+}
+
+// Stream order of one apex.  The kernels skip a block of 32 rows when the bounding cone of the block misses the
+// bounding cone of a wave's 256 rays, so leaves that lie in the same direction from the apex should share a block:
+// the cone axes are mapped to the unit square (octahedral map) and split at medians, always at a multiple of 32
+// leaves, along the wider of the two coordinates.  Any order gives the same image: the nearest hit is the minimum
+// over (t, leaf index) and a shadow ray only asks whether some leaf occludes.
+static void direction_split(std::vector<int> &idx, const std::vector<double> &u, const std::vector<double> &v, size_t lo, size_t hi) {
+    const size_t n = hi - lo;
+    if (n <= (size_t)MF_LEAVES) return;
+    const size_t half = ((n / 2 + MF_LEAVES / 2) / MF_LEAVES) * MF_LEAVES;
+    if (half == 0 || half >= n) return;
+    double ulo = 2, uhi = -2, vlo = 2, vhi = -2;
+    for (size_t k = lo; k < hi; ++k) {
+        ulo = std::fmin(ulo, u[idx[k]]); uhi = std::fmax(uhi, u[idx[k]]);
+        vlo = std::fmin(vlo, v[idx[k]]); vhi = std::fmax(vhi, v[idx[k]]);
+    }
+    const std::vector<double> &key = (uhi - ulo >= vhi - vlo) ? u : v;
+    std::nth_element(idx.begin() + lo, idx.begin() + lo + half, idx.begin() + hi,
+                     [&](int a, int b) { return key[a] < key[b] || (key[a] == key[b] && a < b); });
+    direction_split(idx, u, v, lo, lo + half);
+    direction_split(idx, u, v, lo + half, hi);
+}
+// Bounding cone of a block of leaf cones, as the kernels read it: {axis xyz, cos T, sin T, 0, 0, 0}; a block passes for
+// a ray bundle (axis r, half-angle rho) when r . axis >= cos(rho) cos T - sin(rho) sin T - margin.  cos T = +-1e30
+// with a zero axis encodes "never" (only padding or never-hit leaves) and "always" (some leaf is wide or degenerate).
+static void block_cone(const LeafCone *C, int n, float out[8]) {
+    for (int k = 0; k < 8; ++k) out[k] = 0.f;
+    double ax[3] = {0, 0, 0};
+    int live = 0;
+    for (int i = 0; i < n; ++i) {
+        if (C[i].status == 2) { out[3] = -1e30f; return; }
+        if (C[i].status == 0) { ++live; for (int k = 0; k < 3; ++k) ax[k] += C[i].axis[k]; }
+    }
+    if (live == 0) { out[3] = 1e30f; return; }
+    const double len = std::sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
+    if (!(len > 1e-6 * live)) { out[3] = -1e30f; return; }
+    for (int k = 0; k < 3; ++k) ax[k] /= len;
+    double T = 0;
+    for (int i = 0; i < n; ++i) {
+        if (C[i].status != 0) continue;
+        const double dt = ax[0] * C[i].axis[0] + ax[1] * C[i].axis[1] + ax[2] * C[i].axis[2];
+        T = std::fmax(T, std::acos(std::fmax(-1.0, std::fmin(1.0, dt))) + std::acos(std::fmax(-1.0, std::fmin(1.0, C[i].cs))));
+    }
+    T = T * (1.0 + 1e-9) + 2e-6;                                  // slack for the FP32 axis and the FP32 test
+    if (!(T < 1.4)) { out[3] = -1e30f; return; }                  // wider than 80 degrees: not worth a test
+    out[0] = (float)ax[0]; out[1] = (float)ax[1]; out[2] = (float)ax[2];
+    out[3] = (float)std::cos(T); out[4] = (float)std::sin(T);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -559,16 +617,18 @@ void build_filter_records(rt_scene &s, int w, int h) {
                 if (std::isfinite(v[k][i])) { lo[i] = std::fmin(lo[i], v[k][i]); hi[i] = std::fmax(hi[i], v[k][i]); }
     }
     const CameraD cam = fixed_camera(w, h);
-    // MFMA stream: the planar leaves in tree order, one row each, 32 per block (see rt_types.h), two blocks of padding
-    s.mf_gid.clear();
-    for (size_t g = 0; g < s.leaves.size(); ++g) if (s.leaves[g].kind != LEAF_SPHERE) s.mf_gid.push_back((int32_t)g);
-    const size_t nplanar = s.mf_gid.size();
-    s.mf_groups = (int)((nplanar + MF_LEAVES - 1) / MF_LEAVES);
+    // MFMA stream: one row per planar leaf, 32 per block (see rt_types.h), in a per-apex order (direction_split), two
+    // blocks of padding; live leaves first (padded to a whole block), then the "always" leaves, then the "never" ones
+    std::vector<int32_t> planar;
+    for (size_t g = 0; g < s.leaves.size(); ++g) if (s.leaves[g].kind != LEAF_SPHERE) planar.push_back((int32_t)g);
+    const size_t nplanar = planar.size();
+    s.mf_groups = (int)((nplanar + MF_LEAVES - 1) / MF_LEAVES) + 1;          // + 1: the padding behind the live leaves
     s.mf_groups = (s.mf_groups + 2) / 3 * 3;               // the scan handles three blocks per loop iteration (padding: never rows)
     const size_t gstride = (size_t)s.mf_groups + 2;
-    s.mf_gid.resize(gstride * MF_LEAVES, -1);
+    s.mf_gid.assign(gstride * (size_t)napex * MF_LEAVES, -1);
     s.mf_rows.assign(gstride * (size_t)napex * 32 * 8, 0);
     s.mf_rec.assign(gstride * (size_t)napex * MF_LEAVES, never_rec());
+    s.mf_cone.assign(gstride * (size_t)napex * 8, 0.f);
     for (FilterRec &r : s.mf_rec) { const int32_t none = -1; std::memcpy(&r.c[15], &none, 4); }
     {
         uint16_t never[8];
@@ -577,16 +637,45 @@ void build_filter_records(rt_scene &s, int w, int h) {
     }
     int apex = 0;
     auto fill = [&](const double A[3], const double dmax[3], double eye_d) {
+        std::vector<LeafCone> cone(nplanar);
+        std::vector<double> cu(nplanar), cv(nplanar);
+        std::vector<int> live, always, never;
         for (size_t k = 0; k < nplanar; ++k) {
-            const LeafD &L = s.leaves[s.mf_gid[k]];
-            make_cone_row(L, A, dmax, &s.mf_rows[((size_t)apex * gstride * MF_LEAVES + k) * 8]);
+            cone[k] = leaf_cone(s.leaves[planar[k]], A, dmax);
+            if (cone[k].status == 0) {
+                const double *a = cone[k].axis;
+                const double l1 = std::fabs(a[0]) + std::fabs(a[1]) + std::fabs(a[2]);
+                double ox = a[0] / l1, oy = a[1] / l1;
+                if (a[2] > 0) {                             // the hemisphere behind the eye's view folds outwards
+                    const double fx = (1.0 - std::fabs(oy)) * (ox >= 0 ? 1.0 : -1.0), fy = (1.0 - std::fabs(ox)) * (oy >= 0 ? 1.0 : -1.0);
+                    ox = fx; oy = fy;
+                }
+                cu[k] = ox; cv[k] = oy;
+                live.push_back((int)k);
+            } else (cone[k].status == 2 ? always : never).push_back((int)k);
+        }
+        direction_split(live, cu, cv, 0, live.size());
+        std::vector<int> order(live);
+        order.resize((live.size() + MF_LEAVES - 1) / MF_LEAVES * MF_LEAVES, -1);
+        order.insert(order.end(), always.begin(), always.end());
+        order.insert(order.end(), never.begin(), never.end());
+        const size_t base = (size_t)apex * gstride * MF_LEAVES;
+        std::vector<LeafCone> ordered(gstride * MF_LEAVES, LeafCone{{0, 0, 0}, -2.0, 1});
+        for (size_t k = 0; k < order.size(); ++k) {
+            if (order[k] < 0) continue;
+            const int32_t gid = planar[order[k]];
+            const LeafD &L = s.leaves[gid];
+            ordered[k] = cone[order[k]];
+            s.mf_gid[base + k] = gid;
+            make_cone_row(ordered[k], &s.mf_rows[(base + k) * 8]);
             // second stage of the matrix-core kernels: the leaf's FP32 record, found by stream position; the two
             // spare floats carry the leaf kind and index (bit patterns)
-            FilterRec &r2 = s.mf_rec[((size_t)apex * gstride) * MF_LEAVES + k];
+            FilterRec &r2 = s.mf_rec[base + k];
             r2 = make_rec(L, A, dmax, eye_d);
             std::memcpy(&r2.c[14], &L.kind, 4);
-            std::memcpy(&r2.c[15], &s.mf_gid[k], 4);
+            std::memcpy(&r2.c[15], &gid, 4);
         }
+        for (size_t g = 0; g < gstride; ++g) block_cone(&ordered[g * MF_LEAVES], MF_LEAVES, &s.mf_cone[((size_t)apex * gstride + g) * 8]);
         for (size_t k = 0; k < ntri; ++k) s.tri_rec[(size_t)apex * ntri + k] = make_rec(s.leaves[s.tri_gid[k]], A, dmax, eye_d);
         for (size_t k = 0; k < nrect; ++k) s.rect_rec[(size_t)apex * nrect + k] = make_rec(s.leaves[s.rect_gid[k]], A, dmax, eye_d);
         for (size_t k = 0; k < nsph; ++k) s.sph_rec[(size_t)apex * nsph + k] = make_sphere_rec(s.leaves[s.sph_gid[k]], A, dmax);
@@ -818,14 +907,22 @@ int rt_scene_get_mfma_row(const rt_scene *s, int apex, int leaf, uint16_t out[8]
     if (!s || !out || leaf < 0 || (size_t)leaf >= s->leaves.size() || apex < 0 || apex > s->npoint || s->rec_w < 0) {
         set_error("rt_scene_get_mfma_row: bad argument (call rt_scene_prepare_host first)"); return RT_ERR_ARG;
     }
-    const size_t gstride = (size_t)s->mf_groups + 2;
+    const size_t gstride = (size_t)s->mf_groups + 2, base = (size_t)apex * gstride * MF_LEAVES;
     for (size_t k = 0; k < gstride * MF_LEAVES; ++k)
-        if (s->mf_gid[k] == leaf) {
-            std::memcpy(out, &s->mf_rows[((size_t)apex * gstride * MF_LEAVES + k) * 8], 16);
+        if (s->mf_gid[base + k] == leaf) {
+            std::memcpy(out, &s->mf_rows[(base + k) * 8], 16);
             return (int)k;
         }
     set_error("rt_scene_get_mfma_row: the leaf has no row (spheres are tested by their own loop)");
     return RT_ERR_ARG;
+}
+
+int rt_scene_get_block_cone(const rt_scene *s, int apex, int block, float out[8]) {
+    if (!s || !out || apex < 0 || apex > s->npoint || s->rec_w < 0 || block < 0 || block >= s->mf_groups + 2) {
+        set_error("rt_scene_get_block_cone: bad argument (call rt_scene_prepare_host first)"); return RT_ERR_ARG;
+    }
+    std::memcpy(out, &s->mf_cone[((size_t)apex * ((size_t)s->mf_groups + 2) + (size_t)block) * 8], 32);
+    return s->mf_groups;
 }
 
 int rt_scene_get_guards(const rt_scene *s, int leaf, double *out, int cap) {

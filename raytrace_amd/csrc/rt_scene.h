@@ -28,6 +28,7 @@ struct DeviceScene {          // device copies (HBM), owned by the scene
     int32_t *sph_gid = nullptr;
     uint16_t *mf_rows = nullptr;     // MFMA row blocks (rt_types.h), per apex
     int32_t *mf_gid = nullptr;
+    float *mf_cone = nullptr;        // per apex and block: {axis xyz, cos T, sin T, 0, 0, 0}
     FilterRec *mf_rec = nullptr;
     unsigned long long *counters = nullptr;  // 8 x u64
     // work buffers, grown on demand
@@ -72,7 +73,8 @@ struct rt_scene {
     std::vector<rt::FilterRec> tri_rec, rect_rec, sph_rec;
     std::vector<rt::GenRec> gen_tri, gen_rect, gen_sph;   // only filled when a material reflects
     std::vector<uint16_t> mf_rows;        // MFMA rows: (1 + npoint) x (mf_groups + 2) blocks of 32 rows x 8 halves
-    std::vector<int32_t> mf_gid;          // MFMA stream position -> leaf index (-1: padding)
+    std::vector<int32_t> mf_gid;          // per apex: MFMA stream position -> leaf index (-1: padding)
+    std::vector<float> mf_cone;           // per apex and block: bounding cone of the block's leaves, 8 floats (rt_scene.cpp: block_cone)
     std::vector<rt::FilterRec> mf_rec;    // FP32 records in MFMA stream order, per apex; c[14] = kind, c[15] = leaf index (bits)
     int mf_groups = 0;
     bool reflective = false;
