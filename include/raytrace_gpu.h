@@ -64,8 +64,9 @@ typedef struct {
     double   ms_shadow;          /* ... of k_shadow_mfma / k_shadow (shadow rays)               */
     double   ms_final;           /* ... of k_final (Phong + RGBA8 store)                       */
     double   ms_total;           /* first launch to last kernel end                            */
-    uint64_t mfma_blocks;        /* (wave of 256 rays) x (block of 32 leaves) pairs the matrix-core kernels scanned:
-                                    8 MFMAs each; the others were skipped by the block-cone test  */
+    uint64_t mfma_blocks_primary; /* (wave of 256 rays) x (block of 32 leaves) pairs k_primary_mfma scanned, 8 MFMAs
+                                     each; the others were skipped by the block-cone test         */
+    uint64_t mfma_blocks_shadow;  /* the same for k_shadow_mfma, all lights                        */
 } rt_stats;
 
 /* ---- library / device ------------------------------------------------------------------- */
@@ -136,8 +137,8 @@ int  rt_scene_get_filter_record(const rt_scene *, int apex, int leaf, float out[
  * the leaf's position in the stream. */
 int  rt_scene_get_mfma_row(const rt_scene *, int apex, int leaf, uint16_t out[8]);
 /* Bounding cone of block `block` (32 consecutive stream positions) of that apex's stream: {axis xyz, cos T, sin T,
- * 0, 0, 0}; cos T = 1e30 / -1e30 with a zero axis = a block no ray / every ray has to look at.  A wave skips the
- * block when the cone misses the bounding cone of its 256 rays.  Returns the number of blocks in the stream. */
+ * code, 0, 0}; code 1 / 2 (zero axis, cos T = 1e30 / -1e30) = a block no ray / every ray has to look at.  A wave
+ * skips the block when the cone misses the bound of its 256 ray directions.  Returns the number of blocks. */
 int  rt_scene_get_block_cone(const rt_scene *, int apex, int block, float out[8]);
 /* Guard chain of `leaf`: writes up to cap boxes {x0,y0,z0,x1,y1,z1}, innermost first; returns the count. */
 int  rt_scene_get_guards(const rt_scene *, int leaf, double *out, int cap);

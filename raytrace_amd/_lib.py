@@ -20,7 +20,7 @@ class rt_stats(C.Structure):
     _fields_ = [("primary_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("tri_tests", C.c_uint64),
                 ("rect_tests", C.c_uint64), ("exact_evals", C.c_uint64), ("ms_primary", C.c_double),
                 ("ms_setup", C.c_double), ("ms_shadow", C.c_double), ("ms_final", C.c_double), ("ms_total", C.c_double),
-                ("mfma_blocks", C.c_uint64)]
+                ("mfma_blocks_primary", C.c_uint64), ("mfma_blocks_shadow", C.c_uint64)]
 
 
 # every symbol include/raytrace_gpu.h declares: name -> (restype, argtypes)

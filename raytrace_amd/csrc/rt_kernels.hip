@@ -20,6 +20,7 @@
 //     Main.hs:213-214) and the colour exactly.  The file is compiled with -ffp-contract=off; the FP32 loops use
 //     explicit fma builtins.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 
 #include <cmath>
 #include <cstdio>
@@ -88,6 +89,9 @@ struct RenderParams {
     HitRec *hitrec;                 // per chunk pixel: exact hit point and shading normal
     uint32_t *queue;                // npoint blocks of qcap shadow jobs (chunk pixel indices)
     unsigned *qcount;               // shadow jobs per point light
+    uint32_t *qsparse;              // k_setup's output: per light, RT_SETUP_THREADS slots per block, the block's jobs first
+    unsigned *tcount;               // jobs of every (light, k_setup block); k_queue_offsets turns them into offsets in place
+    int setup_blocks;               // k_setup blocks of this chunk
     uint32_t *lit;                  // per chunk pixel: bit l set = point light l reaches it
     // bounce levels (reflective scenes, trace depth > 1; Main.hs:546-556).  A "slot" is a pixel of the chunk at
     // level 0 and an entry of the level's ray list above it.
@@ -571,9 +575,8 @@ __device__ __forceinline__ void light_terms(const RenderParams &P, const LightD 
 #define RT_SETUP_THREADS 512
 #endif
 __global__ void __launch_bounds__(RT_SETUP_THREADS) k_setup(const RenderParams P) {
-    // shadow jobs of the block per light: per-wave counts, then ONE returning atomic per (block, light)
+    // shadow jobs of the block per light: per-wave counts -> offsets inside the block's run
     __shared__ unsigned s_cnt[32][RT_SETUP_THREADS / 64];
-    __shared__ unsigned s_base[32];
     // level 0: a block takes a 32 x 16 pixel tile, so that the shadow rays it queues (256 consecutive entries make one
     // wave of k_shadow_mfma) leave from neighbouring pixels and form a narrow bundle; bounce levels: slots in order
     int pix = (int)(blockIdx.x * RT_SETUP_THREADS + threadIdx.x);
@@ -656,19 +659,51 @@ __global__ void __launch_bounds__(RT_SETUP_THREADS) k_setup(const RenderParams P
     if ((int)threadIdx.x < P.npoint) {
         unsigned run = 0;
         for (int k = 0; k < RT_SETUP_THREADS / 64; ++k) { const unsigned c = s_cnt[threadIdx.x][k]; s_cnt[threadIdx.x][k] = run; run += c; }
-        unsigned base = 0;
-        if (run) {
-            base = atomicAdd(&P.qcount[threadIdx.x], run);
-            atomicAdd(&P.counters[0], (unsigned long long)run);
-        }
-        s_base[threadIdx.x] = base;
+        P.tcount[(size_t)threadIdx.x * (size_t)P.setup_blocks + blockIdx.x] = run;
     }
     __syncthreads();
+    // the block's jobs go to its own slots; k_queue_offsets + k_queue_compact then line the blocks' runs up in block
+    // order, so that the 256 consecutive jobs of a k_shadow_mfma wave come from the same or from neighbouring tiles
     for (pl = 0; pl < P.npoint; ++pl) {
         const bool need = (needmask >> pl) & 1u;
         const unsigned long long m = __ballot(need);
-        if (need) P.queue[(size_t)pl * (size_t)P.qcap + s_base[pl] + s_cnt[pl][wv] + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)pix;
+        if (need) P.qsparse[((size_t)pl * (size_t)P.setup_blocks + blockIdx.x) * RT_SETUP_THREADS + s_cnt[pl][wv] + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)pix;
     }
+}
+
+// Exclusive prefix sums of one light's per-block job counts (in place), the light's total into qcount and the
+// shadow-ray counter.  One block of 1024 threads per light.
+__global__ void __launch_bounds__(1024) k_queue_offsets(const RenderParams P) {
+    __shared__ unsigned s_part[1024];
+    const int pl = (int)blockIdx.x, t = (int)threadIdx.x;
+    unsigned *cnt = P.tcount + (size_t)pl * (size_t)P.setup_blocks;
+    const int per = (P.setup_blocks + 1023) / 1024;
+    const int lo = t * per, hi = min(P.setup_blocks, lo + per);
+    unsigned sum = 0;
+    for (int k = lo; k < hi; ++k) sum += cnt[k];
+    s_part[t] = sum;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {                         // inclusive scan of the partial sums
+        const unsigned v = t >= o ? s_part[t - o] : 0u;
+        __syncthreads();
+        s_part[t] += v;
+        __syncthreads();
+    }
+    unsigned run = s_part[t] - sum;
+    for (int k = lo; k < hi; ++k) { const unsigned c = cnt[k]; cnt[k] = run; run += c; }
+    if (t == 1023) {
+        P.qcount[pl] = s_part[1023];
+        if (s_part[1023]) atomicAdd(&P.counters[0], (unsigned long long)s_part[1023]);
+    }
+}
+
+// Moves every k_setup block's run of jobs to its place in the light's dense queue.
+__global__ void __launch_bounds__(RT_SETUP_THREADS) k_queue_compact(const RenderParams P) {
+    const int pl = (int)blockIdx.y;
+    const size_t slot = (size_t)pl * (size_t)P.setup_blocks + blockIdx.x;
+    const unsigned off = P.tcount[slot];
+    const unsigned end = (int)blockIdx.x + 1 < P.setup_blocks ? P.tcount[slot + 1] : P.qcount[pl];
+    if (threadIdx.x < end - off) P.queue[(size_t)pl * (size_t)P.qcap + off + threadIdx.x] = P.qsparse[slot * RT_SETUP_THREADS + threadIdx.x];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -991,32 +1026,61 @@ __device__ __forceinline__ void mfma_scan(const i32x4 *base, const uint16_t *lis
         g1 = idx(k + 4); a1 = blk(g1); block(a2, a0, g2);
     }
 }
-// Bounding cone of a wave's rays: unit axis and the cosine / sine of the half-angle, both already on the wide side.
-struct Bundle { float x, y, z, cr, sr; bool cull; };
-__device__ __forceinline__ Bundle make_bundle(float x, float y, float z, float cr) {
-    cr -= 1e-6f;
-    Bundle U = {x, y, z, cr, __builtin_sqrtf(__builtin_fmaxf(0.f, (1.f - cr) * (1.f + cr))), false};
-    U.cull = cr >= 0.1f;                // a NaN or a bundle wider than 84 degrees: look at every block
-    return U;
+// Bound of a wave's ray directions, in LDS (the same for every lane): a capsule on the unit sphere = the directions
+// within rho of the great-circle arc from p to q.  Primary tiles are cones (p = q); the shadow rays of a pixel tile leave
+// from points strung out along the tile's view pyramid, which the light sees as an arc.
+//   [0..2] p  [3..5] q  [6..8] n = p x q / |p x q|  [9..11] e1 = n x p  [12..14] e2 = q x n  [15] cos rho  [16] sin rho
+//   [17] 1: test blocks against the bound (0: scan every block)  [18] 1: p != q
+constexpr int RT_BUNDLE_FLOATS = 20;
+__device__ __forceinline__ void store_bundle(float *bun, const float p[3], const float q[3], bool arc, float cr, bool cull) {
+    float n[3] = {0.f, 0.f, 0.f}, e1[3] = {0.f, 0.f, 0.f}, e2[3] = {0.f, 0.f, 0.f};
+    if (arc) {
+        const float cx = p[1] * q[2] - p[2] * q[1], cy = p[2] * q[0] - p[0] * q[2], cz = p[0] * q[1] - p[1] * q[0];
+        const float rn = __builtin_amdgcn_rsqf(__builtin_fmaf(cx, cx, __builtin_fmaf(cy, cy, cz * cz)));
+        n[0] = cx * rn; n[1] = cy * rn; n[2] = cz * rn;
+        e1[0] = n[1] * p[2] - n[2] * p[1]; e1[1] = n[2] * p[0] - n[0] * p[2]; e1[2] = n[0] * p[1] - n[1] * p[0];
+        e2[0] = q[1] * n[2] - q[2] * n[1]; e2[1] = q[2] * n[0] - q[0] * n[2]; e2[2] = q[0] * n[1] - q[1] * n[0];
+    }
+    cr -= 1e-6f;                                                  // on the wide side
+    const float sr = __builtin_sqrtf(__builtin_fmaxf(0.f, (1.f - cr) * (1.f + cr)));
+    if ((threadIdx.x & 63u) == 0u) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { bun[k] = p[k]; bun[3 + k] = q[k]; bun[6 + k] = n[k]; bun[9 + k] = e1[k]; bun[12 + k] = e2[k]; }
+        bun[15] = cr; bun[16] = sr;
+        bun[17] = (cull && cr >= 0.1f) ? 1.f : 0.f;               // a NaN or a bound wider than 84 degrees: scan every block
+        bun[18] = arc ? 1.f : 0.f;
+    }
 }
 // The first stage over all `groups` blocks of one apex: every lane tests one block's bounding cone (`cones`, 8 floats
-// per block, rt_scene.cpp: block_cone) against the wave's bundle; the blocks that may hold a leaf for some ray of the
+// per block, rt_scene.cpp: block_cone) against the wave's bound; the blocks that may hold a leaf for some ray of the
 // wave go to `list` (LDS, RT_LIST_CAP + 8 entries), which mfma_scan works off RT_LIST_CAP blocks at a time.  Block
 // `groups` is the first padding block (never rows): it fills the list up to a multiple of 3 and feeds the prefetch.
 constexpr int RT_LIST_CAP = 192;
 template <class S1, class EX>
-__device__ __forceinline__ void culled_scan(const i32x4 *base, const float *cones, int groups, const Bundle &U, uint16_t *list,
+__device__ __forceinline__ void culled_scan(const i32x4 *base, const float *cones, int groups, const float *bun, uint16_t *list,
                                             const f16x8 (&B)[8], WaveQueues &Q, int c, int h, unsigned &nblocks, S1 &&stage1, EX &&exact) {
     const int lane = (int)(threadIdx.x & 63u);
     int n = 0;                                                    // wave-uniform
     for (int g0 = 0; g0 < groups; g0 += 64) {
         const int g = g0 + lane;
         bool pass = g < groups;
-        if (pass && U.cull) {
+        if (pass && bun[17] != 0.f) {
             const float4 k = reinterpret_cast<const float4 *>(cones)[2 * g];
-            const float sT = cones[8 * g + 4];
-            const float thr = __builtin_fmaf(U.cr, k.w, -(U.sr * sT)) - 4e-6f;
-            pass = __builtin_fmaf(U.x, k.x, __builtin_fmaf(U.y, k.y, U.z * k.z)) >= thr;
+            const float sT = cones[8 * g + 4], code = cones[8 * g + 5];          // code 1: never, 2: always
+            const float cr = bun[15], sr = bun[16];
+            // the block's cone (axis k.xyz, half-angle T) meets the capsule iff its axis lies within T + rho of the arc
+            const float cc = __builtin_fmaf(cr, k.w, -(sr * sT)) - 4e-6f;         // cos(T + rho), low side
+            const float ss = __builtin_fmaf(sr, k.w, cr * sT) + 4e-6f;            // sin(T + rho), high side
+            bool geo = cc <= 0.f;                                                  // T + rho >= 90 degrees
+            geo |= __builtin_fmaf(bun[0], k.x, __builtin_fmaf(bun[1], k.y, bun[2] * k.z)) >= cc;
+            if (bun[18] != 0.f) {
+                geo |= __builtin_fmaf(bun[3], k.x, __builtin_fmaf(bun[4], k.y, bun[5] * k.z)) >= cc;
+                // between the end points (taken generously: beyond them the great circle is nearer than the arc)
+                const bool between = __builtin_fmaf(bun[9], k.x, __builtin_fmaf(bun[10], k.y, bun[11] * k.z)) >= -1e-3f
+                                   && __builtin_fmaf(bun[12], k.x, __builtin_fmaf(bun[13], k.y, bun[14] * k.z)) >= -1e-3f;
+                geo |= between && __builtin_fabsf(__builtin_fmaf(bun[6], k.x, __builtin_fmaf(bun[7], k.y, bun[8] * k.z))) <= ss;
+            }
+            pass = code == 2.f || (code == 0.f && geo);
         }
         const unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
         if (pass) list[n + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = (uint16_t)g;
@@ -1067,6 +1131,7 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_shadow_mfma(const RenderParams P) {
     __shared__ uint32_t s_occ[RT_WAVES_PER_BLOCK][256];
     __shared__ uint32_t s_q1[RT_WAVES_PER_BLOCK][RT_Q1_CAP], s_q2[RT_WAVES_PER_BLOCK][RT_Q2_CAP];
     __shared__ uint16_t s_list[RT_WAVES_PER_BLOCK][RT_LIST_CAP + 8];
+    __shared__ float s_bun[RT_WAVES_PER_BLOCK][RT_BUNDLE_FLOATS];
     const int wv = (int)(threadIdx.x >> 6);
     f16x8 B[8];
     float ux[8], uy[8], uz[8];              // unit directions of the lane's 8 rays (0: no ray), for the bundle cone
@@ -1097,33 +1162,75 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_shadow_mfma(const RenderParams P) {
         ux[b] = dx * rn; uy[b] = dy * rn; uz[b] = dz * rn;
     }
     __builtin_amdgcn_wave_barrier();
-    // bundle cone: axis = mean direction (both lane halves hold the same rays), half-angle = the farthest ray
-    float ax = 0.f, ay = 0.f, az = 0.f;
+    // bound of the wave's directions (both lane halves hold the same rays): p = the ray farthest from the mean direction,
+    // q = the ray farthest from p, rho = the largest distance of a ray from the arc p..q
+    {
+        bool some[8], bad = false;
+        float ax = 0.f, ay = 0.f, az = 0.f;
 #pragma unroll
-    for (int b = 0; b < 8; ++b) { ax += ux[b]; ay += uy[b]; az += uz[b]; }
+        for (int b = 0; b < 8; ++b) {
+            some[b] = (ux[b] != 0.f) | (uy[b] != 0.f) | (uz[b] != 0.f);
+            bad |= (ux[b] != ux[b]) | (uy[b] != uy[b]) | (uz[b] != uz[b]);
+            ax += ux[b]; ay += uy[b]; az += uz[b];
+        }
 #pragma unroll
-    for (int o = 16; o > 0; o >>= 1) { ax += __shfl_xor(ax, o); ay += __shfl_xor(ay, o); az += __shfl_xor(az, o); }
-    const float an = __builtin_amdgcn_rsqf(__builtin_fmaf(ax, ax, __builtin_fmaf(ay, ay, az * az)));
-    ax *= an; ay *= an; az *= an;
-    float cmin = 1.f;
+        for (int o = 16; o > 0; o >>= 1) { ax += __shfl_xor(ax, o); ay += __shfl_xor(ay, o); az += __shfl_xor(az, o); }
+        // the ray of the wave with the smallest dot product against (vx, vy, vz)
+        auto farthest = [&](float vx, float vy, float vz, float out[3]) {
+            float best = 3.0e38f, bx = 0.f, by = 0.f, bz = 0.f;      // (the mean direction comes unnormalised)
 #pragma unroll
-    for (int b = 0; b < 8; ++b) {
-        const float dt = __builtin_fmaf(ax, ux[b], __builtin_fmaf(ay, uy[b], az * uz[b]));
-        const bool some = (ux[b] != 0.f) | (uy[b] != 0.f) | (uz[b] != 0.f);
-        cmin = some ? __builtin_fminf(cmin, dt) : cmin;
-        if (dt != dt) cmin = dt;                                   // a NaN direction: no culling for this wave
+            for (int b = 0; b < 8; ++b) {
+                const float dt = __builtin_fmaf(vx, ux[b], __builtin_fmaf(vy, uy[b], vz * uz[b]));
+                if (some[b] && dt < best) { best = dt; bx = ux[b]; by = uy[b]; bz = uz[b]; }
+            }
+            float m = best;
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) m = __builtin_fminf(m, __shfl_xor(m, o));
+            const unsigned long long who = __builtin_amdgcn_ballot_w64(best == m);
+            const int src = who ? __ffsll((long long)who) - 1 : 0;
+            out[0] = __shfl(bx, src); out[1] = __shfl(by, src); out[2] = __shfl(bz, src);
+        };
+        float p[3], q[3];
+        farthest(ax, ay, az, p);
+        farthest(p[0], p[1], p[2], q);
+        const float cx = p[1] * q[2] - p[2] * q[1], cy = p[2] * q[0] - p[0] * q[2], cz = p[0] * q[1] - p[1] * q[0];
+        const float dpq = p[0] * q[0] + p[1] * q[1] + p[2] * q[2];
+        // an arc between 0.06 and 168 degrees; otherwise a cone around p
+        const bool arc = __builtin_fmaf(cx, cx, __builtin_fmaf(cy, cy, cz * cz)) > 1e-6f && dpq > -0.98f;
+        if (!arc) { q[0] = p[0]; q[1] = p[1]; q[2] = p[2]; }
+        float nn[3] = {0.f, 0.f, 0.f}, e1[3] = {0.f, 0.f, 0.f}, e2[3] = {0.f, 0.f, 0.f};
+        if (arc) {
+            const float rn = __builtin_amdgcn_rsqf(__builtin_fmaf(cx, cx, __builtin_fmaf(cy, cy, cz * cz)));
+            nn[0] = cx * rn; nn[1] = cy * rn; nn[2] = cz * rn;
+            e1[0] = nn[1] * p[2] - nn[2] * p[1]; e1[1] = nn[2] * p[0] - nn[0] * p[2]; e1[2] = nn[0] * p[1] - nn[1] * p[0];
+            e2[0] = q[1] * nn[2] - q[2] * nn[1]; e2[1] = q[2] * nn[0] - q[0] * nn[2]; e2[2] = q[0] * nn[1] - q[1] * nn[0];
+        }
+        float cmin = 1.f;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const float dp = __builtin_fmaf(p[0], ux[b], __builtin_fmaf(p[1], uy[b], p[2] * uz[b]));
+            const float dq = __builtin_fmaf(q[0], ux[b], __builtin_fmaf(q[1], uy[b], q[2] * uz[b]));
+            float cd = __builtin_fmaxf(dp, dq);                  // never farther from the arc than from its end points
+            // strictly between the end points: the distance to the great circle
+            const bool between = arc && __builtin_fmaf(e1[0], ux[b], __builtin_fmaf(e1[1], uy[b], e1[2] * uz[b])) >= 1e-3f
+                                     && __builtin_fmaf(e2[0], ux[b], __builtin_fmaf(e2[1], uy[b], e2[2] * uz[b])) >= 1e-3f;
+            const float dn = __builtin_fmaf(nn[0], ux[b], __builtin_fmaf(nn[1], uy[b], nn[2] * uz[b]));
+            if (between) cd = __builtin_fmaxf(cd, __builtin_sqrtf(__builtin_fmaxf(0.f, __builtin_fmaf(-dn, dn, 1.f))) - 2e-7f);
+            if (some[b]) cmin = __builtin_fminf(cmin, cd);
+        }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) cmin = __builtin_fminf(cmin, __shfl_xor(cmin, o));
+        bad = __builtin_amdgcn_ballot_w64(bad) != 0ull;
+        store_bundle(s_bun[wv], p, q, arc, cmin, P.cull != 0 && !bad);
     }
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) { const float t = __shfl_xor(cmin, o); cmin = (t != t || cmin != cmin) ? __builtin_nanf("") : __builtin_fminf(cmin, t); }
-    Bundle U = make_bundle(ax, ay, az, cmin);
-    U.cull = U.cull && P.cull != 0;
+    __builtin_amdgcn_wave_barrier();
     const size_t ro = (size_t)__builtin_amdgcn_readfirstlane(Lt.rec_offset);
     const size_t gstride = (size_t)(P.mf_groups + 2);
     const i32x4 *blocks = reinterpret_cast<const i32x4 *>(P.mf_rows) + ro * gstride * 32;
     const FilterRec *recs = P.mf_rec + ro * gstride * MF_LEAVES;
     unsigned nexact = 0, nblocks = 0;
     WaveQueues Q = {s_q1[wv], s_q2[wv], 0u, 0u};
-    culled_scan(blocks, P.mf_cone + ro * gstride * 8, P.mf_groups, U, s_list[wv], B, Q, c, h, nblocks,
+    culled_scan(blocks, P.mf_cone + ro * gstride * 8, P.mf_groups, s_bun[wv], s_list[wv], B, Q, c, h, nblocks,
         [&](uint32_t entry) -> bool {           // FP32 record test of one (ray, leaf) pair
             const int e = (int)(entry & 255u);
             const FilterRec *R = recs + (entry >> 8);
@@ -1180,7 +1287,7 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_shadow_mfma(const RenderParams P) {
         if (nd[r]) atomicOr(&P.lit[pix[r]], 1u << pl);
     for (int o = 32; o > 0; o >>= 1) nexact += __shfl_down(nexact, o);
     if (lane == 0 && nexact) atomicAdd(&P.counters[2], (unsigned long long)nexact);
-    if (lane == 0) atomicAdd(&P.counters[6], (unsigned long long)nblocks);
+    if (lane == 0) atomicAdd(&P.counters[7], (unsigned long long)nblocks);
 }
 
 // Kernel 1 on the matrix cores.  One wave = 32 x 8 pixel tile; ray block b = tile row b, column c = lane & 31.
@@ -1191,6 +1298,7 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_primary_mfma(const RenderParams P) {
     __shared__ int s_bid[RT_WAVES_PER_BLOCK][256];
     __shared__ uint32_t s_q1[RT_WAVES_PER_BLOCK][RT_Q1_CAP], s_q2[RT_WAVES_PER_BLOCK][RT_Q2_CAP];
     __shared__ uint16_t s_list[RT_WAVES_PER_BLOCK][RT_LIST_CAP + 8];
+    __shared__ float s_bun[RT_WAVES_PER_BLOCK][RT_BUNDLE_FLOATS];
     const int wv = (int)(threadIdx.x >> 6);
     const int wave = (int)(blockIdx.x * RT_WAVES_PER_BLOCK) + wv;
     const int lane = (int)(threadIdx.x & 63), c = lane & 31, h = lane >> 5;
@@ -1216,26 +1324,25 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_primary_mfma(const RenderParams P) {
     const i32x4 *blocks = reinterpret_cast<const i32x4 *>(P.mf_rows);          // apex 0 = the eye
     // bundle cone of the tile: axis through its centre, half-angle to the farthest corner (the directions inside a cone
     // cut the image plane in a convex region, so the corners decide); one pixel of slack all round covers the jitter
-    Bundle U;
     {
         const float cx = (float)(P.cam.scaleX * ((double)x0 + 15.5) + P.cam.dX);
         const float cy = (float)(P.cam.scaleY * ((double)(P.row0 + ly0) + 3.5) + P.cam.dY);
         const float hx = (float)(17.5 * fabs(P.cam.scaleX)), hy = (float)(5.5 * fabs(P.cam.scaleY));
         const float cn = __builtin_amdgcn_rsqf(__builtin_fmaf(cx, cx, __builtin_fmaf(cy, cy, dzf * dzf)));
-        const float ax = cx * cn, ay = cy * cn, az = dzf * cn;
+        const float axis[3] = {cx * cn, cy * cn, dzf * cn};
         float cmin = 1.f;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const float qx = cx + ((k & 1) ? hx : -hx), qy = cy + ((k & 2) ? hy : -hy);
             const float qn = __builtin_amdgcn_rsqf(__builtin_fmaf(qx, qx, __builtin_fmaf(qy, qy, dzf * dzf)));
-            cmin = __builtin_fminf(cmin, (ax * qx + ay * qy + az * dzf) * qn);
+            cmin = __builtin_fminf(cmin, (axis[0] * qx + axis[1] * qy + axis[2] * dzf) * qn);
         }
-        U = make_bundle(ax, ay, az, cmin);
-        U.cull = U.cull && P.cull != 0;
+        store_bundle(s_bun[wv], axis, axis, false, cmin, P.cull != 0);
     }
+    __builtin_amdgcn_wave_barrier();
     unsigned nexact = 0, nblocks = 0;
     WaveQueues Q = {s_q1[wv], s_q2[wv], 0u, 0u};
-    culled_scan(blocks, P.mf_cone, P.mf_groups, U, s_list[wv], B, Q, c, h, nblocks,
+    culled_scan(blocks, P.mf_cone, P.mf_groups, s_bun[wv], s_list[wv], B, Q, c, h, nblocks,
         [&](uint32_t entry) -> bool {           // FP32 record test of one (pixel, leaf) pair
             const int e = (int)(entry & 255u);
             const FilterRec *R = P.mf_rec + (entry >> 8);                         // apex 0 = the eye
@@ -1246,6 +1353,9 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_primary_mfma(const RenderParams P) {
             const float px = (float)(P.cam.scaleX * ((double)xe + ox) + P.cam.dX);
             const float py = (float)(P.cam.scaleY * ((double)ye + oy) + P.cam.dY);
             // eye records are affine in (posX, posY): the z column already holds c_z * d
+#ifdef RT_COUNT_EVENTS
+            atomicAdd(&P.counters[4], 1ull);
+#endif
             return gid >= 0 && record_test(R, kind, px, py, 1.0f);
         },
         [&](uint32_t entry) {                   // exact: intersect leaf (cast camera x y), Main.hs:543
@@ -1258,6 +1368,9 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_primary_mfma(const RenderParams P) {
             ++nexact;
             const bool hit = (kind == LEAF_TRI ? leaf_isect<LEAF_TRI>(L, ray, ix, iy, iz, tt, RT_TALK(P)) : leaf_isect<LEAF_RECT>(L, ray, ix, iy, iz, tt, RT_TALK(P)))
                              && guards_ok(P.guards, L.guard, ray);
+#ifdef RT_COUNT_EVENTS
+            if (hit) atomicAdd(&P.counters[3], 1ull);
+#endif
             // Nearest wins; equal t -> the left-most leaf of the tree (Main.hs:213-214).  Several lanes may hold hits of
             // the same pixel: the wave runs in lockstep and its LDS operations complete in order, so (1) all read the
             // old t, (2) all fold their t in with an atomic min, (3) the lanes whose t is the new minimum reset the
@@ -1692,7 +1805,7 @@ void rt_scene_destroy(rt_scene *s) {
     if (!s) return;
     DeviceScene &d = s->dev;
     void *ptrs[] = {d.leaves, d.aux, d.guards, d.mats, d.lights, d.tri_rec, d.rect_rec, d.tri_gid, d.rect_gid,
-                    d.counters, d.qcount, d.hit_id, d.accum, d.rgba, d.hit_out, d.hitrec, d.queue, d.lit, d.gen_tri, d.gen_rect, d.sph_rec, d.gen_sph, d.sph_gid, d.mf_rows, d.mf_gid, d.mf_rec, d.mf_cone};
+                    d.counters, d.qcount, d.hit_id, d.accum, d.rgba, d.hit_out, d.hitrec, d.queue, d.qsparse, d.tcount, d.lit, d.gen_tri, d.gen_rect, d.sph_rec, d.gen_sph, d.sph_gid, d.mf_rows, d.mf_gid, d.mf_rec, d.mf_cone};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (int k = 0; k < 8; ++k) {
         if (d.lvl_rays[k]) (void)hipFree(d.lvl_rays[k]);
@@ -1740,6 +1853,11 @@ static int render_rows(rt_scene *s, int w, int h, int depth, int spp, uint64_t s
         if ((rc = ensure(s->dev.hitrec, s->dev.hitrec_cap, cpix * sizeof(HitRec)))) return rc;
         if ((rc = ensure(s->dev.lit, s->dev.lit_cap, cpix))) return rc;
         if ((rc = ensure(s->dev.queue, s->dev.queue_cap, cpix * (size_t)(s->npoint > 0 ? s->npoint : 1)))) return rc;
+        // k_setup blocks of a chunk: 32 x 16 pixel tiles at level 0, runs of slots at the bounce levels
+        const size_t ub = std::max((size_t)((w + 31) / 32) * ((crow + RT_SETUP_THREADS / 32 - 1) / (RT_SETUP_THREADS / 32)),
+                                   (cpix + RT_SETUP_THREADS - 1) / RT_SETUP_THREADS);
+        if ((rc = ensure(s->dev.qsparse, s->dev.qsparse_cap, ub * RT_SETUP_THREADS * (size_t)(s->npoint > 0 ? s->npoint : 1)))) return rc;
+        if ((rc = ensure(s->dev.tcount, s->dev.tcount_cap, (ub + 1) * (size_t)(s->npoint > 0 ? s->npoint : 1)))) return rc;
     }
     if (d_rgba && levels > 1) {
         if ((rc = ensure(s->dev.lvl_col[0], s->dev.lvl_col_cap[0], cpix))) return rc;
@@ -1763,6 +1881,7 @@ static int render_rows(rt_scene *s, int w, int h, int depth, int spp, uint64_t s
     P.tri_gid = s->dev.tri_gid; P.rect_gid = s->dev.rect_gid;
     P.counters = s->dev.counters;
     P.hitrec = reinterpret_cast<HitRec *>(s->dev.hitrec); P.queue = s->dev.queue; P.qcount = s->dev.qcount; P.lit = s->dev.lit;
+    P.qsparse = s->dev.qsparse; P.tcount = s->dev.tcount;
     P.gen_tri = s->dev.gen_tri; P.gen_rect = s->dev.gen_rect;
     P.sph_rec = s->dev.sph_rec; P.gen_sph = s->dev.gen_sph; P.sph_gid = s->dev.sph_gid; P.nsph = (int)s->sph_gid.size();
     P.mf_rows = s->dev.mf_rows; P.mf_gid = s->dev.mf_gid; P.mf_rec = s->dev.mf_rec; P.mf_groups = s->mf_groups;
@@ -1821,7 +1940,12 @@ static int render_rows(rt_scene *s, int w, int h, int depth, int spp, uint64_t s
                 P.colour = (levels > 1) ? s->dev.lvl_col[lvl] : nullptr;
                 const unsigned ublocks = lvl == 0 ? (unsigned)P.tiles_x * (unsigned)((rows + RT_SETUP_THREADS / 32 - 1) / (RT_SETUP_THREADS / 32))
                                                   : (unsigned)(((size_t)P.qcap + RT_SETUP_THREADS - 1) / RT_SETUP_THREADS);
+                P.setup_blocks = (int)ublocks;
                 hipLaunchKernelGGL(k_setup, dim3(ublocks), dim3(RT_SETUP_THREADS), 0, st, P);
+                if (s->npoint > 0) {
+                    hipLaunchKernelGGL(k_queue_offsets, dim3((unsigned)s->npoint), dim3(1024), 0, st, P);
+                    hipLaunchKernelGGL(k_queue_compact, dim3(ublocks, (unsigned)s->npoint), dim3(RT_SETUP_THREADS), 0, st, P);
+                }
                 if ((rc = next_event(*s, st, 2))) return rc;
                 if (s->npoint > 0) {
                     if (use_mfma) hipLaunchKernelGGL(k_shadow_mfma, dim3(sblocks, (unsigned)s->npoint), dim3(RT_WAVES_PER_BLOCK * 64), 0, st, P);
@@ -1937,9 +2061,10 @@ int rt_get_stats(rt_scene *s, rt_stats *out) {
         st.tri_tests = (st.primary_rays + st.shadow_rays) * (uint64_t)s->tri_gid.size();
         st.rect_tests = (st.primary_rays + st.shadow_rays) * (uint64_t)s->rect_gid.size();
         st.exact_evals = c[1] + c[2];
-        st.mfma_blocks = c[6];
+        st.mfma_blocks_primary = c[6];
+        st.mfma_blocks_shadow = c[7];
 #ifdef RT_COUNT_EVENTS
-        fprintf(stderr, "[rt] slow-path entries (wave x block) %llu, wave iterations %llu, lane passes of the first stage %llu, exact evals primary %llu shadow %llu\n", c[3], c[4], c[5], c[1], c[2]);
+        fprintf(stderr, "[rt] primary: true hits among the exact evaluations %llu, FP32 record tests %llu; exact evals primary %llu shadow %llu\n", c[3], c[4], c[1], c[2]);
 #endif
         st.ms_primary = ms[1]; st.ms_setup = ms[2]; st.ms_shadow = ms[3]; st.ms_final = ms[4]; st.ms_total = tot;
         s->stats = st;

@@ -451,20 +451,21 @@ static void direction_split(std::vector<int> &idx, const std::vector<double> &u,
     direction_split(idx, u, v, lo, lo + half);
     direction_split(idx, u, v, lo + half, hi);
 }
-// Bounding cone of a block of leaf cones, as the kernels read it: {axis xyz, cos T, sin T, 0, 0, 0}; a block passes for
-// a ray bundle (axis r, half-angle rho) when r . axis >= cos(rho) cos T - sin(rho) sin T - margin.  cos T = +-1e30
-// with a zero axis encodes "never" (only padding or never-hit leaves) and "always" (some leaf is wide or degenerate).
+// Bounding cone of a block of leaf cones, as the kernels read it: {axis xyz, cos T, sin T, code, 0, 0}; code 0: a wave
+// scans the block when the axis lies within T + rho of the bound of its ray directions (rt_kernels.hip: culled_scan);
+// code 1 "never" (only padding or never-hit leaves) and 2 "always" (some leaf is wide or degenerate) come with a
+// zero axis and cos T = +-1e30.
 static void block_cone(const LeafCone *C, int n, float out[8]) {
     for (int k = 0; k < 8; ++k) out[k] = 0.f;
     double ax[3] = {0, 0, 0};
     int live = 0;
     for (int i = 0; i < n; ++i) {
-        if (C[i].status == 2) { out[3] = -1e30f; return; }
+        if (C[i].status == 2) { out[3] = -1e30f; out[5] = 2.f; return; }
         if (C[i].status == 0) { ++live; for (int k = 0; k < 3; ++k) ax[k] += C[i].axis[k]; }
     }
-    if (live == 0) { out[3] = 1e30f; return; }
+    if (live == 0) { out[3] = 1e30f; out[5] = 1.f; return; }
     const double len = std::sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
-    if (!(len > 1e-6 * live)) { out[3] = -1e30f; return; }
+    if (!(len > 1e-6 * live)) { out[3] = -1e30f; out[5] = 2.f; return; }
     for (int k = 0; k < 3; ++k) ax[k] /= len;
     double T = 0;
     for (int i = 0; i < n; ++i) {
@@ -473,7 +474,7 @@ static void block_cone(const LeafCone *C, int n, float out[8]) {
         T = std::fmax(T, std::acos(std::fmax(-1.0, std::fmin(1.0, dt))) + std::acos(std::fmax(-1.0, std::fmin(1.0, C[i].cs))));
     }
     T = T * (1.0 + 1e-9) + 2e-6;                                  // slack for the FP32 axis and the FP32 test
-    if (!(T < 1.4)) { out[3] = -1e30f; return; }                  // wider than 80 degrees: not worth a test
+    if (!(T < 1.4)) { out[3] = -1e30f; out[5] = 2.f; return; }    // wider than 80 degrees: not worth a test
     out[0] = (float)ax[0]; out[1] = (float)ax[1]; out[2] = (float)ax[2];
     out[3] = (float)std::cos(T); out[4] = (float)std::sin(T);
 }

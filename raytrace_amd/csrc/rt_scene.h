@@ -38,6 +38,8 @@ struct DeviceScene {          // device copies (HBM), owned by the scene
     int32_t *hit_out = nullptr; size_t hit_out_cap = 0;    // rt_render (host buffers) staging
     char *hitrec = nullptr;     size_t hitrec_cap = 0;     // per chunk pixel: 48-byte HitRec (capacity in bytes)
     uint32_t *queue = nullptr;  size_t queue_cap = 0;      // shadow-job queues, npoint x chunk pixels
+    uint32_t *qsparse = nullptr; size_t qsparse_cap = 0;   // k_setup's per-block runs of shadow jobs, before compaction
+    unsigned *tcount = nullptr; size_t tcount_cap = 0;     // shadow jobs per (light, k_setup block) -> offsets
     uint32_t *lit = nullptr;    size_t lit_cap = 0;        // per chunk pixel: lit-by-light bit mask
     unsigned *qcount = nullptr;                            // shadow jobs per point light; [32..39] rays per bounce level
     GenRec *gen_tri = nullptr, *gen_rect = nullptr;        // general-ray filter records (reflective scenes only)
