@@ -103,6 +103,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--filter", default="mfma", choices=["mfma", "valu"],
                     help="first stage: bounding cones on the matrix cores (default) or the FP32 vector-ALU kernels")
+    ap.add_argument("--no-cull", action="store_true", help="every wave scans every block of the leaf stream (RT_CULL=0): the plain brute-force scan")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the measured path) or gloo (rehearsal on one GPU)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank renders on GPU 0 (gloo only)")
     ap.add_argument("--pieces", type=int, default=4, help="N > 1: pieces per band; piece k's gather overlaps piece k+1's render")
@@ -132,6 +133,7 @@ def main():
             dist.init_process_group("gloo")
     staged = n > 1 and args.dist_backend != "nccl"               # gloo rehearsal: bands travel through host memory
     os.environ["RT_FILTER"] = args.filter
+    os.environ["RT_CULL"] = "0" if args.no_cull else "1"
     _lib.check(_lib.lib().rt_init(local_rank), "rt_init")
 
     w = args.width or (3840 if n == 1 else 16384)
@@ -217,7 +219,8 @@ def main():
         dt = float(tmax.item())
     stats = scene.stats()
     if n > 1:            # untimed pass: ray counts and per-kernel times of this rank's band, summed over its pieces
-        keys = ("primary_rays", "shadow_rays", "exact_evals", "ms_shadow", "ms_primary", "ms_setup", "ms_final")
+        keys = ("primary_rays", "shadow_rays", "exact_evals", "ms_shadow", "ms_primary", "ms_setup", "ms_final",
+                "mfma_blocks_primary", "mfma_blocks_shadow")
         total = dict.fromkeys(keys, 0.0)
         for r0, nr in subs[rank]:
             if nr > 0:
@@ -251,12 +254,13 @@ def main():
         prim_flops = primary / n * per_test
         achieved = prim_flops / (ms_prim * 1e-3) / 1e12
         mfma = args.filter == "mfma"
-        # executed matrix-core work of that launch: one MFMA per 32 rays (a row of a 32 x 8 tile) x block of 32 leaves
+        # executed matrix-core work of that launch: 8 MFMAs (one per 32 rays of the wave's 256) per block of 32 leaves
+        # the wave scanned (the library counts them); the brute-force scan would visit every block for every wave
         tiles = -(-w // 32) * -(-nrows // 8)
         blocks = -(-(ntri + nrect) // 32)
-        blocks = -(-blocks // 3) * 3            # the leaf stream is padded to a multiple of 3 blocks
-        mfma_steps = tiles * 8 * blocks * args.spp
-        executed = mfma_steps * MFMA_FLOPS / (ms_prim * 1e-3) / 1e12
+        scanned = float(stats["mfma_blocks_primary"])
+        executed = scanned * 8 * MFMA_FLOPS / (ms_prim * 1e-3) / 1e12
+        scanned_frac = scanned / max(1.0, float(tiles * blocks * args.spp)) if n == 1 else None
         peak = PEAK_MFMA_F16_TFLOPS if mfma else PEAK_FP32_TFLOPS
         out = {
             "metric": "primary Mrays/s (whole node)", "value": primary / (dt / args.steps) / 1e6, "unit": "Mrays/s",
@@ -264,10 +268,11 @@ def main():
             "higher_is_better": True, "scaling": "strong" if n > 1 else "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{wname} ({ntri + nrect} leaves), {nlt} point light(s) + ambient, "
-                                   f"{w}x{h}, depth {args.depth}, spp {args.spp}, brute force"
+                                   f"{w}x{h}, depth {args.depth}, spp {args.spp}, every ray x leaf pair decided (no hierarchy)"
                                    + (f", {n} cost-balanced row bands gathered to GPU 0 over " + ("RCCL" if not staged else "gloo via host memory (rehearsal)") if n > 1 else ""),
                        "arithmetic": "hits and colours decided in f64 (the reference's Double); conservative filters in front: "
-                                     + ("f16 bounding cones on the matrix cores, then f32 records" if args.filter == "mfma" else "f32 records on the vector ALU"),
+                                     + (("blocks of 32 leaves against the bound of a wave's 256 ray directions, " if not args.no_cull else "")
+                                        + "f16 bounding cones on the matrix cores, then f32 records" if args.filter == "mfma" else "f32 records on the vector ALU"),
                        "width": w, "height": h, "leaves": ntri + nrect, "lights": nlt, "spp": args.spp,
                        "bands": bands if n > 1 else None, "pieces_per_band": pieces if n > 1 else None, "gathered_frame_equals_single_render": verified,
                        "shadow_rays_per_frame": shadow, "exact_fp64_evals_per_frame": exact,
@@ -280,11 +285,32 @@ def main():
                          "frac_of_fp32_valu_peak": achieved / PEAK_FP32_TFLOPS,
                          "executed_mfma_tflops": executed if mfma else None,
                          "executed_mfma_frac": executed / PEAK_MFMA_F16_TFLOPS if mfma else None,
+                         "leaf_blocks_scanned_frac": scanned_frac if mfma else None,
                          "note": "achieved = algorithmic flops (53/45 per ray x triangle/rectangle test, SURVEY.md 8d) x primary rays x leaves "
-                                 "of one launch / its HIP-event time; the kernel executes far fewer (one FP16 MFMA form per pair, then "
-                                 "FP32/FP64 on the candidates), so frac_of_fp32_valu_peak exceeds 1; executed_mfma_* is the matrix-core "
-                                 "work actually issued against the dense FP16 peak"},
+                                 "of one launch / its HIP-event time. The kernel decides every pair but executes far fewer flops: a wave "
+                                 "skips the blocks of 32 leaves whose bounding cone misses the bound of its 256 rays "
+                                 "(leaf_blocks_scanned_frac of the blocks are scanned), a scanned pair costs one FP16 MFMA form, and only "
+                                 "candidates reach FP32/FP64 -- so frac and frac_of_fp32_valu_peak exceed 1 and say how much cheaper than "
+                                 "the reference formulation the decision is, not how busy the matrix pipe is; executed_mfma_* is the "
+                                 "matrix-core work actually issued against the dense FP16 peak, and brute_force_scan is the same frame "
+                                 "with the block test off (every wave scans every block)"},
         }
+        if n == 1 and mfma and not args.no_cull:
+            # the same frame with the block test off (every wave scans every block), timed the same way
+            os.environ["RT_CULL"] = "0"
+            _lib.check(_lib.lib().rt_init(local_rank), "rt_init")
+            step(); sync()
+            t0 = time.perf_counter()
+            for _ in range(2):
+                step()
+            sync()
+            bf = (time.perf_counter() - t0) / 2
+            bst = scene.stats()
+            out["brute_force_scan"] = {"value": primary / bf / 1e6, "unit": "Mrays/s", "ms_per_step": bf * 1e3,
+                                       "k_primary_ms": bst["ms_primary"], "k_shadow_ms": bst["ms_shadow"],
+                                       "executed_mfma_tflops": float(bst["mfma_blocks_primary"]) * 8 * MFMA_FLOPS / (bst["ms_primary"] * 1e-3) / 1e12}
+            os.environ["RT_CULL"] = "1"
+            _lib.check(_lib.lib().rt_init(local_rank), "rt_init")
         if n == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(world, lights, w, h, args.depth)
         print(json.dumps(out), flush=True)

@@ -346,3 +346,113 @@ def test_fp32_records_random_leaves_and_apexes():
         assert (nd >= rec[10]).all(), f"case {case}: segment clip rejects a leaf between light and origin"
         checked += len(D)
     assert checked > 20000
+
+
+# ---------------------------------------------------------------------------------------------
+# Block cones: the matrix-core kernels skip a block of 32 stream positions when its bounding cone misses the bound of
+# a wave's ray directions (rt_scene.cpp: block_cone, rt_kernels.hip: culled_scan).
+
+def stream_layout(sc, apex, w, h):
+    """(position in the apex's stream, decoded row) of every leaf, and the block cones."""
+    L = _lib.lib()
+    assert L.rt_scene_prepare_host(sc.handle, w, h) >= 0
+    out = (C.c_uint16 * 8)()
+    pos = np.zeros(sc.num_leaves, np.int64)
+    rows = np.zeros((sc.num_leaves, 8), np.float64)
+    for i in range(sc.num_leaves):
+        if int(sc.leaf(i)[0]) == 2:
+            pos[i] = -1                                                   # spheres are not in the stream
+            continue
+        pos[i] = L.rt_scene_get_mfma_row(sc.handle, apex, i, out)
+        assert pos[i] >= 0
+        rows[i] = np.frombuffer(out, np.float16).astype(np.float64)
+    cone = (C.c_float * 8)()
+    groups = L.rt_scene_get_block_cone(sc.handle, apex, 0, cone)
+    assert groups > 0 and groups % 3 == 0
+    cones = np.zeros((groups + 2, 8), np.float32)
+    for g in range(groups + 2):
+        assert L.rt_scene_get_block_cone(sc.handle, apex, g, cone) == groups
+        cones[g] = np.frombuffer(cone, np.float32)
+    return pos, rows, cones
+
+
+@pytest.mark.parametrize("name,w,h", [("default", 128, 128), ("stacked_cubes", 96, 96), ("cylinder_axes", 100, 80),
+                                      ("intersection", 96, 96), ("adversarial", 64, 64)])
+def test_block_cones_contain_their_leaf_cones(name, w, h):
+    world, lights = scenes.adversarial() if name == "adversarial" else scenes.REFERENCE_SCENES[name]()
+    sc = api.Scene(world, lights)
+    napex = 1 + sum(isinstance(l, api.PointLight) for l in lights)
+    planar = [i for i in range(sc.num_leaves) if int(sc.leaf(i)[0]) != 2]
+    for apex in range(napex):
+        pos, rows, cones = stream_layout(sc, apex, w, h)
+        assert len(set(pos[planar])) == len(planar)                       # every planar leaf has its own stream position
+        assert (cones[-2:, 5] == 1).all()                                 # the padding blocks are "never" blocks
+        for i in planar:
+            blk = cones[pos[i] // 32]
+            axis = np.array([rows[i][0] + rows[i][1], rows[i][2] + rows[i][3], rows[i][4] + rows[i][5]]) / 1024.0
+            const = (rows[i][6] + rows[i][7]) / 1024.0
+            if not axis.any():                                            # constant row
+                if const > 0:
+                    assert blk[5] == 2, f"{name} apex {apex}: an 'always' leaf sits in a block that can be skipped"
+                continue
+            if blk[5] == 2:
+                continue
+            assert blk[5] == 0
+            cs = min(1.0, 2.0 ** -17 - const)                             # row constant = margin - cos(theta)
+            A = blk[:3].astype(np.float64)
+            between = np.arccos(np.clip(A @ axis / np.linalg.norm(axis), -1, 1))
+            T = np.arctan2(float(blk[4]), float(blk[3]))
+            assert between + np.arccos(cs) <= T + 1e-6, f"{name} apex {apex} leaf {i}: leaf cone sticks out of its block cone"
+    sc.close()
+
+
+def tile_bound(cam, x0, y0):
+    """k_primary_mfma's bound of a 32 x 8 pixel tile (a cone), in float32 like the kernel."""
+    f = np.float32
+    cx, cy, dz = f(cam[0] * (x0 + 15.5) + cam[2]), f(cam[1] * (y0 + 3.5) + cam[3]), f(cam[4])
+    hx, hy = f(17.5 * abs(cam[0])), f(5.5 * abs(cam[1]))
+    cn = f(1.0) / np.sqrt(fma32(cx, cx, fma32(cy, cy, dz * dz)))
+    axis = np.array([cx * cn, cy * cn, dz * cn], np.float32)
+    cmin = f(1.0)
+    for k in range(4):
+        qx, qy = cx + (hx if k & 1 else -hx), cy + (hy if k & 2 else -hy)
+        qn = f(1.0) / np.sqrt(fma32(qx, qx, fma32(qy, qy, dz * dz)))
+        cmin = min(cmin, f((axis[0] * qx + axis[1] * qy + axis[2] * dz) * qn))
+    cr = f(cmin - f(1e-6))
+    sr = np.sqrt(max(f(0), f((f(1) - cr) * (f(1) + cr))))
+    return axis, cr, f(sr)
+
+
+def cone_block_passes(axis, cr, sr, blk):
+    """culled_scan's test for a cone-shaped bound (p = q)."""
+    if blk[5] == 2:
+        return True
+    if blk[5] != 0:
+        return False
+    cc = fma32(cr, blk[3], -(sr * blk[4])) - np.float32(4e-6)
+    return bool(cc <= 0 or fma32(axis[0], blk[0], fma32(axis[1], blk[1], axis[2] * blk[2])) >= cc)
+
+
+@pytest.mark.parametrize("name,w,h", [("default", 256, 256), ("stacked_cubes", 200, 120), ("cylinder_axes", 160, 96)])
+def test_tile_bound_keeps_the_block_of_every_oracle_hit(name, w, h):
+    """Eye apex: for every pixel the oracle hits, the block holding the hit leaf passes the block test of the pixel's
+    tile -- and the test is selective (most (tile, block) pairs are skipped in the height field)."""
+    world, lights = scenes.REFERENCE_SCENES[name]()
+    sc = api.Scene(world, lights)
+    pos, rows, cones = stream_layout(sc, 0, w, h)
+    cam = (C.c_double * 5)()
+    _lib.lib().rt_camera_params(w, h, cam)
+    hit = ob.OracleScene(world, lights).render(w, h, use_bbox=0)["hit_id"]
+    kinds = np.array([int(sc.leaf(i)[0]) for i in range(sc.num_leaves)])
+    passed = total = 0
+    for y0 in range(0, h, 8):
+        for x0 in range(0, w, 32):
+            axis, cr, sr = tile_bound(cam, x0, y0)
+            ok = np.array([cone_block_passes(axis, cr, sr, b) for b in cones[:-2]])
+            passed += int(ok.sum()); total += len(ok)
+            for leaf in np.unique(hit[y0:y0 + 8, x0:x0 + 32]):
+                if leaf >= 0 and kinds[leaf] != 2:
+                    assert ok[pos[leaf] // 32], f"{name}: tile ({x0},{y0}) skips the block of leaf {leaf}, which it hits"
+    if name == "default":
+        assert passed < 0.5 * total
+    sc.close()
