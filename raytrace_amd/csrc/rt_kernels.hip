@@ -107,6 +107,7 @@ struct RenderParams {
     int ntri, nrect, nsph, nlights, nleaves, npoint;
     int mf_groups;                  // blocks of MF_LEAVES planar leaves per apex (+ 2 of padding)
     int cull;                       // 0: every wave scans every block (RT_CULL=0)
+    int nguard_cached;              // guards [0, nguard_cached) are tested per tile (tile_guard_mask); 0: off
     int w, h;
     int row0, nrows;                // this chunk: first absolute image row, rows
     long long out_off;              // index of the chunk's first pixel inside the band-local outputs
@@ -259,12 +260,17 @@ __device__ __forceinline__ bool face_yz(const GuardD &B, double xf, const RayD &
     const double a = r.py + t * r.dy, c = r.pz + t * r.dz;
     return t >= 0 && B.y0 <= a && a <= B.y1 && B.z0 <= c && c <= B.z1;
 }
+// `passed`: bit g set = box g (< 64) and every box above it are known to let this ray through (tile_guard_mask)
 template <bool EARLY = (RT_GUARD_EARLY != 0)>
-__device__ __forceinline__ bool guards_ok(const GuardD *__restrict__ G, int g, const RayD &r) {
+__device__ __forceinline__ bool guards_ok(const GuardD *__restrict__ G, int g, const RayD &r, unsigned long long passed = 0ull) {
     // the faces the ray points at: it leaves the box through one of these three
     const bool nz = r.dz < 0, ny = r.dy < 0, nx = r.dx < 0;
     (void)nz; (void)ny; (void)nx;
+#ifdef RT_NO_GUARDS
+    return true;        // timing experiments only
+#endif
     while (g >= 0) {
+        if (g < 64 && ((passed >> g) & 1ull)) return true;
         const GuardD B = G[g];
         bool any;
         if (EARLY) {
@@ -879,6 +885,43 @@ __global__ void RT_HOT(RT_WAVES_EU_SHADOW) k_shadow(const RenderParams P) {
 // A wave carries 8 B operands (256 rays).  Pairs that pass go to the wave's candidate queues (below): FP32 record
 // test (exact shape, segment clip), then the exact FP64 evaluation.
 
+// The guard boxes [0, P.nguard_cached) are the ones above the most leaves, parents first (rt_scene.cpp: order_guards).
+// For the 32 x 8 pixel tile at (x0, y0): bit g of the result = EVERY camera ray of the tile certainly passes box g and
+// every box above it, so the chain walk of a leaf may stop there.  "Certainly": the ray (posX, posY, 0) + t (posX, posY, d)/n
+// crosses the plane z = zf at t = zf n / d, in the point (posX, posY)(1 + zf/d), which is linear in the pixel position;
+// if that point lies inside the face [x0, x1] x [y0, y1] for the whole tile, with a margin 10^6 times the rounding
+// errors of intersectBB's own arithmetic (Main.hs:157-161), isectXY of that face holds and the `or` (Main.hs:172) is True.
+// One pixel of slack around the tile covers the sample jitter.  One lane per box; the ancestors by pointer jumping.
+__device__ __forceinline__ unsigned long long tile_guard_mask(const RenderParams &P, int x0, int y0) {
+    const int lane = (int)(threadIdx.x & 63u);
+    bool ok = false;
+    int anc = -1;
+    if (lane < P.nguard_cached) {
+        const GuardD B = P.guards[lane];
+        anc = B.parent;
+        const double xa = P.cam.scaleX * (double)(x0 - 1) + P.cam.dX, xb = P.cam.scaleX * (double)(x0 + RT_TILE_W) + P.cam.dX;
+        const double ya = P.cam.scaleY * (double)(y0 - 1) + P.cam.dY, yb = P.cam.scaleY * (double)(y0 + RT_TILE_H) + P.cam.dY;
+        const double XL = fmin(xa, xb), XH = fmax(xa, xb), YL = fmin(ya, yb), YH = fmax(ya, yb);
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            const double zf = f ? B.z0 : B.z1;
+            const double q = zf / P.cam.d;                         // t >= 0 (Main.hs:161)  <=>  q >= 0
+            const double sc = 1.0 + q;
+            const double lx = XL * sc, hx = XH * sc, ly = YL * sc, hy = YH * sc;
+            const double mx = 1e-9 * (fabs(B.x0) + fabs(B.x1) + fabs(lx) + fabs(hx)) + 1e-300;
+            const double my = 1e-9 * (fabs(B.y0) + fabs(B.y1) + fabs(ly) + fabs(hy)) + 1e-300;
+            ok |= q > 1e-9 && B.x0 + mx <= lx && hx <= B.x1 - mx && B.y0 + my <= ly && hy <= B.y1 - my;
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < 6; ++it) {                               // ok[g] &= ok[anc[g]]; anc[g] = anc[anc[g]]
+        const int src = anc >= 0 ? anc : lane;
+        const int aok = __shfl((int)ok, src), aanc = __shfl(anc, src);
+        if (anc >= 0) { ok = ok && aok != 0; anc = aanc; }
+    }
+    return __builtin_amdgcn_ballot_w64(ok);
+}
+
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((__vector_size__(16 * sizeof(float)))) float f32x16;
 typedef __attribute__((__vector_size__(4 * sizeof(int)))) int i32x4;
@@ -1340,6 +1383,7 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_primary_mfma(const RenderParams P) {
         store_bundle(s_bun[wv], axis, axis, false, cmin, P.cull != 0);
     }
     __builtin_amdgcn_wave_barrier();
+    const unsigned long long passed = P.nguard_cached > 0 ? tile_guard_mask(P, x0, P.row0 + ly0) : 0ull;
     unsigned nexact = 0, nblocks = 0;
     WaveQueues Q = {s_q1[wv], s_q2[wv], 0u, 0u};
     culled_scan(blocks, P.mf_cone, P.mf_groups, s_bun[wv], s_list[wv], B, Q, c, h, nblocks,
@@ -1367,7 +1411,7 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_primary_mfma(const RenderParams P) {
             double ix, iy, iz, tt;
             ++nexact;
             const bool hit = (kind == LEAF_TRI ? leaf_isect<LEAF_TRI>(L, ray, ix, iy, iz, tt, RT_TALK(P)) : leaf_isect<LEAF_RECT>(L, ray, ix, iy, iz, tt, RT_TALK(P)))
-                             && guards_ok(P.guards, L.guard, ray);
+                             && guards_ok(P.guards, L.guard, ray, passed);
 #ifdef RT_COUNT_EVENTS
             if (hit) atomicAdd(&P.counters[3], 1ull);
 #endif
@@ -1886,6 +1930,7 @@ static int render_rows(rt_scene *s, int w, int h, int depth, int spp, uint64_t s
     P.sph_rec = s->dev.sph_rec; P.gen_sph = s->dev.gen_sph; P.sph_gid = s->dev.sph_gid; P.nsph = (int)s->sph_gid.size();
     P.mf_rows = s->dev.mf_rows; P.mf_gid = s->dev.mf_gid; P.mf_rec = s->dev.mf_rec; P.mf_groups = s->mf_groups;
     P.mf_cone = s->dev.mf_cone; P.cull = g_cull ? 1 : 0;
+    P.nguard_cached = (g_cull && !s->talk) ? s->guard_cached : 0;
     P.cam = fixed_camera(w, h);
     P.eps = ray_eps();
     P.ntri = (int)s->tri_gid.size(); P.nrect = (int)s->rect_gid.size();

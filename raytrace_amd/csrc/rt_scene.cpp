@@ -531,18 +531,61 @@ static void assign_guards(rt_scene &s, int id, int parent) {
         assign_guards(s, n.kids[k], cur);
     }
 }
+// Renumbers the guard boxes so that the (at most) 64 boxes with the most leaves beneath them come first, parents
+// before children: a wave of k_primary_mfma decides once, for its whole pixel tile, which of those every ray of the
+// tile certainly passes (rt_kernels.hip: tile_guard_mask), and a leaf's chain walk stops at the first such box whose
+// ancestors are all of that kind.  A box has at least as many leaves beneath it as any box below it, so the set is
+// closed under "parent of".
+static void order_guards(rt_scene &s) {
+    const size_t n = s.guards.size();
+    s.guard_cached = 0;
+    if (n == 0) return;
+    std::vector<long long> count(n, 0);
+    std::vector<int> depth(n, 0);
+    for (size_t g = 0; g < n; ++g) depth[g] = s.guards[g].parent < 0 ? 0 : depth[s.guards[g].parent] + 1;   // parents are created first
+    for (const LeafD &L : s.leaves) for (int g = L.guard; g >= 0; g = s.guards[g].parent) ++count[g];
+    std::vector<int> order(n);
+    for (size_t g = 0; g < n; ++g) order[g] = (int)g;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+        return count[a] != count[b] ? count[a] > count[b] : depth[a] < depth[b];
+    });
+    const size_t k = std::min<size_t>(64, n);
+    std::vector<char> chosen(n, 0);
+    size_t taken = 0;
+    for (size_t i = 0; i < n && taken < k; ++i) {           // (a box whose parent was not taken is left out: keeps the set closed)
+        const int g = order[i], p = s.guards[g].parent;
+        if (p < 0 || chosen[p]) { chosen[g] = 1; ++taken; }
+    }
+    std::vector<int> renum(n, -1);
+    int next = 0;
+    for (size_t i = 0; i < n; ++i) if (chosen[order[i]]) renum[order[i]] = next++;
+    s.guard_cached = next;
+    for (size_t g = 0; g < n; ++g) if (!chosen[g]) renum[g] = next++;
+    std::vector<GuardD> out(n);
+    for (size_t g = 0; g < n; ++g) {
+        GuardD B = s.guards[g];
+        if (B.parent >= 0) B.parent = renum[B.parent];
+        out[renum[g]] = B;
+    }
+    s.guards.swap(out);
+    for (LeafD &L : s.leaves) if (L.guard >= 0) L.guard = renum[L.guard];
+}
 bool compute_guards(rt_scene &s) {
     if (!s.open.empty()) { set_error("rt_render: an rt_begin_mconcat/rt_begin_mappend bracket is still open"); return false; }
     s.guards.clear();
+    s.guard_cached = 0;
     if (s.talk) {                                         // Talk.hs:185-194: the monoid has no bounding boxes
         for (LeafD &L : s.leaves) L.guard = -1;
         return true;
     }
     if (s.top.empty()) return true;
-    if (s.top.size() == 1) { assign_guards(s, s.top[0], -1); return true; }
-    s.nodes.push_back(GNode{1, -1, s.top});                // implicit top-level mconcat
-    assign_guards(s, (int)s.nodes.size() - 1, -1);
-    s.nodes.pop_back();
+    if (s.top.size() == 1) assign_guards(s, s.top[0], -1);
+    else {
+        s.nodes.push_back(GNode{1, -1, s.top});                // implicit top-level mconcat
+        assign_guards(s, (int)s.nodes.size() - 1, -1);
+        s.nodes.pop_back();
+    }
+    order_guards(s);
     return true;
 }
 

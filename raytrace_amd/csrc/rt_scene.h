@@ -65,6 +65,7 @@ struct rt_scene {
     std::vector<int> top;                 // children outside any bracket
     std::vector<rt::AuxD> aux;
     std::vector<rt::GuardD> guards;       // guard-box chains, rebuilt by compute_guards
+    int guard_cached = 0;                 // guards [0, guard_cached): the boxes above the most leaves, parents first (<= 64)
     std::vector<rt::MaterialD> mats;
     std::vector<rt::LightD> lights;
     std::vector<int32_t> tri_gid, rect_gid, sph_gid;
