@@ -456,3 +456,84 @@ def test_tile_bound_keeps_the_block_of_every_oracle_hit(name, w, h):
     if name == "default":
         assert passed < 0.5 * total
     sc.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# Guard boxes a whole pixel tile certainly passes (rt_kernels.hip: tile_guard_mask)
+
+def intersect_bb(box, ray):
+    """intersectBB, Main.hs:152-174, in IEEE double with the reference's expression order."""
+    x0, y0, z0, x1, y1, z1 = box
+    px, py, pz, dx, dy, dz, rx, ry, rz = ray
+
+    def xy(z):
+        t = (z - pz) * rz
+        a, b = px + t * dx, py + t * dy
+        return t >= 0 and x0 <= a <= x1 and y0 <= b <= y1
+
+    def yz(x):
+        t = (x - px) * rx
+        a, b = py + t * dy, pz + t * dz
+        return t >= 0 and y0 <= a <= y1 and z0 <= b <= z1
+
+    def xz(y):
+        t = (y - py) * ry
+        a, b = px + t * dx, pz + t * dz
+        return t >= 0 and x0 <= a <= x1 and z0 <= b <= z1
+
+    return xy(z0) or xy(z1) or xz(y0) or xz(y1) or yz(x0) or yz(x1)
+
+
+def tile_certainly_passes(cam, x0, y0, box):
+    """The per-box part of tile_guard_mask, same arithmetic (IEEE double)."""
+    sx, sy, dX, dY, d = cam
+    bx0, by0, bz0, bx1, by1, bz1 = box
+    xa, xb = sx * float(x0 - 1) + dX, sx * float(x0 + 32) + dX
+    ya, yb = sy * float(y0 - 1) + dY, sy * float(y0 + 8) + dY
+    XL, XH, YL, YH = min(xa, xb), max(xa, xb), min(ya, yb), max(ya, yb)
+    ok = False
+    for zf in (bz1, bz0):
+        q = zf / d
+        sc = 1.0 + q
+        lx, hx, ly, hy = XL * sc, XH * sc, YL * sc, YH * sc
+        mx = 1e-9 * (abs(bx0) + abs(bx1) + abs(lx) + abs(hx)) + 1e-300
+        my = 1e-9 * (abs(by0) + abs(by1) + abs(ly) + abs(hy)) + 1e-300
+        ok |= q > 1e-9 and bx0 + mx <= lx and hx <= bx1 - mx and by0 + my <= ly and hy <= by1 - my
+    return ok
+
+
+@pytest.mark.parametrize("name,w,h", [("default", 96, 96), ("stacked_cubes", 128, 72), ("cylinder_axes", 100, 80), ("synthetic", 160, 90)])
+def test_tiles_that_certainly_pass_a_guard_box_do(name, w, h):
+    """Whenever the tile test says "every ray of this tile passes the box", intersectBB is True for the rays of all its
+    pixels; and for the big shared boxes of the synthetic scene the test does say so."""
+    world, lights = scenes.synthetic(ntri=300, ncuboid=40) if name == "synthetic" else scenes.REFERENCE_SCENES[name]()
+    sc = api.Scene(world, lights)
+    L = _lib.lib()
+    assert L.rt_scene_prepare_host(sc.handle, w, h) >= 0
+    buf = (C.c_double * (6 * 4096))()
+    boxes = set()
+    for i in range(sc.num_leaves):
+        n = L.rt_scene_get_guards(sc.handle, i, buf, 4096)
+        for k in range(n):
+            boxes.add(tuple(buf[6 * k:6 * k + 6]))
+    assert boxes
+    cam = (C.c_double * 5)()
+    L.rt_camera_params(w, h, cam)
+    ray = (C.c_double * 9)()
+    said_yes = pairs = 0
+    for y0 in range(0, h, 8):
+        for x0 in range(0, w, 32):
+            rays = []
+            for y in range(y0, min(h, y0 + 8)):
+                for x in range(x0, min(w, x0 + 32)):
+                    ob.lib().orc_camera_ray(w, h, x, y, ray)
+                    rays.append(tuple(ray))
+            for box in boxes:
+                pairs += 1
+                if tile_certainly_passes(tuple(cam), x0, y0, box):
+                    said_yes += 1
+                    assert all(intersect_bb(box, r) for r in rays), f"{name}: tile ({x0},{y0}) box {box}"
+    print(f"{name}: {said_yes} of {pairs} (tile, box) pairs certainly pass")
+    if name == "synthetic":
+        assert said_yes > 0.1 * pairs
+    sc.close()
