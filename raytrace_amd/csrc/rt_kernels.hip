@@ -922,6 +922,55 @@ __device__ __forceinline__ unsigned long long tile_guard_mask(const RenderParams
     return __builtin_amdgcn_ballot_w64(ok);
 }
 
+// The same for the shadow rays of one wave (Main.hs:472: origin o = hit + 1e-5 L^, direction L^ towards the light at lp):
+// all origins lie in the box [lo, hi].  A ray crosses the plane a = f of a guard box at the fraction
+// u = (f - o_a) / (lp_a - o_a) of the way to the light (u > 0: ahead of the origin), which is monotone in o_a, and the
+// other two coordinates of the crossing, o_b + (lp_b - o_b) u, are bilinear in (o_b, u): their extremes over the box
+// of origins are at its corners.  If for some face every crossing lies inside the face, with a margin 10^6 times the
+// rounding errors of intersectBB's arithmetic, that face's test holds for every ray of the wave.
+__device__ __forceinline__ unsigned long long bundle_guard_mask(const RenderParams &P, const LightD &Lt, const double (&lo)[3], const double (&hi)[3]) {
+    const int lane = (int)(threadIdx.x & 63u);
+    bool ok = false;
+    int anc = -1;
+    if (lane < P.nguard_cached) {
+        const GuardD B = P.guards[lane];
+        anc = B.parent;
+        const double b0[3] = {B.x0, B.y0, B.z0}, b1[3] = {B.x1, B.y1, B.z1}, lp[3] = {Lt.px, Lt.py, Lt.pz};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const double f = s ? b1[a] : b0[a];
+                const double n0 = f - lo[a], n1 = f - hi[a], d0 = lp[a] - lo[a], d1 = lp[a] - hi[a];
+                const double tiny = 1e-9 * (fabs(f) + fabs(lp[a]) + fabs(lo[a]) + fabs(hi[a])) + 1e-300;
+                // every origin strictly on one side of the face and of the light's coordinate, and the face ahead; the light
+                // is farther than the 1e-5 that separates the origin from the hit point the direction was taken from
+                const double far = tiny + 1e-4;
+                bool face = (n0 > tiny && n1 > tiny && d0 > far && d1 > far) || (n0 < -tiny && n1 < -tiny && d0 < -far && d1 < -far);
+                const double u0 = n0 / d0, u1 = n1 / d1;
+                const double ul = fmin(u0, u1), uh = fmax(u0, u1);
+#pragma unroll
+                for (int k = 1; k < 3; ++k) {
+                    const int b = (a + k) % 3;
+                    const double v00 = lo[b] + (lp[b] - lo[b]) * ul, v01 = lo[b] + (lp[b] - lo[b]) * uh;
+                    const double v10 = hi[b] + (lp[b] - hi[b]) * ul, v11 = hi[b] + (lp[b] - hi[b]) * uh;
+                    const double vl = fmin(fmin(v00, v01), fmin(v10, v11)), vh = fmax(fmax(v00, v01), fmax(v10, v11));
+                    const double m = 1e-9 * (fabs(b0[b]) + fabs(b1[b]) + (fabs(lp[b]) + fabs(lo[b]) + fabs(hi[b])) * (1.0 + uh)) + 1e-300;
+                    face = face && b0[b] + m <= vl && vh <= b1[b] - m;
+                }
+                ok |= face;
+            }
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < 6; ++it) {                               // ok[g] &= ok[anc[g]]; anc[g] = anc[anc[g]]
+        const int src = anc >= 0 ? anc : lane;
+        const int aok = __shfl((int)ok, src), aanc = __shfl(anc, src);
+        if (anc >= 0) { ok = ok && aok != 0; anc = aanc; }
+    }
+    return __builtin_amdgcn_ballot_w64(ok);
+}
+
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((__vector_size__(16 * sizeof(float)))) float f32x16;
 typedef __attribute__((__vector_size__(4 * sizeof(int)))) int i32x4;
@@ -1178,6 +1227,7 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_shadow_mfma(const RenderParams P) {
     const int wv = (int)(threadIdx.x >> 6);
     f16x8 B[8];
     float ux[8], uy[8], uz[8];              // unit directions of the lane's 8 rays (0: no ray), for the bundle cone
+    double olo[3] = {INFINITY, INFINITY, INFINITY}, ohi[3] = {-INFINITY, -INFINITY, -INFINITY};   // box of the ray origins
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
         const unsigned j = wave * 256u + (unsigned)(b * 32 + c);
@@ -1189,9 +1239,12 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_shadow_mfma(const RenderParams P) {
             const HitRec H = P.hitrec[pix];
             double tx, ty, tz;
             to_light(RT_TALK(P), Lt, H.px, H.py, H.pz, tx, ty, tz);
-            dx = (float)((H.px + 0.00001 * tx) - Lt.px);
-            dy = (float)((H.py + 0.00001 * ty) - Lt.py);
-            dz = (float)((H.pz + 0.00001 * tz) - Lt.pz);
+            const double o[3] = {H.px + 0.00001 * tx, H.py + 0.00001 * ty, H.pz + 0.00001 * tz};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { olo[k] = fmin(olo[k], o[k]); ohi[k] = fmax(ohi[k], o[k]); if (o[k] != o[k]) olo[k] = o[k]; }
+            dx = (float)(o[0] - Lt.px);
+            dy = (float)(o[1] - Lt.py);
+            dz = (float)(o[2] - Lt.pz);
         }
         if (h == 0) {
             const int e = b * 32 + c;
@@ -1267,6 +1320,18 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_shadow_mfma(const RenderParams P) {
         store_bundle(s_bun[wv], p, q, arc, cmin, P.cull != 0 && !bad);
     }
     __builtin_amdgcn_wave_barrier();
+    unsigned long long passed = 0ull;
+    if (P.nguard_cached > 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) {
+                const double l2 = __shfl_xor(olo[k], o), h2 = __shfl_xor(ohi[k], o);
+                olo[k] = (l2 != l2 || olo[k] != olo[k]) ? (double)NAN : fmin(olo[k], l2);       // a NaN origin: nothing is certain
+                ohi[k] = fmax(ohi[k], h2);
+            }
+        passed = bundle_guard_mask(P, Lt, olo, ohi);
+    }
     const size_t ro = (size_t)__builtin_amdgcn_readfirstlane(Lt.rec_offset);
     const size_t gstride = (size_t)(P.mf_groups + 2);
     const i32x4 *blocks = reinterpret_cast<const i32x4 *>(P.mf_rows) + ro * gstride * 32;
@@ -1298,7 +1363,7 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_shadow_mfma(const RenderParams P) {
             double ix, iy, iz, tt;
             ++nexact;
             const bool hit = kind == LEAF_TRI ? leaf_isect<LEAF_TRI>(L, ray, ix, iy, iz, tt, RT_TALK(P)) : leaf_isect<LEAF_RECT>(L, ray, ix, iy, iz, tt, RT_TALK(P));
-            if (hit && guards_ok(P.guards, L.guard, ray)) {
+            if (hit && guards_ok(P.guards, L.guard, ray, passed)) {
                 const double tl = (Lt.pz - ray.pz) * ray.rz;                       // rayDistance ray lpos
                 const bool occ = RT_TALK(P) ? ((Lt.px - ix) * tx + (Lt.py - iy) * ty + (Lt.pz - iz) * tz >= 0)   // Talk.hs:242
                                         : (tt <= tl);                               // Main.hs:474
