@@ -103,6 +103,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--filter", default="mfma", choices=["mfma", "valu"],
                     help="first stage: bounding cones on the matrix cores (default) or the FP32 vector-ALU kernels")
+    ap.add_argument("--no-brute-force-leg", action="store_true", help="skip the extra frames rendered with the block test off (profiling runs)")
     ap.add_argument("--no-cull", action="store_true", help="every wave scans every block of the leaf stream (RT_CULL=0): the plain brute-force scan")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the measured path) or gloo (rehearsal on one GPU)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank renders on GPU 0 (gloo only)")
@@ -295,7 +296,7 @@ def main():
                                  "matrix-core work actually issued against the dense FP16 peak, and brute_force_scan is the same frame "
                                  "with the block test off (every wave scans every block)"},
         }
-        if n == 1 and mfma and not args.no_cull:
+        if n == 1 and mfma and not args.no_cull and not args.no_brute_force_leg:
             # the same frame with the block test off (every wave scans every block), timed the same way
             os.environ["RT_CULL"] = "0"
             _lib.check(_lib.lib().rt_init(local_rank), "rt_init")

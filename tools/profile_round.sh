@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 run() {  # name, rocprofv3 args...
     local name=$1; shift
-    timeout -s KILL 200 rocprofv3 "$@" -d $R/gpurun_out/prof_${TAG}_$name -o $name -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $R/gpurun_out/prof_${TAG}_$name.log 2>&1 || return 1
+    timeout -s KILL 200 rocprofv3 "$@" -d $R/gpurun_out/prof_${TAG}_$name -o $name -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-brute-force-leg > $R/gpurun_out/prof_${TAG}_$name.log 2>&1 || return 1
     python $R/tools/rocprof_summary.py $(ls $R/gpurun_out/prof_${TAG}_$name/*.db $R/gpurun_out/prof_${TAG}_$name/*/*.db 2>/dev/null | head -1) > $R/gpurun_out/prof_${TAG}_$name.txt
 }
 run trace --kernel-trace --stats &&
