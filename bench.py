@@ -43,12 +43,12 @@ PEAK_FP32_TFLOPS = 157.3                        # MI355X_MICROARCH.md: peak FP32
 PEAK_MFMA_F16_TFLOPS = 2500.0                   # MI355X_MICROARCH.md: peak BF16/FP16 MFMA, dense
 MFMA_FLOPS = 2 * 32 * 32 * 16                   # one v_mfma_f32_32x32x16_f16
 # HBM bytes of one k_primary_mfma launch on the default N = 1 workload, from the PMC passes committed under
-# profiles/ (r01_final_pmc_rd / _wr, separate passes): FETCH_SIZE 9 685 KiB and WRITE_SIZE 33 133 KiB per dispatch.
-# MI355X_MICROARCH.md: on gfx950 FETCH_SIZE tallies a 16-B-per-lane streaming read at half its bytes — the kernel's
-# reads are dominated by exactly such a stream (the leaf rows, one global_load_dwordx4 per lane and block) — so the
-# read figure is doubled; WRITE_SIZE is taken as reported (the hit-ID buffer alone is 4 B x 8 294 400 px = 32 400 KiB).
+# profiles/ (r01_cull_pmc_rd / _wr, separate passes): FETCH_SIZE 9 265 KiB and WRITE_SIZE 34 145 KiB per dispatch.
+# MI355X_MICROARCH.md: on gfx950 FETCH_SIZE tallies 16-B-per-lane reads at half their bytes; the kernel's reads (block
+# cones, leaf rows, FP32 records) are mostly of that kind, so the read figure is doubled (an upper bound); WRITE_SIZE is
+# taken as reported (the hit-ID buffer alone is 4 B x 8 294 400 px = 32 400 KiB).
 # The counters cannot be read from inside this process; for any other workload traffic is null.
-K_PRIMARY_TRAFFIC_BYTES_DEFAULT = (2 * 9685 + 33133) * 1024
+K_PRIMARY_TRAFFIC_BYTES_DEFAULT = (2 * 9265 + 34145) * 1024
 
 
 def balanced_bands(scene, w, h, n, depth):
@@ -282,11 +282,13 @@ def main():
             "roofline": {"bound": "mfma" if mfma else "valu_fp32", "kernel": "k_primary_mfma" if mfma else "k_primary",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": K_PRIMARY_TRAFFIC_BYTES_DEFAULT if (mfma and n == 1 and args.spp == 1 and args.workload == "synthetic" and (w, h, ntri, nrect) == (3840, 2160, 10000, 6000)) else None,
-                         "traffic_unit": "bytes per launch (rocprofv3 --pmc: 2 x FETCH_SIZE (gfx950 correction for 16-B-per-lane reads) + WRITE_SIZE, profiles/r01_final_pmc_*)",
+                         "traffic_unit": "bytes per launch (rocprofv3 --pmc: 2 x FETCH_SIZE (gfx950 correction for 16-B-per-lane reads) + WRITE_SIZE, profiles/r01_cull_pmc_*)",
                          "frac_of_fp32_valu_peak": achieved / PEAK_FP32_TFLOPS,
                          "executed_mfma_tflops": executed if mfma else None,
                          "executed_mfma_frac": executed / PEAK_MFMA_F16_TFLOPS if mfma else None,
                          "leaf_blocks_scanned_frac": scanned_frac if mfma else None,
+                         "k_shadow_mfma": {"ms": ms_shade, "achieved_algorithmic_tflops": shadow / n * per_test / (ms_shade * 1e-3) / 1e12,
+                                           "executed_mfma_tflops": float(stats["mfma_blocks_shadow"]) * 8 * MFMA_FLOPS / (ms_shade * 1e-3) / 1e12} if mfma and ms_shade > 0 else None,
                          "note": "achieved = algorithmic flops (53/45 per ray x triangle/rectangle test, SURVEY.md 8d) x primary rays x leaves "
                                  "of one launch / its HIP-event time. The kernel decides every pair but executes far fewer flops: a wave "
                                  "skips the blocks of 32 leaves whose bounding cone misses the bound of its 256 rays "
