@@ -25,6 +25,7 @@
 #include <cmath>
 #include <cstdio>
 #include <string>
+#include <vector>
 
 #include "rt_scene.h"
 
@@ -171,6 +172,14 @@ __device__ __forceinline__ RayD camera_ray(const RenderParams &P, int x, int y) 
     return mkray(posX, posY, 0.0, posX / n, posY / n, P.cam.d / n, P.eps);
 }
 
+// Statistics counters: RT_STAT_SLOTS copies of the 8 counters, one 128-byte line each, picked by wave number.  Every
+// wave adds to them once, and atomics on ONE address are serialised by the L2 (12 ns each: 0.4 ms for the 32 400 waves
+// of a 4K frame, which is what a single set of counters cost); rt_get_stats sums the copies.
+constexpr int RT_STAT_SLOTS = 256;
+__device__ __forceinline__ void stat_add(const RenderParams &P, int k, unsigned long long v) {
+    const unsigned wave = (blockIdx.x + blockIdx.y * gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    atomicAdd(&P.counters[(size_t)(wave % RT_STAT_SLOTS) * 16 + k], v);
+}
 __device__ __forceinline__ unsigned num_slots(const RenderParams &P) {
     if (!P.count_ptr) return (unsigned)P.qcap;
     const unsigned c = *P.count_ptr;
@@ -529,7 +538,7 @@ __global__ void RT_HOT(RT_WAVES_EU_PRIMARY) k_primary(const RenderParams P) {
     for (int r = 0; r < 4; ++r)
         if (act[r]) P.hit_id[row + (x0 + r)] = bid[r];
     for (int o = 32; o > 0; o >>= 1) nexact += __shfl_down(nexact, o);
-    if ((threadIdx.x & 63) == 0 && nexact) atomicAdd(&P.counters[1], (unsigned long long)nexact);
+    if ((threadIdx.x & 63) == 0 && nexact) stat_add(P, 1, (unsigned long long)nexact);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -699,7 +708,7 @@ __global__ void __launch_bounds__(1024) k_queue_offsets(const RenderParams P) {
     for (int k = lo; k < hi; ++k) { const unsigned c = cnt[k]; cnt[k] = run; run += c; }
     if (t == 1023) {
         P.qcount[pl] = s_part[1023];
-        if (s_part[1023]) atomicAdd(&P.counters[0], (unsigned long long)s_part[1023]);
+        if (s_part[1023]) stat_add(P, 0, (unsigned long long)s_part[1023]);
     }
 }
 
@@ -728,7 +737,7 @@ __device__ __forceinline__ void shadow_loop(const RenderParams &P, CRecPtr recs,
         if (filter4<KIND, RT_SHADOW_CLIP != 0>(cur, D, z)) {
             const float negm = cur.c[9];
 #ifdef RT_COUNT_EVENTS
-            if ((threadIdx.x & 63) == __builtin_amdgcn_readfirstlane(threadIdx.x & 63)) atomicAdd(&P.counters[3], 1ull);
+            if ((threadIdx.x & 63) == __builtin_amdgcn_readfirstlane(threadIdx.x & 63)) stat_add(P, 3, 1ull);
 #endif
             bool cand[4];
 #pragma unroll
@@ -749,7 +758,7 @@ __device__ __forceinline__ void shadow_loop(const RenderParams &P, CRecPtr recs,
                 const int gid = gids[i];
                 const LeafD &L = P.leaves[gid];
 #ifdef RT_COUNT_EVENTS
-                if ((threadIdx.x & 63) == __builtin_amdgcn_readfirstlane(threadIdx.x & 63)) atomicAdd(&P.counters[4], 1ull);
+                if ((threadIdx.x & 63) == __builtin_amdgcn_readfirstlane(threadIdx.x & 63)) stat_add(P, 4, 1ull);
 #endif
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -869,7 +878,7 @@ __global__ void RT_HOT(RT_WAVES_EU_SHADOW) k_shadow(const RenderParams P) {
     for (int r = 0; r < 4; ++r)
         if (need[r]) atomicOr(&P.lit[pix[r]], 1u << pl);
     for (int o = 32; o > 0; o >>= 1) nexact += __shfl_down(nexact, o);
-    if (lane == 0 && nexact) atomicAdd(&P.counters[2], (unsigned long long)nexact);
+    if (lane == 0 && nexact) stat_add(P, 2, (unsigned long long)nexact);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1394,8 +1403,8 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_shadow_mfma(const RenderParams P) {
     for (int r = 0; r < 4; ++r)
         if (nd[r]) atomicOr(&P.lit[pix[r]], 1u << pl);
     for (int o = 32; o > 0; o >>= 1) nexact += __shfl_down(nexact, o);
-    if (lane == 0 && nexact) atomicAdd(&P.counters[2], (unsigned long long)nexact);
-    if (lane == 0) atomicAdd(&P.counters[7], (unsigned long long)nblocks);
+    if (lane == 0 && nexact) stat_add(P, 2, (unsigned long long)nexact);
+    if (lane == 0) stat_add(P, 7, (unsigned long long)nblocks);
 }
 
 // Kernel 1 on the matrix cores.  One wave = 32 x 8 pixel tile; ray block b = tile row b, column c = lane & 31.
@@ -1451,6 +1460,9 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_primary_mfma(const RenderParams P) {
     const unsigned long long passed = P.nguard_cached > 0 ? tile_guard_mask(P, x0, P.row0 + ly0) : 0ull;
     unsigned nexact = 0, nblocks = 0;
     WaveQueues Q = {s_q1[wv], s_q2[wv], 0u, 0u};
+#ifdef RT_X_NOSCAN
+    if (P.w < 0)
+#endif
     culled_scan(blocks, P.mf_cone, P.mf_groups, s_bun[wv], s_list[wv], B, Q, c, h, nblocks,
         [&](uint32_t entry) -> bool {           // FP32 record test of one (pixel, leaf) pair
             const int e = (int)(entry & 255u);
@@ -1463,7 +1475,7 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_primary_mfma(const RenderParams P) {
             const float py = (float)(P.cam.scaleY * ((double)ye + oy) + P.cam.dY);
             // eye records are affine in (posX, posY): the z column already holds c_z * d
 #ifdef RT_COUNT_EVENTS
-            atomicAdd(&P.counters[4], 1ull);
+            stat_add(P, 4, 1ull);
 #endif
             return gid >= 0 && record_test(R, kind, px, py, 1.0f);
         },
@@ -1478,7 +1490,7 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_primary_mfma(const RenderParams P) {
             const bool hit = (kind == LEAF_TRI ? leaf_isect<LEAF_TRI>(L, ray, ix, iy, iz, tt, RT_TALK(P)) : leaf_isect<LEAF_RECT>(L, ray, ix, iy, iz, tt, RT_TALK(P)))
                              && guards_ok(P.guards, L.guard, ray, passed);
 #ifdef RT_COUNT_EVENTS
-            if (hit) atomicAdd(&P.counters[3], 1ull);
+            if (hit) stat_add(P, 3, 1ull);
 #endif
             // Nearest wins; equal t -> the left-most leaf of the tree (Main.hs:213-214).  Several lanes may hold hits of
             // the same pixel: the wave runs in lockstep and its LDS operations complete in order, so (1) all read the
@@ -1544,8 +1556,8 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_primary_mfma(const RenderParams P) {
     for (int r = 0; r < 4; ++r)
         if (act[r]) P.hit_id[P.out_off + (long long)(ly0 + 4 * h + r) * P.w + x] = mid[r];
     for (int o = 32; o > 0; o >>= 1) nexact += __shfl_down(nexact, o);
-    if (lane == 0 && nexact) atomicAdd(&P.counters[1], (unsigned long long)nexact);
-    if (lane == 0) atomicAdd(&P.counters[6], (unsigned long long)nblocks);
+    if (lane == 0 && nexact) stat_add(P, 1, (unsigned long long)nexact);
+    if (lane == 0) stat_add(P, 6, (unsigned long long)nblocks);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1748,7 +1760,7 @@ __global__ void RT_HOT(4) k_general(const RenderParams P) {
     for (int r = 0; r < 4; ++r)
         if (act[r]) P.hit_id[P.out_off + slot[r]] = bid[r];
     for (int o2 = 32; o2 > 0; o2 >>= 1) nexact += __shfl_down(nexact, o2);
-    if (lane == 0 && nexact) atomicAdd(&P.counters[1], (unsigned long long)nexact);
+    if (lane == 0 && nexact) stat_add(P, 1, (unsigned long long)nexact);
 }
 
 // colour of a level folded into the level below: addPixelRGB8 direct (scalePixelRGB8 reflectivity sub), Main.hs:545, 554
@@ -1858,7 +1870,7 @@ int prepare(rt_scene &s, int w, int h) {
         }
         if ((rc = upload(s.dev.tri_gid, s.tri_gid))) return rc;
         if ((rc = upload(s.dev.rect_gid, s.rect_gid))) return rc;
-        if (!s.dev.counters) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s.dev.counters), 8 * sizeof(unsigned long long)));
+        if (!s.dev.counters) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s.dev.counters), RT_STAT_SLOTS * 16 * sizeof(unsigned long long)));
         if (!s.dev.qcount) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s.dev.qcount), 64 * sizeof(unsigned)));
         s.dev.device = g_device;
         s.dirty = false;
@@ -1980,7 +1992,7 @@ static int render_rows(rt_scene *s, int w, int h, int depth, int spp, uint64_t s
         if ((rc = ensure(s->dev.accum, s->dev.accum_cap, 3 * npix))) return rc;
         HIP_TRY(hipMemsetAsync(s->dev.accum, 0, 3 * npix * sizeof(uint32_t), st));
     }
-    if (!more) HIP_TRY(hipMemsetAsync(s->dev.counters, 0, 8 * sizeof(unsigned long long), st));
+    if (!more) HIP_TRY(hipMemsetAsync(s->dev.counters, 0, RT_STAT_SLOTS * 16 * sizeof(unsigned long long), st));
 
     // the vector-ALU kernels are compiled for Main.hs only: a Talk.hs scene always takes the matrix-core kernels
     const bool use_mfma = g_use_mfma || s->talk;
@@ -2155,8 +2167,10 @@ int rt_get_stats(rt_scene *s, rt_stats *out) {
     if (!s || !out) { set_error("rt_get_stats: NULL argument"); return RT_ERR_ARG; }
     if (s->stats_pending && s->ev_used > 0) {
         HIP_TRY(hipEventSynchronize((hipEvent_t)s->evpool[s->ev_used - 1]));
-        unsigned long long c[8];
-        HIP_TRY(hipMemcpy(c, s->dev.counters, sizeof c, hipMemcpyDeviceToHost));
+        static thread_local std::vector<unsigned long long> all(RT_STAT_SLOTS * 16);
+        HIP_TRY(hipMemcpy(all.data(), s->dev.counters, all.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        unsigned long long c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int slot = 0; slot < RT_STAT_SLOTS; ++slot) for (int k = 0; k < 8; ++k) c[k] += all[(size_t)slot * 16 + k];
         double ms[5] = {0, 0, 0, 0, 0};
         for (int i = 1; i < s->ev_used; ++i) {
             float t = 0;
