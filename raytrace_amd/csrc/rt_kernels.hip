@@ -1237,8 +1237,11 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_shadow_mfma(const RenderParams P) {
     f16x8 B[8];
     float ux[8], uy[8], uz[8];              // unit directions of the lane's 8 rays (0: no ray), for the bundle cone
     double olo[3] = {INFINITY, INFINITY, INFINITY}, ohi[3] = {-INFINITY, -INFINITY, -INFINITY};   // box of the ray origins
+    // lane half h sets up the rays of blocks 4h .. 4h + 3 (hit record, FP64 direction to the light) and leaves them in
+    // LDS; then every lane picks up column c of all 8 blocks
 #pragma unroll
-    for (int b = 0; b < 8; ++b) {
+    for (int r = 0; r < 4; ++r) {
+        const int b = 4 * h + r;
         const unsigned j = wave * 256u + (unsigned)(b * 32 + c);
         const bool ok = j < count;
         float dx = 0.f, dy = 0.f, dz = 0.f;
@@ -1255,13 +1258,18 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_shadow_mfma(const RenderParams P) {
             dy = (float)(o[1] - Lt.py);
             dz = (float)(o[2] - Lt.pz);
         }
-        if (h == 0) {
-            const int e = b * 32 + c;
-            s_d[wv][0][e] = dx; s_d[wv][1][e] = dy; s_d[wv][2][e] = dz;
-            s_pix[wv][e] = pix;
-            s_own[wv][e] = ok ? P.hit_id[P.out_off + pix] : -1;
-            s_occ[wv][e] = ok ? 0u : 1u;          // a ray that does not exist counts as occluded: never lit
-        }
+        const int e = b * 32 + c;
+        s_d[wv][0][e] = dx; s_d[wv][1][e] = dy; s_d[wv][2][e] = dz;
+        s_pix[wv][e] = pix;
+        s_own[wv][e] = ok ? P.hit_id[P.out_off + pix] : -1;
+        s_occ[wv][e] = ok ? 0u : 1u;          // a ray that does not exist counts as occluded: never lit
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        const int e = b * 32 + c;
+        const float dx = s_d[wv][0][e], dy = s_d[wv][1][e], dz = s_d[wv][2][e];
+        const bool ok = s_occ[wv][e] == 0u;
         B[b] = ray_fragment(dx, dy, dz, ok, h);
         const float rn = ok ? __builtin_amdgcn_rsqf(__builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, dz * dz))) : 0.f;
         ux[b] = dx * rn; uy[b] = dy * rn; uz[b] = dz * rn;
@@ -1334,7 +1342,7 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_shadow_mfma(const RenderParams P) {
 #pragma unroll
         for (int k = 0; k < 3; ++k)
 #pragma unroll
-            for (int o = 16; o > 0; o >>= 1) {
+            for (int o = 32; o > 0; o >>= 1) {
                 const double l2 = __shfl_xor(olo[k], o), h2 = __shfl_xor(ohi[k], o);
                 olo[k] = (l2 != l2 || olo[k] != olo[k]) ? (double)NAN : fmin(olo[k], l2);       // a NaN origin: nothing is certain
                 ohi[k] = fmax(ohi[k], h2);
