@@ -117,6 +117,7 @@ struct RenderParams {
     int talk;                       // 1: the rules of src/Talk.hs (rt_scene_set_dialect)
     uint32_t seed_lo, seed_hi;
     int tiles_x, tiles_y;
+    uint8_t point_light[32];        // index in `lights` of the k-th point light
 };
 
 struct HitRec { double px, py, pz, nx, ny, nz; };
@@ -839,8 +840,7 @@ __global__ void RT_HOT(RT_WAVES_EU_SHADOW) k_shadow(const RenderParams P) {
     if (wave * 256u >= count) return;
     const int lane = (int)(threadIdx.x & 63);
     // the pl-th point light
-    int li = 0;
-    for (int k = -1; li < P.nlights; ++li) if (P.lights[li].kind == 0 && ++k == pl) break;
+    const int li = P.point_light[pl];
     const LightD &Lt = P.lights[li];
     const uint32_t *q = P.queue + (size_t)pl * (size_t)P.qcap;
     uint32_t pix[4]; bool need[4]; int own[4];
@@ -1221,8 +1221,7 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_shadow_mfma(const RenderParams P) {
     const unsigned wave = blockIdx.x * RT_WAVES_PER_BLOCK + (threadIdx.x >> 6);
     if (wave * 256u >= count) return;
     const int lane = (int)(threadIdx.x & 63), c = lane & 31, h = lane >> 5;
-    int li = 0;
-    for (int k = -1; li < P.nlights; ++li) if (P.lights[li].kind == 0 && ++k == pl) break;
+    const int li = P.point_light[pl];
     const LightD &Lt = P.lights[li];
     const uint32_t *q = P.queue + (size_t)pl * (size_t)P.qcap;
     // per ray of the wave: D (FP32), the queue entry, the leaf it starts on, "an occluder was found"
@@ -2016,6 +2015,7 @@ static int render_rows(rt_scene *s, int w, int h, int depth, int spp, uint64_t s
     P.mf_rows = s->dev.mf_rows; P.mf_gid = s->dev.mf_gid; P.mf_rec = s->dev.mf_rec; P.mf_groups = s->mf_groups;
     P.mf_cone = s->dev.mf_cone; P.cull = g_cull ? 1 : 0;
     P.nguard_cached = (g_cull && !s->talk) ? s->guard_cached : 0;
+    for (size_t li = 0, k = 0; li < s->lights.size() && k < 32; ++li) if (s->lights[li].kind == 0) P.point_light[k++] = (uint8_t)li;
     P.cam = fixed_camera(w, h);
     P.eps = ray_eps();
     P.ntri = (int)s->tri_gid.size(); P.nrect = (int)s->rect_gid.size();
