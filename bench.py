@@ -4,7 +4,7 @@
   python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
 
 A "step" renders one frame of the synthetic scene of SURVEY.md §8(d) (10 000 triangles + 1 000
-cuboids = 16 000 leaves, 4 point lights with shadow rays, brute force over all leaves):
+cuboids = 16 000 leaves, 4 point lights with shadow rays, every ray x leaf pair decided, no hierarchy):
   N = 1 : 3840 x 2160 on one GPU                                   (BASELINE.json configs[2])
   N > 1 : 16384 x 16384 split into N contiguous row bands, one per rank, cost-balanced from a
           1/16-scale pre-render; the bands are sent to rank 0 over RCCL (xGMI) inside the timed
@@ -13,13 +13,14 @@ The scene and its FP32 filter records are resident in HBM before the timed regio
 buffer stays in HBM.  value = primary rays of the whole frame / max-over-ranks wall time.
 
 Also on the JSON line:
-  roofline      — the dominant kernel (k_primary_mfma: every primary ray against every leaf) in
-                  ALGORITHMIC flops (52 / 44 flops per ray x triangle / rectangle test + 1 for the
-                  nearest select, SURVEY.md §8 d) over its launch time (HIP events on the render
-                  stream).  The first stage of that kernel runs on the matrix cores, so the bound is
-                  "mfma" and peak is the dense FP16 MFMA peak; the same rate against the FP32 vector
-                  peak of BASELINE.json's metric, and the EXECUTED matrix-core rate (one
-                  v_mfma_f32_32x32x16_f16 = 32768 flops per 32 rays x 32 leaves), are given beside it.
+  roofline      — the dominant kernel (the longer of k_primary_mfma: every primary ray against every
+                  leaf, and k_shadow_mfma: every shadow ray against every leaf; the other one is listed
+                  under "other_kernel") in ALGORITHMIC flops (52 / 44 flops per ray x triangle /
+                  rectangle test + 1 for the nearest select, SURVEY.md §8 d) over its launch time (HIP
+                  events on the render stream).  The first stage of these kernels runs on the matrix
+                  cores, so the bound is "mfma" and peak is the dense FP16 MFMA peak; the same rate
+                  against the FP32 vector peak of BASELINE.json's metric, and the EXECUTED matrix-core
+                  rate (one v_mfma_f32_32x32x16_f16 = 32768 flops per 32 rays x 32 leaves), beside it.
   cpu_baseline  — the CPU oracle (a C restatement of the reference, NOT the Haskell program) on the
                   host cores, on a bounded band of the same frame (rank 0, N = 1 only).
 """
@@ -42,13 +43,14 @@ FLOPS_TRI, FLOPS_RECT = 52 + 1, 44 + 1
 PEAK_FP32_TFLOPS = 157.3                        # MI355X_MICROARCH.md: peak FP32 (vector), packed FMA
 PEAK_MFMA_F16_TFLOPS = 2500.0                   # MI355X_MICROARCH.md: peak BF16/FP16 MFMA, dense
 MFMA_FLOPS = 2 * 32 * 32 * 16                   # one v_mfma_f32_32x32x16_f16
-# HBM bytes of one k_primary_mfma launch on the default N = 1 workload, from the PMC passes committed under
-# profiles/ (r01_cull_pmc_rd / _wr, separate passes): FETCH_SIZE 9 265 KiB and WRITE_SIZE 34 145 KiB per dispatch.
-# MI355X_MICROARCH.md: on gfx950 FETCH_SIZE tallies 16-B-per-lane reads at half their bytes; the kernel's reads (block
-# cones, leaf rows, FP32 records) are mostly of that kind, so the read figure is doubled (an upper bound); WRITE_SIZE is
-# taken as reported (the hit-ID buffer alone is 4 B x 8 294 400 px = 32 400 KiB).
+# HBM bytes of one launch on the default N = 1 workload, from the PMC passes committed under profiles/
+# (r01_cull_pmc_rd / _wr, separate passes), KiB per dispatch: k_primary_mfma FETCH_SIZE 9 265, WRITE_SIZE 34 145 (the
+# hit-ID buffer alone is 4 B x 8 294 400 px = 32 400); k_shadow_mfma FETCH_SIZE 251 990, WRITE_SIZE 24 050 (the hit
+# records of 5.6 M shadow rays at 48 B are 263 000).  MI355X_MICROARCH.md: on gfx950 FETCH_SIZE tallies 16-B-per-lane
+# reads at half their bytes; the kernels' reads (hit records, block cones, leaf rows, FP32 records) are mostly of that
+# kind, so the read figure is doubled (an upper bound); WRITE_SIZE is taken as reported.
 # The counters cannot be read from inside this process; for any other workload traffic is null.
-K_PRIMARY_TRAFFIC_BYTES_DEFAULT = (2 * 9265 + 34145) * 1024
+TRAFFIC_BYTES_DEFAULT = {"k_primary_mfma": (2 * 9265 + 34145) * 1024, "k_shadow_mfma": (2 * 251990 + 24050) * 1024}
 
 
 def balanced_bands(scene, w, h, n, depth):
@@ -259,10 +261,16 @@ def main():
         # the wave scanned (the library counts them); the brute-force scan would visit every block for every wave
         tiles = -(-w // 32) * -(-nrows // 8)
         blocks = -(-(ntri + nrect) // 32)
-        scanned = float(stats["mfma_blocks_primary"])
-        executed = scanned * 8 * MFMA_FLOPS / (ms_prim * 1e-3) / 1e12
-        scanned_frac = scanned / max(1.0, float(tiles * blocks * args.spp)) if n == 1 else None
         peak = PEAK_MFMA_F16_TFLOPS if mfma else PEAK_FP32_TFLOPS
+
+        def kernel_line(name, rays, ms, scanned, waves):
+            return {"kernel": name + ("_mfma" if mfma else ""), "ms": ms,
+                    "achieved": rays / n * per_test / (max(ms, 1e-9) * 1e-3) / 1e12,
+                    "executed": float(scanned) * 8 * MFMA_FLOPS / (max(ms, 1e-9) * 1e-3) / 1e12,
+                    "scanned_frac": float(scanned) / max(1.0, float(waves * blocks)) if n == 1 else None}
+        kp = kernel_line("k_primary", primary, ms_prim, stats["mfma_blocks_primary"], tiles * args.spp)
+        ks = kernel_line("k_shadow", shadow, ms_shade, stats["mfma_blocks_shadow"], shadow / 256.0)
+        dom, oth = (kp, ks) if ms_prim >= ms_shade else (ks, kp)
         out = {
             "metric": "primary Mrays/s (whole node)", "value": primary / (dt / args.steps) / 1e6, "unit": "Mrays/s",
             "n_gpus": n, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
@@ -279,18 +287,20 @@ def main():
                        "shadow_rays_per_frame": shadow, "exact_fp64_evals_per_frame": exact,
                        "whole_frame_algorithmic_tflops": (primary + shadow) * per_test / (dt / args.steps) / 1e12,
                        "kernel_ms": {"k_primary": ms_prim, "k_setup": stats["ms_setup"], "k_shadow": ms_shade, "k_final": stats["ms_final"]}},
-            "roofline": {"bound": "mfma" if mfma else "valu_fp32", "kernel": "k_primary_mfma" if mfma else "k_primary",
-                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": K_PRIMARY_TRAFFIC_BYTES_DEFAULT if (mfma and n == 1 and args.spp == 1 and args.workload == "synthetic" and (w, h, ntri, nrect) == (3840, 2160, 10000, 6000)) else None,
+            "roofline": {"bound": "mfma" if mfma else "valu_fp32", "kernel": dom["kernel"],
+                         "achieved": dom["achieved"], "peak": peak, "unit": "TFLOP/s", "frac": dom["achieved"] / peak,
+                         "traffic": TRAFFIC_BYTES_DEFAULT.get(dom["kernel"]) if (n == 1 and args.spp == 1 and not args.no_cull and args.workload == "synthetic" and (w, h, ntri, nrect) == (3840, 2160, 10000, 6000)) else None,
                          "traffic_unit": "bytes per launch (rocprofv3 --pmc: 2 x FETCH_SIZE (gfx950 correction for 16-B-per-lane reads) + WRITE_SIZE, profiles/r01_cull_pmc_*)",
-                         "frac_of_fp32_valu_peak": achieved / PEAK_FP32_TFLOPS,
-                         "executed_mfma_tflops": executed if mfma else None,
-                         "executed_mfma_frac": executed / PEAK_MFMA_F16_TFLOPS if mfma else None,
-                         "leaf_blocks_scanned_frac": scanned_frac if mfma else None,
-                         "k_shadow_mfma": {"ms": ms_shade, "achieved_algorithmic_tflops": shadow / n * per_test / (ms_shade * 1e-3) / 1e12,
-                                           "executed_mfma_tflops": float(stats["mfma_blocks_shadow"]) * 8 * MFMA_FLOPS / (ms_shade * 1e-3) / 1e12} if mfma and ms_shade > 0 else None,
-                         "note": "achieved = algorithmic flops (53/45 per ray x triangle/rectangle test, SURVEY.md 8d) x primary rays x leaves "
-                                 "of one launch / its HIP-event time. The kernel decides every pair but executes far fewer flops: a wave "
+                         "launch_ms": dom["ms"],
+                         "frac_of_fp32_valu_peak": dom["achieved"] / PEAK_FP32_TFLOPS,
+                         "executed_mfma_tflops": dom["executed"] if mfma else None,
+                         "executed_mfma_frac": dom["executed"] / PEAK_MFMA_F16_TFLOPS if mfma else None,
+                         "leaf_blocks_scanned_frac": dom["scanned_frac"] if mfma else None,
+                         "other_kernel": {"kernel": oth["kernel"], "launch_ms": oth["ms"], "achieved": oth["achieved"], "frac": oth["achieved"] / peak,
+                                          "executed_mfma_tflops": oth["executed"] if mfma else None,
+                                          "leaf_blocks_scanned_frac": oth["scanned_frac"] if mfma else None},
+                         "note": "achieved = algorithmic flops (53/45 per ray x triangle/rectangle test, SURVEY.md 8d) x rays x leaves "
+                                 "of one launch (primary rays for k_primary_mfma, the shadow rays cast for k_shadow_mfma) / its HIP-event time. The kernel decides every pair but executes far fewer flops: a wave "
                                  "skips the blocks of 32 leaves whose bounding cone misses the bound of its 256 rays "
                                  "(leaf_blocks_scanned_frac of the blocks are scanned), a scanned pair costs one FP16 MFMA form, and only "
                                  "candidates reach FP32/FP64 -- so frac and frac_of_fp32_valu_peak exceed 1 and say how much cheaper than "
