@@ -1957,6 +1957,7 @@ static int render_rows(rt_scene *s, int w, int h, int depth, int spp, uint64_t s
     int rc;
     if ((rc = ensure_init())) return rc;
     if ((rc = prepare(*s, w, h))) return rc;
+    if (s->mf_groups + 2 > 65535) { set_error("rt_render: more than 2 million planar leaves are not supported (16-bit block indices)"); return RT_ERR_UNSUPPORTED; }
     hipStream_t st = stream ? (hipStream_t)stream : g_stream;
     const size_t npix = (size_t)w * (size_t)nrows;
     if (!more) { s->last_primary = 0; s->ev_used = 0; }
