@@ -598,8 +598,10 @@ __global__ void __launch_bounds__(RT_SETUP_THREADS) k_setup(const RenderParams P
     int pix = (int)(blockIdx.x * RT_SETUP_THREADS + threadIdx.x);
     bool act = (unsigned)pix < num_slots(P);
     if (!P.rays) {
+        // a wave takes 8 x 8 pixels of the tile (objects are blobs: fewer waves straddle an outline than with 32 x 2 strips)
         const int tx = (int)blockIdx.x % P.tiles_x, ty = (int)blockIdx.x / P.tiles_x;
-        const int x = tx * 32 + (int)(threadIdx.x & 31), y = ty * (RT_SETUP_THREADS / 32) + (int)(threadIdx.x >> 5);
+        const int wq = (int)(threadIdx.x >> 6), lq = (int)(threadIdx.x & 63);
+        const int x = tx * 32 + (wq & 3) * 8 + (lq & 7), y = ty * (RT_SETUP_THREADS / 32) + (wq >> 2) * 8 + (lq >> 3);
         act = x < P.w && y < P.nrows;
         pix = act ? y * P.w + x : 0;
     }
@@ -1572,8 +1574,15 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_primary_mfma(const RenderParams P) {
 //   saturating 8-bit sums, coalesced RGBA8 store.
 
 __global__ void __launch_bounds__(256) k_final(const RenderParams P) {
-    const int pix = (int)(blockIdx.x * 256 + threadIdx.x);
-    const bool act = (unsigned)pix < num_slots(P);
+    // level 0: a block takes a 32 x 8 pixel tile, a wave 8 x 8 pixels of it; bounce levels: slots in order
+    int pix = (int)(blockIdx.x * 256 + threadIdx.x);
+    bool act = (unsigned)pix < num_slots(P);
+    if (!P.rays) {
+        const int tx = (int)blockIdx.x % P.tiles_x, ty = (int)blockIdx.x / P.tiles_x;
+        const int x = tx * 32 + (int)(threadIdx.x >> 6) * 8 + (int)(threadIdx.x & 7), y = ty * 8 + (int)((threadIdx.x & 63) >> 3);
+        act = x < P.w && y < P.nrows;
+        pix = act ? y * P.w + x : 0;
+    }
     const int id = act ? P.hit_id[P.out_off + pix] : -1;
     int cr = 0, cg = 0, cb = 0;
     bool spawn = false;
@@ -2083,7 +2092,7 @@ static int render_rows(rt_scene *s, int w, int h, int depth, int spp, uint64_t s
                     else hipLaunchKernelGGL(k_shadow, dim3(sblocks, (unsigned)s->npoint), dim3(RT_WAVES_PER_BLOCK * 64), 0, st, P);
                 }
                 if ((rc = next_event(*s, st, 3))) return rc;
-                hipLaunchKernelGGL(k_final, dim3(pblocks), dim3(256), 0, st, P);
+                hipLaunchKernelGGL(k_final, dim3(lvl == 0 ? (unsigned)P.tiles_x * (unsigned)((rows + 7) / 8) : pblocks), dim3(256), 0, st, P);
                 if ((rc = next_event(*s, st, 4))) return rc;
             }
             P.rays = nullptr; P.count_ptr = nullptr; P.next_rays = nullptr; P.hit_id = hit0; P.out_off = off0;
