@@ -45,12 +45,12 @@ PEAK_MFMA_F16_TFLOPS = 2500.0                   # MI355X_MICROARCH.md: peak BF16
 MFMA_FLOPS = 2 * 32 * 32 * 16                   # one v_mfma_f32_32x32x16_f16
 # HBM bytes of one launch on the default N = 1 workload, from the PMC passes committed under profiles/
 # (r01_cull_pmc_rd / _wr, separate passes), KiB per dispatch: k_primary_mfma FETCH_SIZE 9 265, WRITE_SIZE 34 145 (the
-# hit-ID buffer alone is 4 B x 8 294 400 px = 32 400); k_shadow_mfma FETCH_SIZE 251 990, WRITE_SIZE 24 050 (the hit
+# hit-ID buffer alone is 4 B x 8 294 400 px = 32 400); k_shadow_mfma FETCH_SIZE 253 938, WRITE_SIZE 24 051 (the hit
 # records of 5.6 M shadow rays at 48 B are 263 000).  MI355X_MICROARCH.md: on gfx950 FETCH_SIZE tallies 16-B-per-lane
 # reads at half their bytes; the kernels' reads (hit records, block cones, leaf rows, FP32 records) are mostly of that
 # kind, so the read figure is doubled (an upper bound); WRITE_SIZE is taken as reported.
 # The counters cannot be read from inside this process; for any other workload traffic is null.
-TRAFFIC_BYTES_DEFAULT = {"k_primary_mfma": (2 * 9265 + 34145) * 1024, "k_shadow_mfma": (2 * 251990 + 24050) * 1024}
+TRAFFIC_BYTES_DEFAULT = {"k_primary_mfma": (2 * 9265 + 34145) * 1024, "k_shadow_mfma": (2 * 253938 + 24051) * 1024}
 
 
 def balanced_bands(scene, w, h, n, depth):
