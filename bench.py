@@ -6,21 +6,26 @@
 A "step" renders one frame of the synthetic scene of SURVEY.md §8(d) (10 000 triangles + 1 000
 cuboids = 16 000 leaves, 4 point lights with shadow rays, every ray x leaf pair decided, no hierarchy):
   N = 1 : 3840 x 2160 on one GPU                                   (BASELINE.json configs[2])
-  N > 1 : 16384 x 16384 split into N contiguous row bands, one per rank, cost-balanced from a
-          1/16-scale pre-render; the bands are sent to rank 0 over RCCL (xGMI) inside the timed
-          region                                                   (BASELINE.json configs[3])
-The scene and its FP32 filter records are resident in HBM before the timed region; the frame
-buffer stays in HBM.  value = primary rays of the whole frame / max-over-ranks wall time.
+  N > 1 : 16384 x 16384 split into N contiguous row bands of equal MEASURED cost, one per rank; the
+          bands are sent to rank 0 over RCCL (xGMI) inside the timed region   (BASELINE.json configs[3])
+The scene and its filter records are resident in HBM before the timed region (`scene_prepare_ms` says what that
+cost); the frame buffer stays in HBM.  value = primary rays of the whole frame / max-over-ranks wall time.
+
+Because N = 1 and N > 1 render different frames, a scaling curve must not be read off `value` alone: the N = 1 line
+carries `same_frame_as_multi_gpu` (the 16384 x 16384 frame on this one GPU, same code path) and every N > 1 line carries
+`n1_same_frame_ms`, measured in the same process on rank 0, and `speedup_vs_n1_same_frame`.
 
 Also on the JSON line:
-  roofline      — the dominant kernel (the longer of k_primary_mfma: every primary ray against every
-                  leaf, and k_shadow_mfma: every shadow ray against every leaf; the other one is listed
-                  under "other_kernel") in ALGORITHMIC flops (52 / 44 flops per ray x triangle /
-                  rectangle test + 1 for the nearest select, SURVEY.md §8 d) over its launch time (HIP
-                  events on the render stream).  The first stage of these kernels runs on the matrix
-                  cores, so the bound is "mfma" and peak is the dense FP16 MFMA peak; the same rate
-                  against the FP32 vector peak of BASELINE.json's metric, and the EXECUTED matrix-core
-                  rate (one v_mfma_f32_32x32x16_f16 = 32768 flops per 32 rays x 32 leaves), beside it.
+  roofline      — the dominant kernel (the longer of k_primary_mfma / k_shadow_mfma) as a UTILISATION (<= 1): the larger
+                  of its vector-issue fraction (SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x kernel cycles)) and its
+                  matrix-pipe fraction (MFMAs x 32768 flop / time / 2.5 PFLOP/s).  Instruction counts per launch, the
+                  clock and the HBM traffic are PMC readings: they come from profiles/r02_pmc.json (written by
+                  tools/profile_round.sh from separate rocprofv3 --pmc passes of this very command) and are combined
+                  with the launch time measured live (HIP events on the render stream).  The MFMA count is also
+                  counted live by the kernels.  The ALGORITHMIC rate (52/44 flops per ray x triangle/rectangle test,
+                  SURVEY.md §8 d) is reported beside it as `algorithmic_tflops` / `speedup_vs_all_pairs`.
+  rt_render     — the same frame through rt_render (host buffers, the call a Haskell caller makes, SURVEY.md §8 d):
+                  into page-locked and into pageable memory, PCIe included.  Never `value`.
   cpu_baseline  — the CPU oracle (a C restatement of the reference, NOT the Haskell program) on the
                   host cores, on a bounded band of the same frame (rank 0, N = 1 only).
 """
@@ -42,28 +47,11 @@ from raytrace_amd.distributed import gather_bands, split_rows, sub_bands  # noqa
 FLOPS_TRI, FLOPS_RECT = 52 + 1, 44 + 1
 PEAK_FP32_TFLOPS = 157.3                        # MI355X_MICROARCH.md: peak FP32 (vector), packed FMA
 PEAK_MFMA_F16_TFLOPS = 2500.0                   # MI355X_MICROARCH.md: peak BF16/FP16 MFMA, dense
+PEAK_CLOCK_GHZ = 2.4
+SIMDS = 256 * 4                                 # 256 CUs x 4 SIMDs; one wave64 VALU instruction holds a SIMD's issue port 4 cycles
 MFMA_FLOPS = 2 * 32 * 32 * 16                   # one v_mfma_f32_32x32x16_f16
-# HBM bytes of one launch on the default N = 1 workload, from the PMC passes committed under profiles/
-# (r01_cull_pmc_rd / _wr, separate passes), KiB per dispatch: k_primary_mfma FETCH_SIZE 9 265, WRITE_SIZE 34 145 (the
-# hit-ID buffer alone is 4 B x 8 294 400 px = 32 400); k_shadow_mfma FETCH_SIZE 253 938, WRITE_SIZE 24 051 (the hit
-# records of 5.6 M shadow rays at 48 B are 263 000).  MI355X_MICROARCH.md: on gfx950 FETCH_SIZE tallies 16-B-per-lane
-# reads at half their bytes; the kernels' reads (hit records, block cones, leaf rows, FP32 records) are mostly of that
-# kind, so the read figure is doubled (an upper bound); WRITE_SIZE is taken as reported.
-# The counters cannot be read from inside this process; for any other workload traffic is null.
-TRAFFIC_BYTES_DEFAULT = {"k_primary_mfma": (2 * 9265 + 34145) * 1024, "k_shadow_mfma": (2 * 253938 + 24051) * 1024}
-
-
-def balanced_bands(scene, w, h, n, depth):
-    """Contiguous row bands of about equal cost, from a 1/16-scale render (rows of a miss-only
-    region cost the primary loop only; hit rows add up to 4 shadow loops)."""
-    if n == 1:
-        return [(0, h)]
-    sw, sh = max(64, w // 16), max(64, h // 16)
-    _, hit = scene.render(sw, sh, depth=depth, want_rgba=True)
-    st = scene.stats()
-    shadow_per_hit = st["shadow_rays"] / max(1, int((hit >= 0).sum()))
-    cost = 1.0 + (hit >= 0).mean(axis=1) * shadow_per_hit          # per low-res row, in units of one primary loop
-    return split_rows(cost, h, n)
+PMC_JSON = os.path.join(ROOT, "profiles", "r02_pmc.json")
+MULTI_W = MULTI_H = 16384                       # configs[3]
 
 
 def cpu_baseline(world, lights, w, h, depth, seconds=18.0):
@@ -88,6 +76,43 @@ def cpu_baseline(world, lights, w, h, depth, seconds=18.0):
                       f"{dt:.1f} s; C restatement of the reference (oracle/), not the Haskell program"}
 
 
+def load_pmc(workload_key):
+    """PMC readings per launch of the two big kernels for the default workload (profiles/r02_pmc.json)."""
+    try:
+        with open(PMC_JSON) as f:
+            pmc = json.load(f)
+    except (OSError, ValueError):
+        return None
+    return pmc if pmc.get("workload_key") == workload_key else None
+
+
+def utilisation(kernel, ms, mfmas_live, pmc):
+    """Roofline of one launch as a utilisation: vector-issue fraction and matrix-pipe fraction (both <= 1)."""
+    k = (pmc or {}).get("kernels", {}).get(kernel, {})
+    clock = k.get("clock_ghz") or PEAK_CLOCK_GHZ
+    cycles = ms * 1e-3 * clock * 1e9
+    out = {"kernel": kernel, "launch_ms": ms, "clock_ghz": clock,
+           "clock_source": "GRBM_GUI_ACTIVE / 8 / duration of the profiled launch" if k.get("clock_ghz") else "peak clock (no PMC file for this workload)"}
+    mfmas = k.get("SQ_INSTS_MFMA") or mfmas_live
+    out["mfma_per_launch"] = mfmas
+    out["mfma_tflops"] = mfmas * MFMA_FLOPS / (ms * 1e-3) / 1e12
+    out["mfma_frac"] = out["mfma_tflops"] / PEAK_MFMA_F16_TFLOPS
+    if k.get("SQ_INSTS_VALU"):
+        out["valu_insts_per_launch"] = k["SQ_INSTS_VALU"]
+        out["valu_issue_frac"] = k["SQ_INSTS_VALU"] * 4 / (SIMDS * cycles)
+    else:
+        out["valu_insts_per_launch"] = None
+        out["valu_issue_frac"] = None
+    if k.get("FETCH_SIZE_KiB") is not None and k.get("WRITE_SIZE_KiB") is not None:
+        # MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE tallies wide (16 B per lane) reads at half their bytes -> x 2
+        # (an upper bound here: the kernels' reads are 16-byte job / record / leaf-row loads and 8-byte FP64 loads);
+        # WRITE_SIZE as reported.  Separate --pmc passes.
+        out["traffic"] = int((2 * k["FETCH_SIZE_KiB"] + k["WRITE_SIZE_KiB"]) * 1024)
+    else:
+        out["traffic"] = None
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -98,18 +123,19 @@ def main():
     ap.add_argument("--ntri", type=int, default=10000)
     ap.add_argument("--ncuboid", type=int, default=1000)
     ap.add_argument("--depth", type=int, default=4)
-    ap.add_argument("--workload", default="synthetic", choices=["synthetic", "cylinders", "default"],
+    ap.add_argument("--workload", default="synthetic", choices=["synthetic", "cylinders", "default", "mirror"],
                     help="synthetic = configs[2]/[3] (the metric's workload); cylinders = configs[4] (specular cylinders + cuboids, "
-                         "use with --spp 16 --width 7680 --height 4320); default = the Main.hs scene (configs[0]/[1])")
+                         "use with --spp 16 --width 7680 --height 4320); default = the Main.hs scene (configs[0]/[1]); "
+                         "mirror = the `spheres` scene of Main.hs:670-690 (mirror materials: reflected rays, trace depth 4)")
     ap.add_argument("--spp", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--filter", default="mfma", choices=["mfma", "valu"],
-                    help="first stage: bounding cones on the matrix cores (default) or the FP32 vector-ALU kernels")
-    ap.add_argument("--no-brute-force-leg", action="store_true", help="skip the extra frames rendered with the block test off (profiling runs)")
-    ap.add_argument("--no-cull", action="store_true", help="every wave scans every block of the leaf stream (RT_CULL=0): the plain brute-force scan")
+                    help="first stage: bounding cones on the matrix cores (the product) or the FP32 vector-ALU kernels of the cross-check build")
+    ap.add_argument("--no-extra-legs", action="store_true", help="profiling runs: only the timed steps (no brute-force, rt_render or 16K legs)")
+    ap.add_argument("--no-cull", action="store_true", help="every wave scans every block of the leaf stream: the plain all-pairs scan")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the measured path) or gloo (rehearsal on one GPU)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank renders on GPU 0 (gloo only)")
-    ap.add_argument("--pieces", type=int, default=4, help="N > 1: pieces per band; piece k's gather overlaps piece k+1's render")
+    ap.add_argument("--pieces", type=int, default=0, help="N > 1: pieces per band (0 = from the band's render time, about 1 ms each, at most 4)")
     ap.add_argument("--verify", action="store_true", help="rank 0 re-renders the whole frame alone and compares it with the gathered one")
     args = ap.parse_args()
 
@@ -135,12 +161,11 @@ def main():
         else:
             dist.init_process_group("gloo")
     staged = n > 1 and args.dist_backend != "nccl"               # gloo rehearsal: bands travel through host memory
-    os.environ["RT_FILTER"] = args.filter
-    os.environ["RT_CULL"] = "0" if args.no_cull else "1"
-    _lib.check(_lib.lib().rt_init(local_rank), "rt_init")
+    L = _lib.valu_lib() if args.filter == "valu" else _lib.lib()
+    _lib.check(L.rt_init(local_rank), "rt_init", L)
 
-    w = args.width or (3840 if n == 1 else 16384)
-    h = args.height or (2160 if n == 1 else 16384)
+    w = args.width or (3840 if n == 1 else MULTI_W)
+    h = args.height or (2160 if n == 1 else MULTI_H)
     if args.workload == "synthetic":
         world, lights = scenes.synthetic(ntri=args.ntri, ncuboid=args.ncuboid)
         ntri, nrect, nlt = args.ntri, 6 * args.ncuboid, 4
@@ -149,52 +174,105 @@ def main():
         world, lights = scenes.synthetic_cylinders()
         ntri, nrect, nlt = 200 * 32, 200 * 16 + 500 * 6, 4
         wname = "200 upright cylinders (n=16) + 500 cuboids, specularity 100/400"
+    elif args.workload == "mirror":
+        world, lights = scenes.mirror_bench()
+        ntri, nrect, nlt = None, None, 2
+        wname = "mirror scene (Main.hs:670-690 `spheres` + 2 000 triangles, reflectivity 0.9 floor strip and sphere)"
     else:
         world, lights = scenes.default_scene()
         ntri, nrect, nlt = 200, 1, 1
         wname = "Main.hs default scene (gaussian height field, linearInterpolation)"
-    scene = api.Scene(world, lights)
-    assert scene.num_leaves == ntri + nrect
+    scene = api.Scene(world, lights, lib=L)
+    if args.filter == "valu":
+        scene.set_option(_lib.RT_OPT_FILTER, 1)
+    if args.no_cull:
+        scene.set_option(_lib.RT_OPT_CULL, 0)
+    if ntri is None:
+        kinds = [scene.leaf(i)[0] for i in range(scene.num_leaves)]
+        ntri, nrect = kinds.count(1.0), kinds.count(0.0)
+    nleaves = scene.num_leaves
+    t0 = time.perf_counter()
+    scene.prepare(w, h)                                           # host index build + upload, outside the timed region
+    prepare_wall_ms = (time.perf_counter() - t0) * 1e3
 
-    bands = balanced_bands(scene, w, h, n, args.depth)
+    # ---- bands: rank 0 measures the cost of 32 strips of the frame (HIP events, reduced scale) and everybody cuts the
+    # same bands from it
+    n1_same_frame_ms = None
+    if n == 1:
+        bands = [(0, h)]
+    else:
+        info = torch.zeros(33, dtype=torch.float64)
+        if rank == 0:
+            info[:32] = torch.tensor(scene.row_costs(w, h, 32, depth=args.depth, spp=args.spp), dtype=torch.float64)
+            # the same frame on this GPU alone, same code path: the honest N = 1 point of the scaling curve
+            full = torch.empty((h, w, 4), dtype=torch.uint8, device=dev)
+            fhit = torch.empty((h, w), dtype=torch.int32, device=dev)
+            for k in range(3):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                scene.render_device(w, h, full.data_ptr(), fhit.data_ptr(), depth=args.depth, spp=args.spp, seed=20260355)
+                _lib.check(L.rt_synchronize(), "rt_synchronize", L)
+                info[32] = (time.perf_counter() - t0) * 1e3
+            del full, fhit
+            torch.cuda.empty_cache()
+        if staged:
+            dist.broadcast(info, 0)
+        else:
+            info = info.to(dev)
+            dist.broadcast(info, 0)
+            info = info.cpu()
+        bands = split_rows(info[:32].numpy(), h, n)
+        n1_same_frame_ms = float(info[32])
     row0, nrows = bands[rank]
     # frame buffer: rank 0 owns the whole image (bands of the other ranks land in it), others own a band
     frame = torch.empty((h if rank == 0 else nrows, w, 4), dtype=torch.uint8, device=dev)
     mine = frame[row0:row0 + nrows] if rank == 0 else frame
     hit = torch.empty((nrows, w), dtype=torch.int32, device=dev)
-    stream = torch.cuda.current_stream().cuda_stream
+    # The renders go to a torch stream that is ALSO torch's current stream while the gather is enqueued: RCCL orders its
+    # own stream behind the current stream, so piece k's send waits for piece k's render and for nothing later.  (With the
+    # library's private stream, or the legacy default stream, the send would not be ordered behind the render at all.)
+    rs = torch.cuda.Stream(dev)
 
     # every band is rendered in `pieces` consecutive pieces; piece k of all peers travels to GPU 0 in one group
-    # of send/recv while piece k+1 renders (the library returns once the piece is enqueued on `stream`; RCCL's
-    # own stream waits for that piece only), so only the last piece's exchange is exposed
-    pieces = max(1, args.pieces) if n > 1 else 1
+    # of send/recv while piece k+1 renders, so only the last piece's exchange is exposed.  A piece should take about
+    # a millisecond: 6 kernel launches and their tails are then a few per cent of it.
+    if n > 1:
+        pieces = args.pieces if args.pieces > 0 else max(1, min(4, int(n1_same_frame_ms / n / 1.0)))
+    else:
+        pieces = 1
     subs = [sub_bands(b, pieces) for b in bands]
+    marks = {}
 
-    def step():
+    def step(seed=20260355):
         pending, host = [], []
         host_frame = torch.empty((h, w, 4), dtype=torch.uint8) if staged and rank == 0 else None
-        for k in range(pieces):
-            r0, nr = subs[rank][k]
-            piece = mine[r0 - row0:r0 - row0 + nr]
-            if nr > 0:
-                scene.render_device(w, h, piece.data_ptr(), hit[r0 - row0:].data_ptr(), depth=args.depth, spp=args.spp,
-                                    seed=20260355, row0=r0, nrows=nr, stream=stream)
-            if n == 1:
-                continue
-            group = [s[k] for s in subs]
-            if not staged:     # ncclSend/ncclRecv in one group: every peer has a direct xGMI link to GPU 0
-                pending += gather_bands(dist, frame, piece, group, rank, wait=False)
-            else:              # gloo rehearsal: the same groups, through host memory
-                torch.cuda.synchronize()
-                host_piece = piece.cpu()
-                host.append((r0, nr, host_piece))
-                pending += gather_bands(dist, host_frame, host_piece, group, rank, wait=False)
-        for req in pending:
-            req.wait()
-        if staged and rank == 0:
-            for r0, nr, host_piece in host:
-                host_frame[r0:r0 + nr] = host_piece
-            frame.copy_(host_frame)
+        with torch.cuda.stream(rs):
+            marks["start"] = rs.record_event(torch.cuda.Event(enable_timing=True))
+            for k in range(pieces):
+                r0, nr = subs[rank][k]
+                piece = mine[r0 - row0:r0 - row0 + nr]
+                if nr > 0:
+                    scene.render_device(w, h, piece.data_ptr(), hit[r0 - row0:].data_ptr(), depth=args.depth, spp=args.spp,
+                                        seed=seed, row0=r0, nrows=nr, stream=rs.cuda_stream)
+                if k == pieces - 1:
+                    marks["rendered"] = rs.record_event(torch.cuda.Event(enable_timing=True))
+                if n == 1:
+                    continue
+                group = [s[k] for s in subs]
+                if not staged:     # ncclSend/ncclRecv in one group: every peer has a direct xGMI link to GPU 0
+                    pending += gather_bands(dist, frame, piece, group, rank, wait=False)
+                else:              # gloo rehearsal: the same groups, through host memory
+                    rs.synchronize()
+                    host_piece = piece.cpu()
+                    host.append((r0, nr, host_piece))
+                    pending += gather_bands(dist, host_frame, host_piece, group, rank, wait=False)
+            for req in pending:
+                req.wait()
+            if staged and rank == 0:
+                for r0, nr, host_piece in host:
+                    host_frame[r0:r0 + nr] = host_piece
+                frame.copy_(host_frame)
+            marks["end"] = rs.record_event(torch.cuda.Event(enable_timing=True))
 
     def sync():
         torch.cuda.synchronize()
@@ -214,6 +292,9 @@ def main():
             shade_ms.append(stats["ms_shadow"]); prim_ms.append(stats["ms_primary"])
     sync()
     dt = time.perf_counter() - t0
+    # the last step of this rank: render of its band, and what followed until the frame was complete (exposed exchange)
+    rank_render_ms = marks["start"].elapsed_time(marks["rendered"])
+    rank_total_ms = marks["start"].elapsed_time(marks["end"])
     if n > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         if staged:
@@ -223,29 +304,40 @@ def main():
     stats = scene.stats()
     if n > 1:            # untimed pass: ray counts and per-kernel times of this rank's band, summed over its pieces
         keys = ("primary_rays", "shadow_rays", "exact_evals", "ms_shadow", "ms_primary", "ms_setup", "ms_final",
-                "mfma_blocks_primary", "mfma_blocks_shadow")
+                "mfma_blocks_primary", "mfma_blocks_shadow", "record_tests")
         total = dict.fromkeys(keys, 0.0)
         for r0, nr in subs[rank]:
             if nr > 0:
                 scene.render_device(w, h, mine[r0 - row0:].data_ptr(), hit[r0 - row0:].data_ptr(), depth=args.depth, spp=args.spp,
-                                    seed=20260355, row0=r0, nrows=nr, stream=stream)
+                                    seed=20260355, row0=r0, nrows=nr, stream=rs.cuda_stream)
                 st = scene.stats()
                 for key in keys:
                     total[key] += st[key]
-        stats = total
+        stats.update(total)
     counts = torch.tensor([stats["primary_rays"], stats["shadow_rays"], stats["exact_evals"]], dtype=torch.float64, device=dev)
     shade_t = torch.tensor([stats["ms_shadow"], stats["ms_primary"]], dtype=torch.float64, device=dev)
+    per_rank = torch.zeros((n, 2), dtype=torch.float64, device=dev)
+    per_rank[rank, 0], per_rank[rank, 1] = rank_render_ms, rank_total_ms
     if n > 1:
         if staged:
-            counts, shade_t = counts.cpu(), shade_t.cpu()
+            counts, shade_t, per_rank = counts.cpu(), shade_t.cpu(), per_rank.cpu()
         dist.all_reduce(counts)
         dist.all_reduce(shade_t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(per_rank)
     verified = None
-    if args.verify and rank == 0:
-        alone = torch.empty((h, w, 4), dtype=torch.uint8, device=dev)
-        scene.render_device(w, h, alone.data_ptr(), None, depth=args.depth, spp=args.spp, seed=20260355, stream=stream)
-        torch.cuda.synchronize()
-        verified = bool(torch.equal(alone, frame))
+    if args.verify:
+        # a frame nobody has seen yet (another seed has no effect at spp 1, so the buffers are poisoned instead): stale
+        # or unordered data in the gathered frame cannot pass
+        frame.fill_(0x5a)
+        sync()
+        step()
+        sync()
+        if rank == 0:
+            alone = torch.empty((h, w, 4), dtype=torch.uint8, device=dev)
+            scene.render_device(w, h, alone.data_ptr(), None, depth=args.depth, spp=args.spp, seed=20260355, stream=rs.cuda_stream)
+            torch.cuda.synchronize()
+            verified = bool(torch.equal(alone, frame))
+            del alone
     if rank == 0:
         primary, shadow, exact = (float(c) for c in counts.tolist())
         assert primary == float(w) * h * args.spp, (primary, w, h, args.spp)   # every pixel of the frame was traced once per sample
@@ -253,77 +345,140 @@ def main():
         per_test = ntri * FLOPS_TRI + nrect * FLOPS_RECT
         ms_shade = float(np.mean(shade_ms)) if shade_ms else float(shade_t[0])
         ms_prim = float(np.mean(prim_ms)) if prim_ms else float(shade_t[1])
-        # per-launch algorithmic flops of the dominant kernel (k_primary*: one test per primary ray x leaf)
-        prim_flops = primary / n * per_test
-        achieved = prim_flops / (ms_prim * 1e-3) / 1e12
         mfma = args.filter == "mfma"
-        # executed matrix-core work of that launch: 8 MFMAs (one per 32 rays of the wave's 256) per block of 32 leaves
-        # the wave scanned (the library counts them); the brute-force scan would visit every block for every wave
+        default_workload = (n == 1 and args.spp == 1 and not args.no_cull and mfma and args.workload == "synthetic"
+                            and (w, h, ntri, nrect, args.depth) == (3840, 2160, 10000, 6000, 4))
+        pmc = load_pmc("synthetic-10000-1000-3840x2160-d4-spp1") if default_workload else None
         tiles = -(-w // 32) * -(-nrows // 8)
         blocks = -(-(ntri + nrect) // 32)
-        peak = PEAK_MFMA_F16_TFLOPS if mfma else PEAK_FP32_TFLOPS
 
         def kernel_line(name, rays, ms, scanned, waves):
-            return {"kernel": name + ("_mfma" if mfma else ""), "ms": ms,
-                    "achieved": rays / n * per_test / (max(ms, 1e-9) * 1e-3) / 1e12,
-                    "executed": float(scanned) * 8 * MFMA_FLOPS / (max(ms, 1e-9) * 1e-3) / 1e12,
-                    "scanned_frac": float(scanned) / max(1.0, float(waves * blocks)) if n == 1 else None}
+            u = utilisation(name + ("_mfma" if mfma else ""), ms, float(scanned) * 8, pmc) if n == 1 else {"kernel": name, "launch_ms": ms}
+            u["algorithmic_tflops"] = rays / n * per_test / (max(ms, 1e-9) * 1e-3) / 1e12
+            u["leaf_blocks_scanned_frac"] = float(scanned) / max(1.0, float(waves * blocks)) if (n == 1 and mfma) else None
+            return u
         kp = kernel_line("k_primary", primary, ms_prim, stats["mfma_blocks_primary"], tiles * args.spp)
         ks = kernel_line("k_shadow", shadow, ms_shade, stats["mfma_blocks_shadow"], shadow / 256.0)
         dom, oth = (kp, ks) if ms_prim >= ms_shade else (ks, kp)
+        roof = {"kernel": dom["kernel"], "launch_ms": dom["launch_ms"]}
+        if n == 1 and mfma:
+            vf, mf = dom.get("valu_issue_frac"), dom["mfma_frac"]
+            if vf is not None and vf >= mf:
+                clock = dom["clock_ghz"]
+                roof.update({"bound": "valu_issue", "achieved": dom["valu_insts_per_launch"] / (dom["launch_ms"] * 1e-3) / 1e9,
+                             "peak": SIMDS * clock / 4, "unit": "G wave-instructions/s", "frac": vf})
+            else:
+                roof.update({"bound": "mfma", "achieved": dom["mfma_tflops"], "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s", "frac": mf})
+            roof.update({
+                "traffic": dom["traffic"],
+                "traffic_unit": "HBM bytes per launch: (2 x FETCH_SIZE + WRITE_SIZE) KiB x 1024 from separate rocprofv3 --pmc passes "
+                                "(profiles/r02_pmc.json; x 2 = the gfx950 correction for wide reads, MI355X_MICROARCH.md), "
+                                "null when no PMC file matches this workload",
+                "valu_issue_frac": vf, "mfma_frac": mf, "mfma_tflops": dom["mfma_tflops"], "clock_ghz": dom["clock_ghz"],
+                "clock_source": dom["clock_source"],
+                "pmc_source": (pmc or {}).get("source"), "pmc_command": (pmc or {}).get("command"),
+                "algorithmic_tflops": dom["algorithmic_tflops"],
+                "speedup_vs_all_pairs": dom["algorithmic_tflops"] / PEAK_FP32_TFLOPS,
+                "leaf_blocks_scanned_frac": dom["leaf_blocks_scanned_frac"],
+                "other_kernel": {k: oth.get(k) for k in ("kernel", "launch_ms", "valu_issue_frac", "mfma_frac", "mfma_tflops", "traffic",
+                                                         "algorithmic_tflops", "leaf_blocks_scanned_frac")},
+                "note": "frac = the larger of the kernel's vector-issue fraction (SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x kernel cycles)) "
+                        "and matrix-pipe fraction (MFMAs x 32768 flop / launch time / 2.5 PFLOP/s dense FP16): how busy the issue ports "
+                        "are, not how much of the reference's arithmetic was avoided.  algorithmic_tflops = 53/45 flops per ray x "
+                        "triangle/rectangle pair (SURVEY.md 8d) x the pairs the launch decides / launch time; speedup_vs_all_pairs = that "
+                        "over the 157.3 TFLOP/s FP32 vector peak a literal all-pairs kernel could not exceed."})
+        elif n == 1:
+            roof.update({"bound": "valu_fp32", "achieved": dom["algorithmic_tflops"], "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                         "frac": None, "traffic": None,
+                         "note": "cross-check build (FP32 vector-ALU kernels): algorithmic rate only; the executed rate is in profiles/README.md"})
+        else:
+            roof.update({"bound": "valu_issue", "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
+                         "note": "per-kernel utilisation is reported by the N = 1 line; here launch_ms is the slowest rank's sum over its pieces"})
         out = {
             "metric": "primary Mrays/s (whole node)", "value": primary / (dt / args.steps) / 1e6, "unit": "Mrays/s",
             "n_gpus": n, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
-            "higher_is_better": True, "scaling": "strong" if n > 1 else "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{wname} ({ntri + nrect} leaves), {nlt} point light(s) + ambient, "
+            "config": {"workload": f"{wname} ({nleaves} leaves), {nlt} point light(s) + ambient, "
                                    f"{w}x{h}, depth {args.depth}, spp {args.spp}, every ray x leaf pair decided (no hierarchy)"
-                                   + (f", {n} cost-balanced row bands gathered to GPU 0 over " + ("RCCL" if not staged else "gloo via host memory (rehearsal)") if n > 1 else ""),
+                                   + (f", {n} row bands of equal measured cost gathered to GPU 0 over " + ("RCCL" if not staged else "gloo via host memory (rehearsal)") if n > 1 else ""),
                        "arithmetic": "hits and colours decided in f64 (the reference's Double); conservative filters in front: "
                                      + (("blocks of 32 leaves against the bound of a wave's 256 ray directions, " if not args.no_cull else "")
-                                        + "f16 bounding cones on the matrix cores, then f32 records" if args.filter == "mfma" else "f32 records on the vector ALU"),
-                       "width": w, "height": h, "leaves": ntri + nrect, "lights": nlt, "spp": args.spp,
-                       "bands": bands if n > 1 else None, "pieces_per_band": pieces if n > 1 else None, "gathered_frame_equals_single_render": verified,
+                                        + "f16 bounding cones on the matrix cores, then f32 records" if mfma else "f32 records on the vector ALU"),
+                       "width": w, "height": h, "leaves": nleaves, "lights": nlt, "spp": args.spp,
                        "shadow_rays_per_frame": shadow, "exact_fp64_evals_per_frame": exact,
-                       "whole_frame_algorithmic_tflops": (primary + shadow) * per_test / (dt / args.steps) / 1e12,
+                       "record_tests_per_frame": stats.get("record_tests"), "bounce_rays_per_frame": stats.get("bounce_rays"),
                        "kernel_ms": {"k_primary": ms_prim, "k_setup": stats["ms_setup"], "k_shadow": ms_shade, "k_final": stats["ms_final"]}},
-            "roofline": {"bound": "mfma" if mfma else "valu_fp32", "kernel": dom["kernel"],
-                         "achieved": dom["achieved"], "peak": peak, "unit": "TFLOP/s", "frac": dom["achieved"] / peak,
-                         "traffic": TRAFFIC_BYTES_DEFAULT.get(dom["kernel"]) if (n == 1 and args.spp == 1 and not args.no_cull and args.workload == "synthetic" and (w, h, ntri, nrect) == (3840, 2160, 10000, 6000)) else None,
-                         "traffic_unit": "bytes per launch (rocprofv3 --pmc: 2 x FETCH_SIZE (gfx950 correction for 16-B-per-lane reads) + WRITE_SIZE, profiles/r01_cull_pmc_*)",
-                         "launch_ms": dom["ms"],
-                         "frac_of_fp32_valu_peak": dom["achieved"] / PEAK_FP32_TFLOPS,
-                         "executed_mfma_tflops": dom["executed"] if mfma else None,
-                         "executed_mfma_frac": dom["executed"] / PEAK_MFMA_F16_TFLOPS if mfma else None,
-                         "leaf_blocks_scanned_frac": dom["scanned_frac"] if mfma else None,
-                         "other_kernel": {"kernel": oth["kernel"], "launch_ms": oth["ms"], "achieved": oth["achieved"], "frac": oth["achieved"] / peak,
-                                          "executed_mfma_tflops": oth["executed"] if mfma else None,
-                                          "leaf_blocks_scanned_frac": oth["scanned_frac"] if mfma else None},
-                         "note": "achieved = algorithmic flops (53/45 per ray x triangle/rectangle test, SURVEY.md 8d) x rays x leaves "
-                                 "of one launch (primary rays for k_primary_mfma, the shadow rays cast for k_shadow_mfma) / its HIP-event time. The kernel decides every pair but executes far fewer flops: a wave "
-                                 "skips the blocks of 32 leaves whose bounding cone misses the bound of its 256 rays "
-                                 "(leaf_blocks_scanned_frac of the blocks are scanned), a scanned pair costs one FP16 MFMA form, and only "
-                                 "candidates reach FP32/FP64 -- so frac and frac_of_fp32_valu_peak exceed 1 and say how much cheaper than "
-                                 "the reference formulation the decision is, not how busy the matrix pipe is; executed_mfma_* is the "
-                                 "matrix-core work actually issued against the dense FP16 peak, and brute_force_scan is the same frame "
-                                 "with the block test off (every wave scans every block)"},
+            "roofline": roof,
+            "scene_prepare_ms": {"host_index_build": stats["prepare_ms"], "upload": stats["upload_ms"], "wall_of_rt_scene_prepare_device": prepare_wall_ms,
+                                 "note": "guard chains, bounding cones, direction sort and filter records for 5 apexes, then the upload: once per scene, outside the timed region"},
         }
-        if n == 1 and mfma and not args.no_cull and not args.no_brute_force_leg:
-            # the same frame with the block test off (every wave scans every block), timed the same way
-            os.environ["RT_CULL"] = "0"
-            _lib.check(_lib.lib().rt_init(local_rank), "rt_init")
-            step(); sync()
-            t0 = time.perf_counter()
-            for _ in range(2):
-                step()
-            sync()
-            bf = (time.perf_counter() - t0) / 2
-            bst = scene.stats()
-            out["brute_force_scan"] = {"value": primary / bf / 1e6, "unit": "Mrays/s", "ms_per_step": bf * 1e3,
-                                       "k_primary_ms": bst["ms_primary"], "k_shadow_ms": bst["ms_shadow"],
-                                       "executed_mfma_tflops": float(bst["mfma_blocks_primary"]) * 8 * MFMA_FLOPS / (bst["ms_primary"] * 1e-3) / 1e12}
-            os.environ["RT_CULL"] = "1"
-            _lib.check(_lib.lib().rt_init(local_rank), "rt_init")
+        if n > 1:
+            out["distributed"] = {
+                "backend": "RCCL (torch.distributed nccl)" if not staged else "gloo (rehearsal, bands staged through host memory)",
+                "world_size": dist.get_world_size(), "bands": bands, "pieces_per_band": pieces,
+                "rank_render_ms": [float(v) for v in per_rank[:, 0].tolist()],
+                "rank_step_ms": [float(v) for v in per_rank[:, 1].tolist()],
+                "exposed_gather_ms": float(per_rank[0, 1] - per_rank[:, 0].max()),
+                "n1_same_frame_ms": n1_same_frame_ms,
+                "speedup_vs_n1_same_frame": n1_same_frame_ms / ms_step,
+                "gathered_frame_equals_single_render": verified,
+                "note": "rank_render_ms / rank_step_ms: last timed step, events on each rank's render stream; exposed_gather_ms = rank 0's "
+                        "step minus the slowest rank's render; n1_same_frame_ms = this very frame rendered by rank 0 alone (same process, "
+                        "same code path) before the timed region"}
+        elif verified is not None:
+            out["config"]["frame_equals_second_render"] = verified
+        if n == 1 and mfma and not args.no_extra_legs:
+            if not args.no_cull:
+                # the same frame with the block test off (every wave scans every block), timed the same way
+                scene.set_option(_lib.RT_OPT_CULL, 0)
+                step(); sync()
+                t0 = time.perf_counter()
+                for _ in range(2):
+                    step()
+                sync()
+                bf = (time.perf_counter() - t0) / 2
+                bst = scene.stats()
+                out["brute_force_scan"] = {"value": primary / bf / 1e6, "unit": "Mrays/s", "ms_per_step": bf * 1e3,
+                                           "k_primary_ms": bst["ms_primary"], "k_shadow_ms": bst["ms_shadow"],
+                                           "mfma_tflops": float(bst["mfma_blocks_primary"]) * 8 * MFMA_FLOPS / (bst["ms_primary"] * 1e-3) / 1e12,
+                                           "mfma_frac": float(bst["mfma_blocks_primary"]) * 8 * MFMA_FLOPS / (bst["ms_primary"] * 1e-3) / 1e12 / PEAK_MFMA_F16_TFLOPS}
+                scene.set_option(_lib.RT_OPT_CULL, 1)
+            # the call SURVEY.md 8(d) defines the metric on: rt_render into HOST buffers (PCIe included)
+            legs = {}
+            dests = {"page_locked": (api.host_buffer((h, w, 4), np.uint8), api.host_buffer((h, w), np.int32)),
+                     "pageable": (np.zeros((h, w, 4), np.uint8), np.zeros((h, w), np.int32))}
+            for name, (rgba_h, hit_h) in dests.items():
+                ts = []
+                for _ in range(6):
+                    t0 = time.perf_counter()
+                    scene.render(w, h, depth=args.depth, spp=args.spp, seed=20260355, out_rgba=rgba_h, out_hit=hit_h)
+                    ts.append(time.perf_counter() - t0)
+                legs[name] = {"ms": min(ts[1:]) * 1e3, "median_ms": float(np.median(ts[1:])) * 1e3, "mrays": primary / min(ts[1:]) / 1e6}
+            same = bool((torch.from_numpy(dests["pageable"][0]).to(dev) == frame).all())
+            out["rt_render"] = {"page_locked": legs["page_locked"], "pageable": legs["pageable"], "frame_equals_device_render": same,
+                                "note": "wall time of rt_render(scene, w, h, ...) into caller-owned host buffers, RGBA8 + int32 hit IDs, best of 5 "
+                                        "after one warm-up; rendered as row bands whose copies overlap the next band's kernels"}
+            out["rt_render_mrays"] = legs["page_locked"]["mrays"]
+            del dests
+            if args.workload == "synthetic" and (w, h) != (MULTI_W, MULTI_H):
+                # configs[3]'s frame on this one GPU: the N = 1 point that the N > 1 lines of this script compare with
+                big = torch.empty((MULTI_H, MULTI_W, 4), dtype=torch.uint8, device=dev)
+                bhit = torch.empty((MULTI_H, MULTI_W), dtype=torch.int32, device=dev)
+                ts = []
+                for _ in range(4):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    scene.render_device(MULTI_W, MULTI_H, big.data_ptr(), bhit.data_ptr(), depth=args.depth, spp=args.spp, seed=20260355,
+                                        stream=rs.cuda_stream)
+                    rs.synchronize()
+                    ts.append(time.perf_counter() - t0)
+                bst = scene.stats()
+                out["same_frame_as_multi_gpu"] = {"width": MULTI_W, "height": MULTI_H, "ms": min(ts[1:]) * 1e3,
+                                                  "mrays": MULTI_W * MULTI_H * args.spp / min(ts[1:]) / 1e6,
+                                                  "kernel_ms": {"k_primary": bst["ms_primary"], "k_setup": bst["ms_setup"], "k_shadow": bst["ms_shadow"], "k_final": bst["ms_final"]},
+                                                  "note": "the frame `bench.py --gpus N` (N > 1) splits across ranks, on this one GPU: divide by it, not by `value`, for a scaling ratio"}
+                del big, bhit
         if n == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(world, lights, w, h, args.depth)
         print(json.dumps(out), flush=True)

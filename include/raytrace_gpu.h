@@ -48,16 +48,24 @@ typedef struct {
 typedef enum {
     RT_NORMAL_GEOMETRIC = 0,  /* rectangle Main.hs:228 / triangle Main.hs:371                        */
     RT_NORMAL_MANTLE    = 1,  /* cylinder mantle: lerped, y forced to 0, not renormalised (:769-771) */
-    RT_NORMAL_GAUSSIAN  = 2   /* linearInterpolation's `normals` wrapper with main's gaussian fnorm
+    RT_NORMAL_GAUSSIAN  = 2,  /* linearInterpolation's `normals` wrapper with main's gaussian fnorm
                                  (Main.hs:956-965, 580-584); params = {scaleInv, offset x,y,z}      */
+    RT_NORMAL_CALLBACK  = 3   /* the same wrapper with ANY fnorm (Main.hs:956-965 takes an arbitrary
+                                 Double -> Double -> Vector3D): set with rt_set_normal_callback       */
 } rt_normal_mode;
+
+/* An `fnorm` closure of linearInterpolation (Main.hs:937, 956-965) as a C callback: for each of the n hit points,
+ * xy[2i], xy[2i+1] are the arguments x, y the reference passes to fnorm ((x, _, y) = scaleInv * (i - offset),
+ * Main.hs:958) and normals[3i..3i+2] receives fnorm x y.  Called on the host, from the thread inside rt_render. */
+typedef void (*rt_normal_fn)(int n, const double *xy, double *normals, void *user);
 
 /* Per-render statistics (filled by rt_get_stats after a render) */
 typedef struct {
     uint64_t primary_rays;       /* w * nrows * spp                                           */
     uint64_t shadow_rays;        /* shadow rays actually cast (hit pixel, L.N > 0), all lights */
-    uint64_t tri_tests;          /* ray x triangle  pairs decided (rays x triangles; most through a block's cone) */
-    uint64_t rect_tests;         /* ray x rectangle pairs decided                               */
+    uint64_t tri_pairs;          /* ray x triangle pairs the render decided = rays x triangles (an identity, not a
+                                    count: most pairs are decided 256 rays x 32 leaves at a time by a block's cone) */
+    uint64_t rect_pairs;         /* ray x rectangle pairs decided, likewise                     */
     uint64_t exact_evals;        /* FP64 exact leaf evaluations (candidates of the filter)     */
     double   ms_primary;         /* HIP-event time of k_primary (nearest hit)                  */
     double   ms_setup;           /* ... of k_setup (exact hit records + shadow-job queues)     */
@@ -67,10 +75,18 @@ typedef struct {
     uint64_t mfma_blocks_primary; /* (wave of 256 rays) x (block of 32 leaves) pairs k_primary_mfma scanned, 8 MFMAs
                                      each; the others were skipped by the block-cone test         */
     uint64_t mfma_blocks_shadow;  /* the same for k_shadow_mfma, all lights                        */
+    uint64_t record_tests;        /* FP32 record tests (second stage), counted in the kernels       */
+    uint64_t bounce_rays;         /* reflected rays traced (all levels)                             */
+    double   prepare_ms;          /* host time of the last rebuild of guard chains and filter records */
+    double   upload_ms;           /* host time of the last upload of the scene to this device       */
 } rt_stats;
 
 /* ---- library / device ------------------------------------------------------------------- */
-int  rt_init(int device);                       /* hipSetDevice + stream; call once per process/thread  */
+/* Selects the HIP device the CALLING THREAD renders on (hipSetDevice) and sets the library up on it.  Optional: the
+ * first render of a thread that never called it uses device 0.  Every (scene, device) pair has its own streams and
+ * work buffers, so distinct scenes may be rendered from different threads, on the same or on different devices; one
+ * scene must not be rendered from two threads at once. */
+int  rt_init(int device);
 const char *rt_last_error(void);
 const char *rt_version(void);
 
@@ -81,6 +97,17 @@ const char *rt_version(void);
  * rt_add_point_light), no reflection (traceAndShade, :255-258).  Rectangles only.  Call before the first shape. */
 enum { RT_DIALECT_MAIN = 0, RT_DIALECT_TALK = 1 };
 int  rt_scene_set_dialect(rt_scene *, int dialect);
+
+/* Per-scene options (no counterpart in the reference; nothing is read from the environment).
+ *   RT_OPT_CULL        1 (default): a wave skips the blocks of 32 leaves whose bounding cone misses the bound of its
+ *                      256 rays; 0: every wave scans every block (the plain all-pairs scan).  Same pixels either way.
+ *   RT_OPT_FILTER      0 (default): first stage on the matrix cores; 1: the FP32 vector-ALU kernels, which exist only
+ *                      in the cross-check build libraytrace_gpu_valu.so (RT_ERR_UNSUPPORTED in the product library).
+ *   RT_OPT_HOST_BANDS  copy bands of rt_render, 1..8 (0 = default: one per 2 Mi pixels).
+ *   RT_OPT_MULTI_STAGE 1: rt_render_multi sends the bands of devices[0] through a staging buffer and a peer copy too,
+ *                      like those of the other devices (default 0: they are rendered in place; tests use 1). */
+enum { RT_OPT_CULL = 0, RT_OPT_FILTER = 1, RT_OPT_HOST_BANDS = 2, RT_OPT_MULTI_STAGE = 3 };
+int  rt_scene_set_option(rt_scene *, int option, int value);
 
 /* ---- scene construction (replaces the closure-building constructors) -------------------- */
 int  rt_scene_create(rt_scene **out);
@@ -116,6 +143,13 @@ int  rt_end_mappend(rt_scene *);
 /* the `normals` wrapper of linearInterpolation                            Main.hs:956-965 */
 int  rt_set_normal_mode(rt_scene *, int first_leaf, int nleaves, int mode,
                         const double *params, int nparams);
+/* the `normals` wrapper with an arbitrary fnorm (e.g. the sine-cosine surface, Main.hs:599-605): leaves
+ * [first_leaf, first_leaf + nleaves) take their shading normal from `fn` (RT_NORMAL_CALLBACK); params =
+ * {scaleInv, offset x,y,z} as for RT_NORMAL_GAUSSIAN.  The render pauses after the hit points are known, hands the
+ * hit points of those leaves to `fn` on the host and continues with the returned normals, so the closure itself
+ * is evaluated and parity stays exact. */
+int  rt_set_normal_callback(rt_scene *, int first_leaf, int nleaves, const double params[4],
+                            rt_normal_fn fn, void *user);
 /* pointLight world diffuse specular lpos (world = this scene)             Main.hs:467-487 */
 int  rt_add_point_light(rt_scene *, double diffuse, double specular, const double pos[3]);
 /* ambient f                                                               Main.hs:490-492 */
@@ -152,13 +186,33 @@ int  rt_camera_params(int w, int h, double out[5]);
  * spp = 1 is the reference (one ray through the integer pixel coordinate, Main.hs:529-530);
  * spp > 1 (jittered supersampling, seed) is an extension documented in DESIGN.md.
  * rt_render takes HOST buffers (what a Haskell caller hands over); rt_render_device takes DEVICE
- * pointers on the current device and an optional hipStream_t (NULL = the library's stream) and
- * does not synchronise. */
+ * pointers on the calling thread's device and an optional hipStream_t, and does not synchronise.
+ * stream = NULL means the scene's OWN stream on that device, which is created non-blocking: it does
+ * NOT synchronise with the legacy default stream, so a caller that consumes the frame on another stream
+ * must either pass that stream here or call rt_synchronize() first. */
 int  rt_render(rt_scene *, int w, int h, int depth, int spp, uint64_t seed,
                int row0, int nrows, uint8_t *rgba_out, int32_t *hit_id_out);
 int  rt_render_device(rt_scene *, int w, int h, int depth, int spp, uint64_t seed,
                       int row0, int nrows, void *d_rgba, void *d_hit_id, void *stream);
-int  rt_synchronize(void);
+/* Makes the scene resident on the calling thread's device for w x h renders: builds the records on the host if the
+ * scene changed (rt_get_stats reports that time as prepare_ms) and uploads what is stale.  Renders do this
+ * themselves; call it to keep that work out of a timed region. */
+int  rt_scene_prepare_device(rt_scene *, int w, int h);
+/* parallelTrace for a whole image on `ngpus` devices of this process at once (Main.hs:623-637 in ONE call, for a
+ * caller that is a single process, e.g. the Haskell program): the image is cut into contiguous row bands of about
+ * equal cost (rt_split_rows over a 1/16-scale pre-render on devices[0]), band k is rendered on devices[k] (NULL:
+ * devices 0..ngpus-1; a device may be named more than once), copied to devices[0] over xGMI (peer-to-peer DMA) as
+ * its pieces finish, and from there to the caller's HOST buffers band by band.  Same pixels as rt_render. */
+int  rt_render_multi(rt_scene *, int w, int h, int depth, int spp, uint64_t seed, int ngpus, const int *devices,
+                     uint8_t *rgba_out, int32_t *hit_id_out);
+/* The band splitter of rt_render_multi (and of raytrace_amd/distributed.py, which must agree with it): n contiguous
+ * bands (row0[k], nrows[k]) of [0, h), cut at multiples of `align` rows, of about equal summed cost; `cost` is a
+ * per-row estimate at any vertical resolution (ncost entries cover [0, h)).  No device needed. */
+/* Relative cost of `ncost` equal horizontal strips of the w x h frame on the calling thread's device, measured with
+ * HIP events on a reduced-scale render of each strip (what rt_render_multi and bench.py cut their bands from). */
+int  rt_scene_row_costs(rt_scene *, int w, int h, int depth, int spp, int ncost, double *cost);
+int  rt_split_rows(const double *cost, int ncost, int h, int n, int align, int *row0, int *nrows);
+int  rt_synchronize(void);                      /* waits for everything enqueued on the calling thread's device */
 /* Page-locked host memory for rt_render's output buffers, in place of the reference's storable-vector
  * allocation behind `generateImage` (Main.hs:621 builds the image rt_render now fills).  Optional: any
  * host pointer works, but into these buffers the copy back is DMA at PCIe rate and hides behind the

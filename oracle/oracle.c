@@ -114,7 +114,7 @@ static int bb_fragile(bbox b, const ray *r) { return bb_any(b, r, 1.0) != bb_any
 /* ------------------------------------------------------------------------------------------ */
 /* Scene tree                                                                                  */
 
-enum { N_EMPTY, N_RECT, N_TRI, N_SPHERE, N_MANTLE, N_APPEND, N_LIST, N_GAUSS };
+enum { N_EMPTY, N_RECT, N_TRI, N_SPHERE, N_MANTLE, N_APPEND, N_LIST, N_GAUSS, N_FNORM };
 
 typedef struct {
     int kind;
@@ -134,8 +134,9 @@ typedef struct {
     /* interior */
     int left, right;          /* N_APPEND; N_GAUSS uses left */
     int *kids; bbox *sfx; int nkids;  /* N_LIST: children and suffix boxes */
-    /* gaussian normals wrapper */
+    /* normals wrapper: N_GAUSS (main's fnorm) and N_FNORM (any fnorm, given as a C callback) */
     double scale_inv; v3 offset;
+    orc_fnorm fnorm; void *fnorm_user;
 } node;
 
 typedef struct { int kind; double diffuse, specular, f; v3 pos; } lightsrc; /* kind 0 point, 1 ambient */
@@ -341,6 +342,17 @@ int orc_normals_gaussian(orc_scene *s, int child, double scale_inv, const double
     return i;
 }
 
+/* the `normals` wrapper with an arbitrary fnorm (Main.hs:956-965 takes any Double -> Double -> Vector3D) */
+int orc_normals_callback(orc_scene *s, int child, double scale_inv, const double offset[3], orc_fnorm fn, void *user) {
+    if (child < 0 || child >= s->nnodes || !fn) return -1;
+    int i = new_node(s, N_FNORM);
+    s->nodes[i].left = child;
+    s->nodes[i].bb = s->nodes[child].bb;                                               /* :964 */
+    s->nodes[i].scale_inv = scale_inv; s->nodes[i].offset = P(offset);
+    s->nodes[i].fnorm = fn; s->nodes[i].fnorm_user = user;
+    return i;
+}
+
 static int add_light(orc_scene *s, lightsrc l) {
     if (s->nlights == s->caplights) {
         s->caplights = s->caplights ? 2 * s->caplights : 8;
@@ -505,6 +517,15 @@ static int isect_node(const orc_scene *s, int idx, const ray *r, hit *out, int u
         if (!isect_node(s, n->left, r, out, use_bbox)) return 0;
         v3 q = scalar(n->scale_inv, vsub(out->pos, n->offset));
         v3 np = gauss_fnorm(q.x, q.z);
+        out->normal = scalar(hs_signum(dot(out->normal, np)), np);
+        return 1;
+    }
+    case N_FNORM: {                                                                    /* :959-963, fnorm' = the callback */
+        if (!isect_node(s, n->left, r, out, use_bbox)) return 0;
+        v3 q = scalar(n->scale_inv, vsub(out->pos, n->offset));
+        double nv[3] = { 0, 0, 0 };
+        n->fnorm(q.x, q.z, nv, n->fnorm_user);
+        v3 np = V(nv[0], nv[1], nv[2]);
         out->normal = scalar(hs_signum(dot(out->normal, np)), np);
         return 1;
     }
@@ -676,7 +697,7 @@ static void number_leaves(orc_scene *s, int idx, int *next, int *list) {
         if (list) list[*next] = idx;
         n->leaf_id = (*next)++;
         break;
-    case N_GAUSS: number_leaves(s, n->left, next, list); break;
+    case N_GAUSS: case N_FNORM: number_leaves(s, n->left, next, list); break;
     case N_APPEND: number_leaves(s, n->left, next, list); number_leaves(s, n->right, next, list); break;
     case N_LIST: for (int k = 0; k < n->nkids; ++k) number_leaves(s, n->kids[k], next, list); break;
     default: break;
@@ -713,7 +734,7 @@ static int leaf_margin(const node *n, const ray *r, double *t_out, double *margi
 static int guards_fragile(const orc_scene *s, int idx, const ray *r) {
     const node *n = &s->nodes[idx];
     switch (n->kind) {
-    case N_GAUSS: return guards_fragile(s, n->left, r);
+    case N_GAUSS: case N_FNORM: return guards_fragile(s, n->left, r);
     case N_APPEND:
         return bb_fragile(n->bb, r) || guards_fragile(s, n->left, r) || guards_fragile(s, n->right, r);
     case N_LIST:

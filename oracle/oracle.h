@@ -66,6 +66,9 @@ int orc_cylinder(orc_scene *, const orc_material *top, const orc_material *bot,
                  double h, double r);                                               /* Main.hs:725-774 */
 /* `normals` wrapper of linearInterpolation with the gaussian fnorm of main (Main.hs:580-584, 956-965) */
 int orc_normals_gaussian(orc_scene *, int child, double scale_inv, const double offset[3]);
+/* the same wrapper with any fnorm (Main.hs:956-965): out[0..2] = fnorm x y; called from the render threads */
+typedef void (*orc_fnorm)(double x, double y, double out[3], void *user);
+int orc_normals_callback(orc_scene *, int child, double scale_inv, const double offset[3], orc_fnorm fn, void *user);
 /* linearInterpolation with f = gaussian, fnorm = Just gaussian normal (Main.hs:578-585, 937-988).
  * Returns the world node; adds its point light and ambient light to the scene's light list. */
 int orc_linear_interpolation_gaussian(orc_scene *, double x1, double y1, double x2, double y2,

@@ -17,10 +17,16 @@ class rt_material(C.Structure):
 
 
 class rt_stats(C.Structure):
-    _fields_ = [("primary_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("tri_tests", C.c_uint64),
-                ("rect_tests", C.c_uint64), ("exact_evals", C.c_uint64), ("ms_primary", C.c_double),
+    _fields_ = [("primary_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("tri_pairs", C.c_uint64),
+                ("rect_pairs", C.c_uint64), ("exact_evals", C.c_uint64), ("ms_primary", C.c_double),
                 ("ms_setup", C.c_double), ("ms_shadow", C.c_double), ("ms_final", C.c_double), ("ms_total", C.c_double),
-                ("mfma_blocks_primary", C.c_uint64), ("mfma_blocks_shadow", C.c_uint64)]
+                ("mfma_blocks_primary", C.c_uint64), ("mfma_blocks_shadow", C.c_uint64),
+                ("record_tests", C.c_uint64), ("bounce_rays", C.c_uint64), ("prepare_ms", C.c_double), ("upload_ms", C.c_double)]
+
+
+# an `fnorm` closure as a C callback: void fn(int n, const double *xy, double *normals, void *user)
+NORMAL_FN = C.CFUNCTYPE(None, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p)
+RT_OPT_CULL, RT_OPT_FILTER, RT_OPT_HOST_BANDS, RT_OPT_MULTI_STAGE = 0, 1, 2, 3
 
 
 # every symbol include/raytrace_gpu.h declares: name -> (restype, argtypes)
@@ -35,6 +41,13 @@ SYMBOLS = {
     "rt_scene_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "rt_scene_destroy": (None, [C.c_void_p]),
     "rt_scene_set_dialect": (C.c_int, [C.c_void_p, C.c_int]),
+    "rt_scene_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "rt_set_normal_callback": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _D3, NORMAL_FN, C.c_void_p]),
+    "rt_scene_prepare_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "rt_scene_row_costs": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _D3]),
+    "rt_split_rows": (C.c_int, [_D3, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "rt_render_multi": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, C.POINTER(C.c_int),
+                                  C.c_void_p, C.c_void_p]),
     "rt_add_rectangle": (C.c_int, [C.c_void_p, _MAT, _D3, _D3, _D3]),
     "rt_add_triangle": (C.c_int, [C.c_void_p, _MAT, _D3, _D3, _D3]),
     "rt_add_sphere": (C.c_int, [C.c_void_p, _MAT, _D3, C.c_double]),
@@ -65,28 +78,43 @@ SYMBOLS = {
     "rt_write_bmp": (C.c_int, [C.c_char_p, C.c_void_p, C.c_int, C.c_int]),
 }
 
+VALU_LIB_PATH = os.path.join(_HERE, "lib", "libraytrace_gpu_valu.so")
 _lib = None
+_valu_lib = None
+
+
+def _load(path):
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`"
+                           " (there is no CPU fallback)")
+    L = C.CDLL(path)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    return L
 
 
 def lib():
     """Load libraytrace_gpu.so (built by __graft_entry__.build() / raytrace_amd/csrc/Makefile)."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`"
-                               " (there is no CPU fallback)")
-        L = C.CDLL(LIB_PATH)
-        for name, (res, args) in SYMBOLS.items():
-            fn = getattr(L, name)
-            fn.restype = res
-            fn.argtypes = args
-        _lib = L
+        _lib = _load(LIB_PATH)
     return _lib
 
 
-def check(rc, what="raytrace_gpu"):
+def valu_lib():
+    """The cross-check build (same sources, -DRT_VALU_FILTER): it also holds the FP32 vector-ALU kernel family, an
+    independent implementation of the filters.  Tests and tools compare whole frames of the two; never the product."""
+    global _valu_lib
+    if _valu_lib is None:
+        _valu_lib = _load(VALU_LIB_PATH)
+    return _valu_lib
+
+
+def check(rc, what="raytrace_gpu", L=None):
     if rc < 0:
-        msg = lib().rt_last_error().decode("utf-8", "replace")
+        msg = (L or lib()).rt_last_error().decode("utf-8", "replace")
         raise RuntimeError(f"{what} failed (rt_status {rc}): {msg}")
     return rc
 

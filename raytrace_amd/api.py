@@ -146,6 +146,16 @@ class GaussianNormals(Shape):
 
 
 @dataclass
+class CallbackNormals(Shape):
+    """linearInterpolation's `normals` wrapper with ANY fnorm (Main.hs:956-965): a Python callable
+    fnorm(x, y) -> (nx, ny, nz), evaluated on the host for the hit points the GPU finds (RT_NORMAL_CALLBACK)."""
+    child: Shape
+    scale_inv: float
+    offset: Vec
+    fnorm: Callable[[float, float], Vec]
+
+
+@dataclass
 class TalkDialect(Shape):
     """Marks a world as a src/Talk.hs world: rendered with Talk.hs's rules (rectangles only)."""
     child: Shape
@@ -276,7 +286,8 @@ def _steps(a, b, step):                  # Main.hs:948
 
 
 def linearInterpolation(f: Callable[[float, float], float], fnorm, p1, p2, step, origin, scale):
-    """Returns (world, lights).  fnorm is None (geometric normals) or GAUSSIAN_FNORM."""
+    """Returns (world, lights).  fnorm is None (geometric normals, `Nothing`), GAUSSIAN_FNORM (main's gaussian,
+    evaluated on the GPU) or any callable (x, y) -> (nx, ny, nz) (`Just fnorm`, evaluated on the host)."""
     (x1, y1), (x2, y2) = p1, p2
     x = (x2 + x1) / 2
     y = (y2 + y1) / 2
@@ -300,8 +311,10 @@ def linearInterpolation(f: Callable[[float, float], float], fnorm, p1, p2, step,
                 cells.append(two)
             elif fnorm == GAUSSIAN_FNORM:
                 cells.append(GaussianNormals(two, scale_inv, offset))
+            elif callable(fnorm):                                                  # any Double -> Double -> Vector3D
+                cells.append(CallbackNormals(two, scale_inv, offset, fnorm))
             else:
-                raise NotImplementedError("only the gaussian fnorm of main (Main.hs:581-584) is available on the GPU")
+                raise TypeError("fnorm must be None, GAUSSIAN_FNORM or a callable (x, y) -> (nx, ny, nz)")
     shape = mconcat([mconcat(cells),
                      rectangle(aquamarine, origin, (1.5 * scale * w, 0, 0), (0, 0, -(1.5 * scale * h)))])
     light = mconcat_lights([
@@ -326,8 +339,9 @@ def _cmat(m: Material):
 class Scene:
     """Owns an rt_scene.  Built from (world, lights) in the reference's depth-first leaf order."""
 
-    def __init__(self, world: Shape, lights):
-        self._L = _lib.lib()
+    def __init__(self, world: Shape, lights, lib=None):
+        self._L = lib or _lib.lib()
+        self._callbacks = []                      # keeps the ctypes callback objects alive
         h = C.c_void_p()
         _lib.check(self._L.rt_scene_create(C.byref(h)), "rt_scene_create")
         self._h = h
@@ -377,6 +391,21 @@ class Scene:
             n = L.rt_scene_num_leaves(h) - first
             params = (C.c_double * 4)(s.scale_inv, *s.offset)
             _lib.check(L.rt_set_normal_mode(h, first, n, 2, params, 4))
+        elif isinstance(s, CallbackNormals):
+            first = L.rt_scene_num_leaves(h)
+            self._add(s.child)
+            n = L.rt_scene_num_leaves(h) - first
+            params = (C.c_double * 4)(s.scale_inv, *s.offset)
+            fnorm = s.fnorm
+
+            def thunk(count, xy, normals, _user, fnorm=fnorm):
+                for i in range(count):
+                    v = fnorm(xy[2 * i], xy[2 * i + 1])
+                    normals[3 * i], normals[3 * i + 1], normals[3 * i + 2] = float(v[0]), float(v[1]), float(v[2])
+
+            cb = _lib.NORMAL_FN(thunk)
+            self._callbacks.append(cb)
+            _lib.check(L.rt_set_normal_callback(h, first, n, params, cb, None))
         else:
             raise TypeError(f"not a shape: {s!r}")
 
@@ -408,14 +437,40 @@ class Scene:
         hit = (out_hit if out_hit is not None else np.empty((nrows, w), np.int32)) if want_hit else None
         _lib.check(self._L.rt_render(self._h, w, h, depth, spp, seed, row0, nrows,
                                      rgba.ctypes.data if want_rgba else None,
-                                     hit.ctypes.data if want_hit else None), "rt_render")
+                                     hit.ctypes.data if want_hit else None), "rt_render", self._L)
+        return rgba, hit
+
+    def set_option(self, option, value):
+        """rt_scene_set_option: _lib.RT_OPT_CULL / RT_OPT_FILTER / RT_OPT_HOST_BANDS / RT_OPT_MULTI_STAGE."""
+        _lib.check(self._L.rt_scene_set_option(self._h, option, value), "rt_scene_set_option", self._L)
+        return self
+
+    def prepare(self, w, h):
+        """rt_scene_prepare_device: build the records and upload the scene now (keeps it out of a timed region)."""
+        _lib.check(self._L.rt_scene_prepare_device(self._h, w, h), "rt_scene_prepare_device", self._L)
+
+    def row_costs(self, w, h, ncost=32, depth=4, spp=1):
+        """rt_scene_row_costs: measured relative cost of ncost equal strips of the frame."""
+        out = (C.c_double * ncost)()
+        _lib.check(self._L.rt_scene_row_costs(self._h, w, h, depth, spp, ncost, out), "rt_scene_row_costs", self._L)
+        return [float(v) for v in out]
+
+    def render_multi(self, w, h, devices, depth=4, spp=1, seed=0, want_rgba=True, want_hit=True):
+        """rt_render_multi: the whole image on several devices of this process (bands of equal measured cost,
+        gathered on devices[0] over xGMI, then copied to host memory)."""
+        devs = (C.c_int * len(devices))(*devices)
+        rgba = np.empty((h, w, 4), np.uint8) if want_rgba else None
+        hit = np.empty((h, w), np.int32) if want_hit else None
+        _lib.check(self._L.rt_render_multi(self._h, w, h, depth, spp, seed, len(devices), devs,
+                                           rgba.ctypes.data if want_rgba else None,
+                                           hit.ctypes.data if want_hit else None), "rt_render_multi", self._L)
         return rgba, hit
 
     def render_device(self, w, h, d_rgba, d_hit, depth=4, spp=1, seed=0, row0=0, nrows=None, stream=None):
         """Device-buffer render (rt_render_device); d_rgba/d_hit are device addresses (int) or None."""
         nrows = h - row0 if nrows is None else nrows
         _lib.check(self._L.rt_render_device(self._h, w, h, depth, spp, seed, row0, nrows, d_rgba, d_hit, stream),
-                   "rt_render_device")
+                   "rt_render_device", self._L)
 
     def stats(self):
         st = _lib.rt_stats()

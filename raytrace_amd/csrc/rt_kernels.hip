@@ -21,8 +21,9 @@
 //     explicit fma builtins.
 #include <hip/hip_runtime.h>
 #include <algorithm>
-
+#include <chrono>
 #include <cmath>
+#include <mutex>
 #include <cstdio>
 #include <string>
 #include <vector>
@@ -94,6 +95,13 @@ struct RenderParams {
     unsigned *tcount;               // jobs of every (light, k_setup block); k_queue_offsets turns them into offsets in place
     int setup_blocks;               // k_setup blocks of this chunk
     uint32_t *lit;                  // per chunk pixel: bit l set = point light l reaches it
+    // RT_NORMAL_CALLBACK leaves (an arbitrary fnorm, Main.hs:956-965): k_cb_gather lists the hit points on them, the host
+    // evaluates the caller's function, k_setup reads the normals back
+    uint32_t *cb_slot;              // per slot of the chunk / level: index into the list
+    double *cb_xy;                  // per list entry: the arguments x, y of fnorm
+    int32_t *cb_group;              // per list entry: which callback
+    const double *cb_normal;        // per list entry: fnorm x y
+    unsigned *cb_count;             // entries in the list
     // bounce levels (reflective scenes, trace depth > 1; Main.hs:546-556).  A "slot" is a pixel of the chunk at
     // level 0 and an entry of the level's ray list above it.
     const RayRec *rays;             // this level's rays (nullptr at level 0: camera rays)
@@ -177,6 +185,9 @@ __device__ __forceinline__ RayD camera_ray(const RenderParams &P, int x, int y) 
 // wave adds to them once, and atomics on ONE address are serialised by the L2 (12 ns each: 0.4 ms for the 32 400 waves
 // of a 4K frame, which is what a single set of counters cost); rt_get_stats sums the copies.
 constexpr int RT_STAT_SLOTS = 256;
+// Workspace::qcount: [0, 32) shadow jobs per point light; [32, 32 + RT_MAX_LEVELS] rays per bounce level; then the
+// number of hit points waiting for a normal callback
+constexpr int RT_QCOUNT_CB = 32 + RT_MAX_LEVELS + 1, RT_QCOUNT_WORDS = RT_QCOUNT_CB + 1;
 __device__ __forceinline__ void stat_add(const RenderParams &P, int k, unsigned long long v) {
     const unsigned wave = (blockIdx.x + blockIdx.y * gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
     atomicAdd(&P.counters[(size_t)(wave % RT_STAT_SLOTS) * 16 + k], v);
@@ -328,6 +339,7 @@ __device__ __forceinline__ f2 pkfma(f2 a, f2 b, f2 c) { return __builtin_element
 
 struct Dir4 { f2 x[2], y[2], z[2]; };   // directions of the lane's 4 rays from the apex
 
+#ifdef RT_VALU_FILTER   // the FP32 vector-ALU kernel family: cross-check build only (libraytrace_gpu_valu.so)
 // Returns z[r] for the lane's 4 rays: ray r passes the filter iff z[r] >= R.c[9] (= -margin).
 //   triangle : z = min(q1*N, q2*N, (1-q1-q2)*N [, N - Kq])      q1, q2 = barycentrics r, s
 //   rectangle: z = min(N - max(|a'N|, |b'N|)     [, N - Kq])     a', b' in [-1, 1]
@@ -358,6 +370,7 @@ __device__ __forceinline__ bool filter4(const FilterRec &R, const Dir4 &D, float
     return mx >= R.c[9];
 }
 
+#endif // RT_VALU_FILTER
 // Sphere, apex form: z = (D.oc)^2 - |D|^2 cs; dd = |D|^2 of the lane's rays.
 __device__ __forceinline__ bool filter4_sphere(const FilterRec &R, const Dir4 &D, const f2 dd[2], float z[4]) {
 #pragma unroll
@@ -374,6 +387,7 @@ __device__ __forceinline__ void dir_norms(const Dir4 &D, f2 dd[2]) {
     for (int p = 0; p < 2; ++p) dd[p] = pkfma(D.x[p], D.x[p], pkfma(D.y[p], D.y[p], D.z[p] * D.z[p]));
 }
 
+#ifdef RT_VALU_FILTER   // the FP32 vector-ALU kernel family: cross-check build only (libraytrace_gpu_valu.so)
 // Eye-apex variant: the forms are affine in the pixel's viewport position (posX, posY); the lane's 4
 // pixels share posY (SHARED_Y, spp == 1), so the posY part of a form is computed once per lane.
 //   triangle : z = min(U, V, W)          rectangle: z = N - max(|A|, |B|)
@@ -542,6 +556,7 @@ __global__ void RT_HOT(RT_WAVES_EU_PRIMARY) k_primary(const RenderParams P) {
     if ((threadIdx.x & 63) == 0 && nexact) stat_add(P, 1, (unsigned long long)nexact);
 }
 
+#endif // RT_VALU_FILTER
 // ------------------------------------------------------------------------------------------
 // Kernel 2: per hit pixel, the exact hit point and shading normal; shadow jobs for every point light
 //   with L.N > 0, compacted into one queue per light (wave-aggregated atomics).
@@ -639,6 +654,12 @@ __global__ void __launch_bounds__(RT_SETUP_THREADS) k_setup(const RenderParams P
             const double dt = nx * ux + ny * uy + nz * uz;
             const double sg = dt > 0 ? 1.0 : (dt < 0 ? -1.0 : dt);                      // signum
             nx = sg * ux; ny = sg * uy; nz = sg * uz;
+        } else if (L.nmode == RT_NORMAL_CALLBACK) {                                    // Main.hs:959-963 with the caller's fnorm
+            const double *un = P.cb_normal + 3 * (size_t)P.cb_slot[pix];               // n' = fnorm' x y, evaluated on the host
+            const double ux = un[0], uy = un[1], uz = un[2];
+            const double dt = nx * ux + ny * uy + nz * uz;
+            const double sg = dt > 0 ? 1.0 : (dt < 0 ? -1.0 : dt);                      // signum
+            nx = sg * ux; ny = sg * uy; nz = sg * uz;
         }
         H.px = ix; H.py = iy; H.pz = iz; H.nx = nx; H.ny = ny; H.nz = nz;
         P.hitrec[pix] = H;
@@ -729,6 +750,7 @@ __global__ void __launch_bounds__(RT_SETUP_THREADS) k_queue_compact(const Render
 //   replaces `intersect world ray_to_light` + the t <= distance test of pointLight (Main.hs:472-474).
 //   Apex = the light, D = shadow-ray origin - light; the filter's clip keeps leaves between them.
 
+#ifdef RT_VALU_FILTER   // the FP32 vector-ALU kernel family: cross-check build only (libraytrace_gpu_valu.so)
 template <int KIND>
 __device__ __forceinline__ void shadow_loop(const RenderParams &P, CRecPtr recs, CIntPtr gids, int n, const Dir4 &D,
                                             const uint32_t pix[4], const int own[4], const LightD &Lt, bool need[4],
@@ -802,6 +824,7 @@ __device__ __forceinline__ void shadow_loop(const RenderParams &P, CRecPtr recs,
 #endif
 }
 
+#endif // RT_VALU_FILTER
 // spheres between a light and the shadow-ray origins (no own-leaf exclusion: a sphere is not planar)
 __device__ __forceinline__ void shadow_sphere_loop(const RenderParams &P, CRecPtr recs, const Dir4 &D, const uint32_t pix[4],
                                                 const LightD &Lt, bool need[4], unsigned &nexact) {
@@ -835,6 +858,7 @@ __device__ __forceinline__ void shadow_sphere_loop(const RenderParams &P, CRecPt
     }
 }
 
+#ifdef RT_VALU_FILTER   // the FP32 vector-ALU kernel family: cross-check build only (libraytrace_gpu_valu.so)
 __global__ void RT_HOT(RT_WAVES_EU_SHADOW) k_shadow(const RenderParams P) {
     const int pl = (int)blockIdx.y;
     const unsigned count = P.qcount[pl];
@@ -883,6 +907,7 @@ __global__ void RT_HOT(RT_WAVES_EU_SHADOW) k_shadow(const RenderParams P) {
     if (lane == 0 && nexact) stat_add(P, 2, (unsigned long long)nexact);
 }
 
+#endif // RT_VALU_FILTER
 // ------------------------------------------------------------------------------------------
 // Matrix-core versions of kernels 1 and 3.
 //
@@ -1042,6 +1067,7 @@ constexpr int RT_Q1_CAP = 128, RT_Q2_CAP = 128;
 struct WaveQueues {
     uint32_t *q1, *q2;
     unsigned n1, n2;
+    unsigned nrec;                  // FP32 record tests so far (statistics)
 };
 __device__ __forceinline__ void q_push(uint32_t *q, unsigned &n, bool pred, uint32_t entry) {
     const unsigned long long m = __builtin_amdgcn_ballot_w64(pred);
@@ -1054,6 +1080,7 @@ __device__ __forceinline__ void q_drain(WaveQueues &Q, unsigned keep, S1 &&stage
     while (Q.n1 > keep) {
         const unsigned take = Q.n1 < 64u ? Q.n1 : 64u;
         Q.n1 -= take;
+        Q.nrec += take;
         const bool have = lane < take;
         const uint32_t entry = have ? Q.q1[Q.n1 + lane] : 0u;
         const bool pass = have && stage1(entry);
@@ -1355,7 +1382,7 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_shadow_mfma(const RenderParams P) {
     const i32x4 *blocks = reinterpret_cast<const i32x4 *>(P.mf_rows) + ro * gstride * 32;
     const FilterRec *recs = P.mf_rec + ro * gstride * MF_LEAVES;
     unsigned nexact = 0, nblocks = 0;
-    WaveQueues Q = {s_q1[wv], s_q2[wv], 0u, 0u};
+    WaveQueues Q = {s_q1[wv], s_q2[wv], 0u, 0u, 0u};
     culled_scan(blocks, P.mf_cone + ro * gstride * 8, P.mf_groups, s_bun[wv], s_list[wv], B, Q, c, h, nblocks,
         [&](uint32_t entry) -> bool {           // FP32 record test of one (ray, leaf) pair
             const int e = (int)(entry & 255u);
@@ -1414,6 +1441,7 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_shadow_mfma(const RenderParams P) {
     for (int o = 32; o > 0; o >>= 1) nexact += __shfl_down(nexact, o);
     if (lane == 0 && nexact) stat_add(P, 2, (unsigned long long)nexact);
     if (lane == 0) stat_add(P, 7, (unsigned long long)nblocks);
+    if (lane == 0 && Q.nrec) stat_add(P, 4, (unsigned long long)Q.nrec);
 }
 
 // Kernel 1 on the matrix cores.  One wave = 32 x 8 pixel tile; ray block b = tile row b, column c = lane & 31.
@@ -1468,7 +1496,7 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_primary_mfma(const RenderParams P) {
     __builtin_amdgcn_wave_barrier();
     const unsigned long long passed = P.nguard_cached > 0 ? tile_guard_mask(P, x0, P.row0 + ly0) : 0ull;
     unsigned nexact = 0, nblocks = 0;
-    WaveQueues Q = {s_q1[wv], s_q2[wv], 0u, 0u};
+    WaveQueues Q = {s_q1[wv], s_q2[wv], 0u, 0u, 0u};
 #ifdef RT_X_NOSCAN
     if (P.w < 0)
 #endif
@@ -1483,9 +1511,6 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_primary_mfma(const RenderParams P) {
             const float px = (float)(P.cam.scaleX * ((double)xe + ox) + P.cam.dX);
             const float py = (float)(P.cam.scaleY * ((double)ye + oy) + P.cam.dY);
             // eye records are affine in (posX, posY): the z column already holds c_z * d
-#ifdef RT_COUNT_EVENTS
-            stat_add(P, 4, 1ull);
-#endif
             return gid >= 0 && record_test(R, kind, px, py, 1.0f);
         },
         [&](uint32_t entry) {                   // exact: intersect leaf (cast camera x y), Main.hs:543
@@ -1505,7 +1530,8 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_primary_mfma(const RenderParams P) {
             // the same pixel: the wave runs in lockstep and its LDS operations complete in order, so (1) all read the
             // old t, (2) all fold their t in with an atomic min, (3) the lanes whose t is the new minimum reset the
             // leaf index if the minimum moved, (4) and fold their leaf index in with an atomic min.
-            const unsigned long long tb = (unsigned long long)__double_as_longlong(tt);
+            // t = -0.0 passes `t >= 0` (a leaf in the viewport plane) and must order as 0, not as the largest pattern
+            const unsigned long long tb = (unsigned long long)__double_as_longlong(tt + 0.0);
             unsigned long long old = 0;
             if (hit) { old = bt[e]; atomicMin(&bt[e], tb); }
             __builtin_amdgcn_wave_barrier();
@@ -1567,6 +1593,7 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_primary_mfma(const RenderParams P) {
     for (int o = 32; o > 0; o >>= 1) nexact += __shfl_down(nexact, o);
     if (lane == 0 && nexact) stat_add(P, 1, (unsigned long long)nexact);
     if (lane == 0) stat_add(P, 6, (unsigned long long)nblocks);
+    if (lane == 0 && Q.nrec) stat_add(P, 4, (unsigned long long)Q.nrec);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1777,6 +1804,7 @@ __global__ void RT_HOT(4) k_general(const RenderParams P) {
         if (act[r]) P.hit_id[P.out_off + slot[r]] = bid[r];
     for (int o2 = 32; o2 > 0; o2 >>= 1) nexact += __shfl_down(nexact, o2);
     if (lane == 0 && nexact) stat_add(P, 1, (unsigned long long)nexact);
+    if (lane == 0) stat_add(P, 5, (unsigned long long)min(256u, count - wave * 256u));     // reflected rays traced
 }
 
 // colour of a level folded into the level below: addPixelRGB8 direct (scalePixelRGB8 reflectivity sub), Main.hs:545, 554
@@ -1817,19 +1845,52 @@ __global__ void k_resolve(const uint32_t *__restrict__ accum, uint8_t *__restric
     reinterpret_cast<uint32_t *>(rgba)[i] = r | (g << 8) | (b << 16) | 0xff000000u;
 }
 
+// RT_NORMAL_CALLBACK (an arbitrary fnorm, Main.hs:956-965): lists the slots of this chunk / level whose nearest hit lies
+// on such a leaf, with the arguments the reference passes to fnorm: (x, _, y) = scaleInv * (i - offset), Main.hs:961.
+__global__ void __launch_bounds__(256) k_cb_gather(const RenderParams P) {
+    const int pix = (int)(blockIdx.x * 256 + threadIdx.x);
+    const bool act = (unsigned)pix < num_slots(P);
+    const int id = act ? P.hit_id[P.out_off + pix] : -1;
+    bool want = false;
+    double fx = 0, fy = 0;
+    int group = 0;
+    if (id >= 0) {
+        const LeafD L = P.leaves[id];
+        if (L.nmode == RT_NORMAL_CALLBACK) {
+            const RayD ray = slot_ray(P, pix);
+            double ix = 0, iy = 0, iz = 0, t;
+            if (L.kind == LEAF_RECT) leaf_isect<LEAF_RECT>(L, ray, ix, iy, iz, t, RT_TALK(P));
+            else if (L.kind == LEAF_TRI) leaf_isect<LEAF_TRI>(L, ray, ix, iy, iz, t, RT_TALK(P));
+            else leaf_isect<LEAF_SPHERE>(L, ray, ix, iy, iz, t, RT_TALK(P));
+            const AuxD A = P.aux[L.aux];
+            fx = A.a[0] * (ix - A.a[1]); fy = A.a[0] * (iz - A.a[3]);
+            group = (int)A.a[4];
+            want = true;
+        }
+    }
+    const unsigned long long m = __ballot(want);
+    if (!m) return;
+    const int lane = (int)(threadIdx.x & 63), leader = __ffsll((long long)m) - 1;
+    unsigned base = 0;
+    if (lane == leader) base = atomicAdd(P.cb_count, (unsigned)__popcll(m));
+    base = __shfl(base, leader);
+    if (want) {
+        const unsigned k = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+        P.cb_slot[pix] = k;
+        P.cb_xy[2 * (size_t)k] = fx; P.cb_xy[2 * (size_t)k + 1] = fy;
+        P.cb_group[k] = group;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // Host side
 
-hipStream_t g_stream = nullptr;
-// rt_render's device-to-host copies run here, band by band, behind the render of the following bands
-hipStream_t g_copy_stream = nullptr;
-constexpr int RT_HOST_BANDS_MAX = 8;
-hipEvent_t g_band_done[RT_HOST_BANDS_MAX] = {};
-int g_device = -1;
-// RT_FILTER=valu selects the scalar-record VALU kernels (k_primary / k_shadow) instead of the matrix-core ones
-bool g_use_mfma = true;
-// RT_CULL=0: every wave scans every block of the leaf stream (the plain brute-force scan, for comparison)
-bool g_cull = true;
+// Library state per device and per thread.  Everything else lives in the (scene, device) pair: streams, events,
+// uploaded records, work buffers — so distinct scenes can be rendered from different threads.
+struct DeviceCtx { bool ready = false; };
+DeviceCtx g_ctx[RT_MAX_DEVICES];
+std::mutex g_ctx_mutex;
+thread_local int t_device = -1;          // the device this thread renders on (rt_init)
 
 bool hip_ok(hipError_t e, const char *what) {
     if (e == hipSuccess) return true;
@@ -1838,12 +1899,52 @@ bool hip_ok(hipError_t e, const char *what) {
 }
 #define HIP_TRY(expr) do { if (!hip_ok((expr), #expr)) return RT_ERR_HIP; } while (0)
 
+double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// Sets the library up on `device` and makes it the calling thread's device.
+int device_init(int device) {
+    int n = 0;
+    if (!hip_ok(hipGetDeviceCount(&n), "hipGetDeviceCount") || n <= 0) {
+        set_error("rt_init: no HIP device available (this library has no CPU fallback)");
+        return RT_ERR_HIP;
+    }
+    if (device < 0 || device >= n || device >= RT_MAX_DEVICES) { set_error("rt_init: device index out of range"); return RT_ERR_ARG; }
+    HIP_TRY(hipSetDevice(device));
+    {
+        std::lock_guard<std::mutex> lock(g_ctx_mutex);
+        DeviceCtx &C = g_ctx[device];
+        if (!C.ready) C.ready = true;
+    }
+    t_device = device;
+    return RT_OK;
+}
+// Every entry point that touches the device starts here: the thread's device is made current again (the caller may
+// have switched it, e.g. through another library).
+int enter() {
+    if (t_device < 0) return device_init(0);
+    HIP_TRY(hipSetDevice(t_device));
+    return RT_OK;
+}
+
 template <typename T>
-int upload(T *&dst, const std::vector<T> &src) {
-    if (dst) { HIP_TRY(hipFree(dst)); dst = nullptr; }
+int upload(DevBuf &dst, const std::vector<T> &src) {
     const size_t bytes = sizeof(T) * (src.empty() ? 1 : src.size());
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dst), bytes));
-    if (!src.empty()) HIP_TRY(hipMemcpy(dst, src.data(), sizeof(T) * src.size(), hipMemcpyHostToDevice));
+    if (!dst.p || dst.cap < bytes) {
+        if (dst.p) { HIP_TRY(hipFree(dst.p)); dst.p = nullptr; dst.cap = 0; }
+        HIP_TRY(hipMalloc(&dst.p, bytes));
+        dst.cap = bytes;
+    }
+    if (!src.empty()) HIP_TRY(hipMemcpy(dst.p, src.data(), sizeof(T) * src.size(), hipMemcpyHostToDevice));
+    return RT_OK;
+}
+// elements [first, first + count) of an array that is already resident
+template <typename T>
+int upload_slice(DevBuf &dst, const std::vector<T> &src, size_t first, size_t count) {
+    if (count == 0) return RT_OK;
+    if (!dst.p || dst.cap < sizeof(T) * (first + count) || src.size() < first + count) { set_error("upload_slice: array not resident"); return RT_ERR_ARG; }
+    HIP_TRY(hipMemcpy((char *)dst.p + sizeof(T) * first, src.data() + first, sizeof(T) * count, hipMemcpyHostToDevice));
     return RT_OK;
 }
 
@@ -1851,180 +1952,221 @@ template <typename T>
 int ensure(T *&buf, size_t &cap, size_t need) {
     if (cap >= need && buf) return RT_OK;
     if (buf) { HIP_TRY(hipFree(buf)); buf = nullptr; cap = 0; }
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&buf), sizeof(T) * need));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&buf), sizeof(T) * (need ? need : 1)));
     cap = need;
     return RT_OK;
 }
 
-int ensure_init() {
-    if (g_device >= 0) return RT_OK;
-    return rt_init(0);
-}
-
-int prepare(rt_scene &s, int w, int h) {
+// Makes the scene resident on the thread's device for w x h renders (rt_scene_prepare_device).
+int device_prepare(rt_scene &s, DeviceScene &D, int device, int w, int h) {
+    if (!prepare_host(s, w, h)) return RT_ERR_ARG;
+    if (s.mf_groups + 2 > 65535) { set_error("rt_render: more than 2 million planar leaves are not supported (16-bit block indices)"); return RT_ERR_UNSUPPORTED; }
+    D.device = device;
+    if (!D.stream) { hipStream_t st; HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); D.stream = st; }
+    if (!D.copy_stream) { hipStream_t st; HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); D.copy_stream = st; }
+    if (!D.copy_stream2) { hipStream_t st; HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); D.copy_stream2 = st; }
+    for (void *&e : D.band_done) if (!e) { hipEvent_t ev; HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); e = ev; }
+    if (D.version == s.version && D.eye_version == s.eye_version) return RT_OK;
+    const double t0 = now_ms();
     int rc;
-    if (s.dirty || s.rec_w != w || s.rec_h != h || s.dev.device != g_device) {
-        if (!compute_guards(s)) return RT_ERR_ARG;
-        build_filter_records(s, w, h);
-        if ((rc = upload(s.dev.leaves, s.leaves))) return rc;
-        if ((rc = upload(s.dev.aux, s.aux))) return rc;
-        if ((rc = upload(s.dev.guards, s.guards))) return rc;
-        if ((rc = upload(s.dev.mats, s.mats))) return rc;
-        if ((rc = upload(s.dev.lights, s.lights))) return rc;
-        if ((rc = upload(s.dev.tri_rec, s.tri_rec))) return rc;
-        if ((rc = upload(s.dev.rect_rec, s.rect_rec))) return rc;
-        if ((rc = upload(s.dev.sph_rec, s.sph_rec))) return rc;
-        if ((rc = upload(s.dev.sph_gid, s.sph_gid))) return rc;
-        if ((rc = upload(s.dev.mf_rows, s.mf_rows))) return rc;
-        if ((rc = upload(s.dev.mf_gid, s.mf_gid))) return rc;
-        if ((rc = upload(s.dev.mf_cone, s.mf_cone))) return rc;
-        if ((rc = upload(s.dev.mf_rec, s.mf_rec))) return rc;
+    // a render of the stale copy may still be in flight on some stream: the arrays are overwritten in place
+    if (D.version != 0) HIP_TRY(hipDeviceSynchronize());
+    const size_t ntri = s.tri_gid.size(), nrect = s.rect_gid.size(), nsph = s.sph_gid.size();
+    const size_t gstride = (size_t)s.mf_groups + 2;
+    if (D.version != s.version) {
+        if ((rc = upload(D.leaves, s.leaves))) return rc;
+        if ((rc = upload(D.aux, s.aux))) return rc;
+        if ((rc = upload(D.guards, s.guards))) return rc;
+        if ((rc = upload(D.mats, s.mats))) return rc;
+        if ((rc = upload(D.lights, s.lights))) return rc;
+        if ((rc = upload(D.tri_rec, s.tri_rec))) return rc;
+        if ((rc = upload(D.rect_rec, s.rect_rec))) return rc;
+        if ((rc = upload(D.sph_rec, s.sph_rec))) return rc;
+        if ((rc = upload(D.sph_gid, s.sph_gid))) return rc;
+        if ((rc = upload(D.mf_rows, s.mf_rows))) return rc;
+        if ((rc = upload(D.mf_gid, s.mf_gid))) return rc;
+        if ((rc = upload(D.mf_cone, s.mf_cone))) return rc;
+        if ((rc = upload(D.mf_rec, s.mf_rec))) return rc;
         if (s.reflective) {
-            if ((rc = upload(s.dev.gen_sph, s.gen_sph))) return rc;
-            if ((rc = upload(s.dev.gen_tri, s.gen_tri))) return rc;
-            if ((rc = upload(s.dev.gen_rect, s.gen_rect))) return rc;
+            if ((rc = upload(D.gen_sph, s.gen_sph))) return rc;
+            if ((rc = upload(D.gen_tri, s.gen_tri))) return rc;
+            if ((rc = upload(D.gen_rect, s.gen_rect))) return rc;
         }
-        if ((rc = upload(s.dev.tri_gid, s.tri_gid))) return rc;
-        if ((rc = upload(s.dev.rect_gid, s.rect_gid))) return rc;
-        if (!s.dev.counters) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s.dev.counters), RT_STAT_SLOTS * 16 * sizeof(unsigned long long)));
-        if (!s.dev.qcount) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s.dev.qcount), 64 * sizeof(unsigned)));
-        s.dev.device = g_device;
-        s.dirty = false;
+        if ((rc = upload(D.tri_gid, s.tri_gid))) return rc;
+        if ((rc = upload(D.rect_gid, s.rect_gid))) return rc;
+    } else {
+        // only the camera bound grew: apex 0 (the eye) of every per-apex array
+        if ((rc = upload_slice(D.tri_rec, s.tri_rec, 0, ntri))) return rc;
+        if ((rc = upload_slice(D.rect_rec, s.rect_rec, 0, nrect))) return rc;
+        if ((rc = upload_slice(D.sph_rec, s.sph_rec, 0, nsph))) return rc;
+        if ((rc = upload_slice(D.mf_rows, s.mf_rows, 0, gstride * 32 * 8))) return rc;
+        if ((rc = upload_slice(D.mf_gid, s.mf_gid, 0, gstride * MF_LEAVES))) return rc;
+        if ((rc = upload_slice(D.mf_cone, s.mf_cone, 0, gstride * 8))) return rc;
+        if ((rc = upload_slice(D.mf_rec, s.mf_rec, 0, gstride * MF_LEAVES))) return rc;
     }
+    D.version = s.version;
+    D.eye_version = s.eye_version;
+    D.stats.upload_ms = now_ms() - t0;
     return RT_OK;
 }
 
 // event pool: one event per kernel boundary, so that rt_get_stats can attribute time to each kernel
-int next_event(rt_scene &s, hipStream_t st, int kind) {
-    if (s.ev_used == (int)s.evpool.size()) {
+int next_event(DeviceScene &D, hipStream_t st, int kind) {
+    if (D.ev_used == (int)D.evpool.size()) {
         hipEvent_t e;
         HIP_TRY(hipEventCreate(&e));
-        s.evpool.push_back(e);
-        s.evkind.push_back(0);
+        D.evpool.push_back(e);
+        D.evkind.push_back(0);
     }
-    s.evkind[s.ev_used] = kind;
-    HIP_TRY(hipEventRecord((hipEvent_t)s.evpool[s.ev_used], st));
-    ++s.ev_used;
+    D.evkind[D.ev_used] = kind;
+    HIP_TRY(hipEventRecord((hipEvent_t)D.evpool[D.ev_used], st));
+    ++D.ev_used;
     return RT_OK;
 }
 
 constexpr size_t RT_CHUNK_PIXELS = 16u << 20;   // rows are processed in chunks of about 16 Mi pixels
 
-} // namespace
-
-extern "C" {
-
-int rt_init(int device) {
-    int n = 0;
-    if (!hip_ok(hipGetDeviceCount(&n), "hipGetDeviceCount") || n <= 0) {
-        set_error("rt_init: no HIP device available (this library has no CPU fallback)");
-        return RT_ERR_HIP;
+int render_levels(const rt_scene *s, int depth) {
+    return (s->reflective && depth > 1 && !s->talk) ? (depth < RT_MAX_LEVELS ? depth : RT_MAX_LEVELS) : 1;
+}
+bool levels_supported(const rt_scene *s, int depth) {
+    if (s->reflective && !s->talk && depth > RT_MAX_LEVELS) {
+        set_error("rt_render: trace depth > 64 with reflective materials is not supported"); return false;
     }
-    if (device < 0 || device >= n) { set_error("rt_init: device index out of range"); return RT_ERR_ARG; }
-    HIP_TRY(hipSetDevice(device));
-    if (g_stream && g_device != device) {
-        (void)hipStreamDestroy(g_stream); g_stream = nullptr;
-        (void)hipStreamDestroy(g_copy_stream); g_copy_stream = nullptr;
-        for (hipEvent_t &e : g_band_done) { if (e) (void)hipEventDestroy(e); e = nullptr; }
+    return true;
+}
+
+// What one render needs beyond its inputs and outputs, in elements of each buffer.
+struct WsNeeds {
+    size_t hit_id = 0, accum = 0, hitrec = 0, queue = 0, qsparse = 0, tcount = 0, lit = 0, lvl = 0, cb = 0;
+    int levels = 1;
+};
+size_t setup_blocks_bound(int w, size_t crow) {   // k_setup blocks of a chunk: 32 x 16 pixel tiles at level 0, runs of slots above
+    const size_t cpix = crow * (size_t)w;
+    return std::max((size_t)((w + 31) / 32) * ((crow + RT_SETUP_THREADS / 32 - 1) / (RT_SETUP_THREADS / 32)),
+                    (cpix + RT_SETUP_THREADS - 1) / RT_SETUP_THREADS);
+}
+WsNeeds ws_needs(int w, int nrows, size_t crow, int npoint, int levels, int spp, bool own_hit, bool shade, bool callbacks) {
+    WsNeeds n;
+    const size_t npix = (size_t)w * (size_t)nrows, cpix = crow * (size_t)w, np = (size_t)(npoint > 0 ? npoint : 1);
+    n.levels = levels;
+    if (own_hit || spp > 1) n.hit_id = npix;
+    if (!shade) return n;
+    if (spp > 1) n.accum = 3 * npix;
+    n.hitrec = cpix * sizeof(HitRec);
+    n.lit = cpix;
+    n.queue = cpix * np;
+    const size_t ub = setup_blocks_bound(w, crow);
+    n.qsparse = ub * RT_SETUP_THREADS * np;
+    n.tcount = (ub + 1) * np;
+    if (levels > 1) n.lvl = cpix;
+    if (callbacks) n.cb = cpix;
+    return n;
+}
+// rt_render / rt_render_device: the work buffers of the (scene, device) pair, grown on demand
+int ws_grow(DeviceScene &D, const WsNeeds &n) {
+    int rc;
+    Workspace &W = D.ws;
+    if (!W.counters) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&W.counters), RT_STAT_SLOTS * 16 * sizeof(unsigned long long)));
+    if (!W.qcount) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&W.qcount), RT_QCOUNT_WORDS * sizeof(unsigned)));
+    if (n.hit_id && (rc = ensure(W.hit_id, D.hit_id_cap, n.hit_id))) return rc;
+    if (n.accum && (rc = ensure(W.accum, D.accum_cap, n.accum))) return rc;
+    if (n.hitrec && (rc = ensure(W.hitrec, D.hitrec_cap, n.hitrec))) return rc;
+    if (n.lit && (rc = ensure(W.lit, D.lit_cap, n.lit))) return rc;
+    if (n.queue && (rc = ensure(W.queue, D.queue_cap, n.queue))) return rc;
+    if (n.qsparse && (rc = ensure(W.qsparse, D.qsparse_cap, n.qsparse))) return rc;
+    if (n.tcount && (rc = ensure(W.tcount, D.tcount_cap, n.tcount))) return rc;
+    if (n.lvl) {
+        if ((rc = ensure(W.lvl_col[0], D.lvl_col_cap[0], n.lvl))) return rc;
+        for (int k = 1; k < n.levels && k < RT_MAX_LEVELS; ++k) {
+            if ((rc = ensure(W.lvl_rays[k], D.lvl_rays_cap[k], n.lvl))) return rc;
+            if ((rc = ensure(W.lvl_hit[k], D.lvl_hit_cap[k], n.lvl))) return rc;
+            if ((rc = ensure(W.lvl_col[k], D.lvl_col_cap[k], n.lvl))) return rc;
+        }
     }
-    if (!g_stream) HIP_TRY(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
-    if (!g_copy_stream) HIP_TRY(hipStreamCreateWithFlags(&g_copy_stream, hipStreamNonBlocking));
-    for (hipEvent_t &e : g_band_done) if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    g_device = device;
-    const char *f = getenv("RT_FILTER");
-    g_use_mfma = !(f && std::string(f) == "valu");
-    const char *cl = getenv("RT_CULL");
-    g_cull = !(cl && std::string(cl) == "0");
+    if (n.cb) {
+        if ((rc = ensure(W.cb_slot, D.cb_cap[0], n.cb))) return rc;
+        if ((rc = ensure(W.cb_xy, D.cb_cap[1], 2 * n.cb))) return rc;
+        if ((rc = ensure(W.cb_group, D.cb_cap[2], n.cb))) return rc;
+        if ((rc = ensure(W.cb_normal, D.cb_cap[3], 3 * n.cb))) return rc;
+    }
     return RT_OK;
 }
 
-void rt_scene_destroy(rt_scene *s) {
-    if (!s) return;
-    DeviceScene &d = s->dev;
-    void *ptrs[] = {d.leaves, d.aux, d.guards, d.mats, d.lights, d.tri_rec, d.rect_rec, d.tri_gid, d.rect_gid,
-                    d.counters, d.qcount, d.hit_id, d.accum, d.rgba, d.hit_out, d.hitrec, d.queue, d.qsparse, d.tcount, d.lit, d.gen_tri, d.gen_rect, d.sph_rec, d.gen_sph, d.sph_gid, d.mf_rows, d.mf_gid, d.mf_rec, d.mf_cone};
-    for (void *p : ptrs) if (p) (void)hipFree(p);
-    for (int k = 0; k < 8; ++k) {
-        if (d.lvl_rays[k]) (void)hipFree(d.lvl_rays[k]);
-        if (d.lvl_hit[k]) (void)hipFree(d.lvl_hit[k]);
-        if (d.lvl_col[k]) (void)hipFree(d.lvl_col[k]);
+// RT_NORMAL_CALLBACK: between the nearest-hit kernel and k_setup, the hit points that lie on callback leaves go to the
+// host, the caller's fnorm is evaluated there (per callback group), and the normals come back.
+int run_normal_callbacks(rt_scene &s, const RenderParams &P, hipStream_t st, unsigned pblocks) {
+    HIP_TRY(hipMemsetAsync(P.cb_count, 0, sizeof(unsigned), st));
+    hipLaunchKernelGGL(k_cb_gather, dim3(pblocks), dim3(256), 0, st, P);
+    unsigned count = 0;
+    HIP_TRY(hipMemcpyAsync(&count, P.cb_count, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (count == 0) return RT_OK;
+    std::vector<double> xy(2 * (size_t)count), nrm(3 * (size_t)count);
+    std::vector<int32_t> grp(count);
+    HIP_TRY(hipMemcpy(xy.data(), P.cb_xy, xy.size() * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(grp.data(), P.cb_group, grp.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    std::vector<double> gxy, gn;
+    std::vector<unsigned> idx;
+    for (size_t g = 0; g < s.normal_fn.size(); ++g) {
+        gxy.clear(); idx.clear();
+        for (unsigned k = 0; k < count; ++k)
+            if (grp[k] == (int32_t)g) { idx.push_back(k); gxy.push_back(xy[2 * (size_t)k]); gxy.push_back(xy[2 * (size_t)k + 1]); }
+        if (idx.empty()) continue;
+        gn.assign(3 * idx.size(), 0.0);
+        s.normal_fn[g]((int)idx.size(), gxy.data(), gn.data(), s.normal_user[g]);
+        for (size_t j = 0; j < idx.size(); ++j)
+            for (int c = 0; c < 3; ++c) nrm[3 * (size_t)idx[j] + c] = gn[3 * j + c];
     }
-    for (void *e : s->evpool) if (e) (void)hipEventDestroy((hipEvent_t)e);
-    delete s;
+    HIP_TRY(hipMemcpy(const_cast<double *>(P.cb_normal), nrm.data(), nrm.size() * sizeof(double), hipMemcpyHostToDevice));
+    return RT_OK;
 }
 
-// Enqueues the kernels of one row band.  `more` = this band continues a frame whose earlier bands were enqueued by
-// the previous call(s): events, counters and ray counts then accumulate, so rt_get_stats describes the whole frame.
-static int render_rows(rt_scene *s, int w, int h, int depth, int spp, uint64_t seed, int row0, int nrows,
-                       void *d_rgba, void *d_hit_id, void *stream, bool more) {
-    if (!s) { set_error("rt_render: scene is NULL"); return RT_ERR_ARG; }
-    if (w <= 0 || h <= 0 || spp < 1 || row0 < 0 || nrows < 0 || row0 + nrows > h) {
-        set_error("rt_render: bad image size or row band"); return RT_ERR_ARG;
-    }
-    if (depth < 0) { set_error("rt_render: depth must be >= 0"); return RT_ERR_ARG; }
-    if (s->npoint > 32) { set_error("rt_render: more than 32 point lights are not supported yet"); return RT_ERR_UNSUPPORTED; }
+// Enqueues the kernels of one row band on `st`.  `more` = this band continues a frame whose earlier bands were
+// enqueued by the previous call(s): events, counters and ray counts then accumulate, so rt_get_stats describes the
+// whole frame.  `W` holds buffers of at least ws_needs(...) elements for chunks of `crow` rows; `timed` records an
+// event per kernel boundary (creates events on first use).
+int render_rows(rt_scene *s, DeviceScene &D, const Workspace &W, size_t crow, int w, int h, int depth, int spp, uint64_t seed,
+                int row0, int nrows, void *d_rgba, void *d_hit_id, hipStream_t st, bool more, bool timed) {
     int rc;
-    if ((rc = ensure_init())) return rc;
-    if ((rc = prepare(*s, w, h))) return rc;
-    if (s->mf_groups + 2 > 65535) { set_error("rt_render: more than 2 million planar leaves are not supported (16-bit block indices)"); return RT_ERR_UNSUPPORTED; }
-    hipStream_t st = stream ? (hipStream_t)stream : g_stream;
     const size_t npix = (size_t)w * (size_t)nrows;
-    if (!more) { s->last_primary = 0; s->ev_used = 0; }
-    s->last_primary += (uint64_t)npix * (uint64_t)spp;
-    s->stats_pending = false;
+    if (!more) { D.last_primary = 0; D.ev_used = 0; }
+    D.last_primary += (uint64_t)npix * (uint64_t)spp;
+    D.stats_pending = false;
+    D.last_counters = W.counters;
+    s->last_device = D.device;
+    s->multi_stats = false;
     if (npix == 0) return RT_OK;
     // bounce levels: trace n reflects at most n - 1 times (trace 0 = black, Main.hs:542); only scenes with a
     // reflective material ever spawn a reflected ray (Main.hs:553)
-    const int levels = (s->reflective && depth > 1 && !s->talk) ? (depth < 8 ? depth : 8) : 1;
-    if (s->reflective && depth > 8) { set_error("rt_render: trace depth > 8 with reflective materials is not supported"); return RT_ERR_UNSUPPORTED; }
-    // rows per chunk: a multiple of the tile height
-    size_t crow = (levels > 1 ? RT_CHUNK_PIXELS / 4 : RT_CHUNK_PIXELS) / (size_t)w;
-    crow = crow < RT_TILE_H ? RT_TILE_H : crow - crow % RT_TILE_H;
-    if (crow > (size_t)nrows) crow = (size_t)nrows;
-    const size_t cpix = crow * (size_t)w;
+    const int levels = render_levels(s, depth);
     int32_t *hit = (int32_t *)d_hit_id;
-    if (!hit || spp > 1) {
-        if ((rc = ensure(s->dev.hit_id, s->dev.hit_id_cap, npix))) return rc;
-        if (!hit) hit = s->dev.hit_id;
-    }
-    if (d_rgba) {
-        if ((rc = ensure(s->dev.hitrec, s->dev.hitrec_cap, cpix * sizeof(HitRec)))) return rc;
-        if ((rc = ensure(s->dev.lit, s->dev.lit_cap, cpix))) return rc;
-        if ((rc = ensure(s->dev.queue, s->dev.queue_cap, cpix * (size_t)(s->npoint > 0 ? s->npoint : 1)))) return rc;
-        // k_setup blocks of a chunk: 32 x 16 pixel tiles at level 0, runs of slots at the bounce levels
-        const size_t ub = std::max((size_t)((w + 31) / 32) * ((crow + RT_SETUP_THREADS / 32 - 1) / (RT_SETUP_THREADS / 32)),
-                                   (cpix + RT_SETUP_THREADS - 1) / RT_SETUP_THREADS);
-        if ((rc = ensure(s->dev.qsparse, s->dev.qsparse_cap, ub * RT_SETUP_THREADS * (size_t)(s->npoint > 0 ? s->npoint : 1)))) return rc;
-        if ((rc = ensure(s->dev.tcount, s->dev.tcount_cap, (ub + 1) * (size_t)(s->npoint > 0 ? s->npoint : 1)))) return rc;
-    }
-    if (d_rgba && levels > 1) {
-        if ((rc = ensure(s->dev.lvl_col[0], s->dev.lvl_col_cap[0], cpix))) return rc;
-        for (int k = 1; k < levels; ++k) {
-            if ((rc = ensure(s->dev.lvl_rays[k], s->dev.lvl_rays_cap[k], cpix))) return rc;
-            if ((rc = ensure(s->dev.lvl_hit[k], s->dev.lvl_hit_cap[k], cpix))) return rc;
-            if ((rc = ensure(s->dev.lvl_col[k], s->dev.lvl_col_cap[k], cpix))) return rc;
-        }
-    }
-    if (spp > 1 && d_rgba) {
-        if ((rc = ensure(s->dev.accum, s->dev.accum_cap, 3 * npix))) return rc;
-        HIP_TRY(hipMemsetAsync(s->dev.accum, 0, 3 * npix * sizeof(uint32_t), st));
-    }
-    if (!more) HIP_TRY(hipMemsetAsync(s->dev.counters, 0, RT_STAT_SLOTS * 16 * sizeof(unsigned long long), st));
+    if (!hit) hit = W.hit_id;
+    if (spp > 1 && d_rgba) HIP_TRY(hipMemsetAsync(W.accum, 0, 3 * npix * sizeof(uint32_t), st));
+    if (!more) HIP_TRY(hipMemsetAsync(W.counters, 0, RT_STAT_SLOTS * 16 * sizeof(unsigned long long), st));
 
+#ifdef RT_VALU_FILTER
     // the vector-ALU kernels are compiled for Main.hs only: a Talk.hs scene always takes the matrix-core kernels
-    const bool use_mfma = g_use_mfma || s->talk;
+    const bool use_mfma = s->opt_filter == 0 || s->talk;
+#else
+    const bool use_mfma = true;
+#endif
     RenderParams P{};
-    P.leaves = s->dev.leaves; P.aux = s->dev.aux; P.guards = s->dev.guards; P.mats = s->dev.mats; P.lights = s->dev.lights;
-    P.tri_rec = s->dev.tri_rec; P.rect_rec = s->dev.rect_rec;
-    P.tri_gid = s->dev.tri_gid; P.rect_gid = s->dev.rect_gid;
-    P.counters = s->dev.counters;
-    P.hitrec = reinterpret_cast<HitRec *>(s->dev.hitrec); P.queue = s->dev.queue; P.qcount = s->dev.qcount; P.lit = s->dev.lit;
-    P.qsparse = s->dev.qsparse; P.tcount = s->dev.tcount;
-    P.gen_tri = s->dev.gen_tri; P.gen_rect = s->dev.gen_rect;
-    P.sph_rec = s->dev.sph_rec; P.gen_sph = s->dev.gen_sph; P.sph_gid = s->dev.sph_gid; P.nsph = (int)s->sph_gid.size();
-    P.mf_rows = s->dev.mf_rows; P.mf_gid = s->dev.mf_gid; P.mf_rec = s->dev.mf_rec; P.mf_groups = s->mf_groups;
-    P.mf_cone = s->dev.mf_cone; P.cull = g_cull ? 1 : 0;
-    P.nguard_cached = (g_cull && !s->talk) ? s->guard_cached : 0;
+    P.leaves = (const LeafD *)D.leaves.p; P.aux = (const AuxD *)D.aux.p; P.guards = (const GuardD *)D.guards.p;
+    P.mats = (const MaterialD *)D.mats.p; P.lights = (const LightD *)D.lights.p;
+    P.tri_rec = (const FilterRec *)D.tri_rec.p; P.rect_rec = (const FilterRec *)D.rect_rec.p;
+    P.tri_gid = (const int32_t *)D.tri_gid.p; P.rect_gid = (const int32_t *)D.rect_gid.p;
+    P.counters = W.counters;
+    P.hitrec = reinterpret_cast<HitRec *>(W.hitrec); P.queue = W.queue; P.qcount = W.qcount; P.lit = W.lit;
+    P.qsparse = W.qsparse; P.tcount = W.tcount;
+    P.cb_slot = W.cb_slot; P.cb_xy = W.cb_xy; P.cb_group = W.cb_group; P.cb_normal = W.cb_normal; P.cb_count = W.qcount + RT_QCOUNT_CB;
+    P.gen_tri = (const GenRec *)D.gen_tri.p; P.gen_rect = (const GenRec *)D.gen_rect.p;
+    P.sph_rec = (const FilterRec *)D.sph_rec.p; P.gen_sph = (const GenRec *)D.gen_sph.p; P.sph_gid = (const int32_t *)D.sph_gid.p;
+    P.nsph = (int)s->sph_gid.size();
+    P.mf_rows = (const uint16_t *)D.mf_rows.p; P.mf_gid = (const int32_t *)D.mf_gid.p; P.mf_rec = (const FilterRec *)D.mf_rec.p;
+    P.mf_groups = s->mf_groups;
+    P.mf_cone = (const float *)D.mf_cone.p; P.cull = s->opt_cull ? 1 : 0;
+    P.nguard_cached = (s->opt_cull && !s->talk) ? s->guard_cached : 0;
     for (size_t li = 0, k = 0; li < s->lights.size() && k < 32; ++li) if (s->lights[li].kind == 0) P.point_light[k++] = (uint8_t)li;
     P.cam = fixed_camera(w, h);
     P.eps = ray_eps();
@@ -2033,14 +2175,15 @@ static int render_rows(rt_scene *s, int w, int h, int depth, int spp, uint64_t s
     P.w = w; P.h = h;
     P.talk = s->talk ? 1 : 0;
     P.spp = spp; P.seed_lo = (uint32_t)seed; P.seed_hi = (uint32_t)(seed >> 32);
+    const bool callbacks = !s->normal_fn.empty();
 
-    if ((rc = next_event(*s, st, 0))) return rc;
+    if (timed && (rc = next_event(D, st, 0))) return rc;
     for (int sample = 0; sample < spp; ++sample) {
         P.sample = sample;
         // sample 0 writes the caller's hit-ID buffer; later samples use the scratch one
-        P.hit_id = (sample == 0) ? hit : s->dev.hit_id;
+        P.hit_id = (sample == 0) ? hit : W.hit_id;
         P.rgba = (spp == 1) ? (uint8_t *)d_rgba : nullptr;
-        P.accum = (spp == 1) ? nullptr : s->dev.accum;
+        P.accum = (spp == 1) ? nullptr : W.accum;
         for (size_t r = 0; r < (size_t)nrows; r += crow) {
             const int rows = (int)((size_t)nrows - r < crow ? (size_t)nrows - r : crow);
             P.row0 = row0 + (int)r; P.nrows = rows;
@@ -2055,29 +2198,32 @@ static int render_rows(rt_scene *s, int w, int h, int depth, int spp, uint64_t s
                 HIP_TRY(hipMemsetAsync(P.hit_id + P.out_off, 0xff, (size_t)P.qcap * sizeof(int32_t), st));
             } else {
                 if (use_mfma) hipLaunchKernelGGL(k_primary_mfma, dim3(tblocks), dim3(RT_WAVES_PER_BLOCK * 64), 0, st, P);
+#ifdef RT_VALU_FILTER
                 else if (spp == 1) hipLaunchKernelGGL(k_primary<true>, dim3(tblocks), dim3(RT_WAVES_PER_BLOCK * 64), 0, st, P);
                 else hipLaunchKernelGGL(k_primary<false>, dim3(tblocks), dim3(RT_WAVES_PER_BLOCK * 64), 0, st, P);
+#endif
             }
-            if ((rc = next_event(*s, st, 1))) return rc;
+            if (timed && (rc = next_event(D, st, 1))) return rc;
             if (!d_rgba) continue;
             const unsigned sblocks = (unsigned)(((size_t)P.qcap + 256 * RT_WAVES_PER_BLOCK - 1) / (256 * RT_WAVES_PER_BLOCK));
             int32_t *const hit0 = P.hit_id;
             const long long off0 = P.out_off;
             uint8_t *const rgba0 = P.rgba;
             uint32_t *const accum0 = P.accum;
-            unsigned *const lvl_count = s->dev.qcount + 32;
-            HIP_TRY(hipMemsetAsync(s->dev.qcount, 0, 64 * sizeof(unsigned), st));
+            unsigned *const lvl_count = W.qcount + 32;
+            HIP_TRY(hipMemsetAsync(W.qcount, 0, RT_QCOUNT_WORDS * sizeof(unsigned), st));
             for (int lvl = 0; lvl < levels; ++lvl) {
                 if (lvl > 0) {      // trace (n-1) lights world reflected, Main.hs:554
-                    HIP_TRY(hipMemsetAsync(s->dev.qcount, 0, 32 * sizeof(unsigned), st));
-                    P.rays = s->dev.lvl_rays[lvl]; P.count_ptr = lvl_count + lvl;
-                    P.hit_id = s->dev.lvl_hit[lvl]; P.out_off = 0;
+                    HIP_TRY(hipMemsetAsync(W.qcount, 0, 32 * sizeof(unsigned), st));
+                    P.rays = W.lvl_rays[lvl]; P.count_ptr = lvl_count + lvl;
+                    P.hit_id = W.lvl_hit[lvl]; P.out_off = 0;
                     hipLaunchKernelGGL(k_general, dim3(sblocks), dim3(RT_WAVES_PER_BLOCK * 64), 0, st, P);
-                    if ((rc = next_event(*s, st, 1))) return rc;
+                    if (timed && (rc = next_event(D, st, 1))) return rc;
                 }
-                P.next_rays = (lvl + 1 < levels) ? s->dev.lvl_rays[lvl + 1] : nullptr;
+                P.next_rays = (lvl + 1 < levels) ? W.lvl_rays[lvl + 1] : nullptr;
                 P.next_count = lvl_count + lvl + 1;
-                P.colour = (levels > 1) ? s->dev.lvl_col[lvl] : nullptr;
+                P.colour = (levels > 1) ? W.lvl_col[lvl] : nullptr;
+                if (callbacks && (rc = run_normal_callbacks(*s, P, st, pblocks))) return rc;
                 const unsigned ublocks = lvl == 0 ? (unsigned)P.tiles_x * (unsigned)((rows + RT_SETUP_THREADS / 32 - 1) / (RT_SETUP_THREADS / 32))
                                                   : (unsigned)(((size_t)P.qcap + RT_SETUP_THREADS - 1) / RT_SETUP_THREADS);
                 P.setup_blocks = (int)ublocks;
@@ -2086,59 +2232,141 @@ static int render_rows(rt_scene *s, int w, int h, int depth, int spp, uint64_t s
                     hipLaunchKernelGGL(k_queue_offsets, dim3((unsigned)s->npoint), dim3(1024), 0, st, P);
                     hipLaunchKernelGGL(k_queue_compact, dim3(ublocks, (unsigned)s->npoint), dim3(RT_SETUP_THREADS), 0, st, P);
                 }
-                if ((rc = next_event(*s, st, 2))) return rc;
+                if (timed && (rc = next_event(D, st, 2))) return rc;
                 if (s->npoint > 0) {
                     if (use_mfma) hipLaunchKernelGGL(k_shadow_mfma, dim3(sblocks, (unsigned)s->npoint), dim3(RT_WAVES_PER_BLOCK * 64), 0, st, P);
+#ifdef RT_VALU_FILTER
                     else hipLaunchKernelGGL(k_shadow, dim3(sblocks, (unsigned)s->npoint), dim3(RT_WAVES_PER_BLOCK * 64), 0, st, P);
+#endif
                 }
-                if ((rc = next_event(*s, st, 3))) return rc;
+                if (timed && (rc = next_event(D, st, 3))) return rc;
                 hipLaunchKernelGGL(k_final, dim3(lvl == 0 ? (unsigned)P.tiles_x * (unsigned)((rows + 7) / 8) : pblocks), dim3(256), 0, st, P);
-                if ((rc = next_event(*s, st, 4))) return rc;
+                if (timed && (rc = next_event(D, st, 4))) return rc;
             }
             P.rays = nullptr; P.count_ptr = nullptr; P.next_rays = nullptr; P.hit_id = hit0; P.out_off = off0;
             if (levels > 1) {       // fold the levels back: direct `addPixelRGB8` scaled reflection, deepest first
                 for (int lvl = levels - 1; lvl >= 1; --lvl)
-                    hipLaunchKernelGGL(k_combine, dim3(pblocks), dim3(256), 0, st, s->dev.lvl_rays[lvl], s->dev.lvl_col[lvl],
-                                       lvl_count + lvl, (unsigned)P.qcap, s->dev.lvl_col[lvl - 1]);
-                P.colour = s->dev.lvl_col[0]; P.rgba = rgba0; P.accum = accum0;
+                    hipLaunchKernelGGL(k_combine, dim3(pblocks), dim3(256), 0, st, W.lvl_rays[lvl], W.lvl_col[lvl],
+                                       lvl_count + lvl, (unsigned)P.qcap, W.lvl_col[lvl - 1]);
+                P.colour = W.lvl_col[0]; P.rgba = rgba0; P.accum = accum0;
                 hipLaunchKernelGGL(k_store, dim3(pblocks), dim3(256), 0, st, P);
                 P.colour = nullptr;
-                if ((rc = next_event(*s, st, 4))) return rc;
+                if (timed && (rc = next_event(D, st, 4))) return rc;
             }
         }
     }
     if (d_rgba && spp > 1) {
         hipLaunchKernelGGL(k_resolve, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st,
-                           s->dev.accum, (uint8_t *)d_rgba, npix, (uint32_t)spp);
-        if ((rc = next_event(*s, st, 4))) return rc;
+                           W.accum, (uint8_t *)d_rgba, npix, (uint32_t)spp);
+        if (timed && (rc = next_event(D, st, 4))) return rc;
     }
     HIP_TRY(hipGetLastError());
-    s->stats_pending = true;
+    D.stats_pending = true;
     return RT_OK;
+}
+
+int check_render_args(const rt_scene *s, int w, int h, int depth, int spp, int row0, int nrows) {
+    if (!s) { set_error("rt_render: scene is NULL"); return RT_ERR_ARG; }
+    if (w <= 0 || h <= 0 || spp < 1 || row0 < 0 || nrows < 0 || row0 + nrows > h) {
+        set_error("rt_render: bad image size or row band"); return RT_ERR_ARG;
+    }
+    if (depth < 0) { set_error("rt_render: depth must be >= 0"); return RT_ERR_ARG; }
+    if (s->npoint > 32) { set_error("rt_render: more than 32 point lights are not supported yet"); return RT_ERR_UNSUPPORTED; }
+    return RT_OK;
+}
+// chunk rows of the growing-workspace renders: a multiple of the tile height
+size_t chunk_rows(int w, int nrows, int levels) {
+    // a bounce level keeps 72 bytes per slot: a quarter of the pixels for up to 8 levels, fewer beyond
+    const size_t pixels = levels > 1 ? std::min<size_t>(RT_CHUNK_PIXELS / 4, 2 * RT_CHUNK_PIXELS / (size_t)levels) : RT_CHUNK_PIXELS;
+    size_t crow = pixels / (size_t)w;
+    crow = crow < RT_TILE_H ? RT_TILE_H : crow - crow % RT_TILE_H;
+    if (crow > (size_t)nrows) crow = (size_t)nrows;
+    return crow ? crow : 1;
+}
+
+// rt_render_device on the growing workspace of the (scene, device) pair
+int render_band(rt_scene *s, int device, int w, int h, int depth, int spp, uint64_t seed, int row0, int nrows,
+                void *d_rgba, void *d_hit_id, hipStream_t st, bool more) {
+    int rc;
+    DeviceScene &D = s->dev[device];
+    if ((rc = device_prepare(*s, D, device, w, h))) return rc;
+    if (!levels_supported(s, depth)) return RT_ERR_UNSUPPORTED;
+    const int levels = render_levels(s, depth);
+    const size_t crow = chunk_rows(w, nrows, levels);
+    const WsNeeds need = ws_needs(w, nrows, crow, s->npoint, levels, spp, d_hit_id == nullptr, d_rgba != nullptr, !s->normal_fn.empty());
+    if ((rc = ws_grow(D, need))) return rc;
+    return render_rows(s, D, D.ws, crow, w, h, depth, spp, seed, row0, nrows, d_rgba, d_hit_id, st ? st : (hipStream_t)D.stream, more, true);
+}
+
+} // namespace
+
+extern "C" {
+
+int rt_init(int device) { return device_init(device); }
+
+int rt_scene_prepare_device(rt_scene *s, int w, int h) {
+    if (!s || w <= 0 || h <= 0) { set_error("rt_scene_prepare_device: bad argument"); return RT_ERR_ARG; }
+    int rc;
+    if ((rc = enter())) return rc;
+    return device_prepare(*s, s->dev[t_device], t_device, w, h);
+}
+
+void rt_scene_destroy(rt_scene *s) {
+    if (!s) return;
+    int cur = -1;
+    (void)hipGetDevice(&cur);
+    for (DeviceScene &d : s->dev) {
+        if (d.device < 0) continue;
+        if (hipSetDevice(d.device) != hipSuccess) continue;
+        if (d.stream) (void)hipStreamSynchronize((hipStream_t)d.stream);
+        if (d.copy_stream) (void)hipStreamSynchronize((hipStream_t)d.copy_stream);
+        DevBuf *bufs[] = {&d.leaves, &d.aux, &d.guards, &d.mats, &d.lights, &d.tri_rec, &d.rect_rec, &d.tri_gid, &d.rect_gid,
+                          &d.sph_rec, &d.gen_sph, &d.sph_gid, &d.mf_rows, &d.mf_gid, &d.mf_cone, &d.mf_rec, &d.gen_tri, &d.gen_rect};
+        for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
+        Workspace &W = d.ws;
+        void *ptrs[] = {W.counters, W.qcount, W.hit_id, W.accum, W.hitrec, W.queue, W.qsparse, W.tcount, W.lit,
+                        W.cb_slot, W.cb_xy, W.cb_group, W.cb_normal, d.rgba, d.hit_out, d.stage_rgba, d.stage_hit};
+        for (void *p : ptrs) if (p) (void)hipFree(p);
+        for (int k = 0; k < RT_MAX_LEVELS; ++k) {
+            if (W.lvl_rays[k]) (void)hipFree(W.lvl_rays[k]);
+            if (W.lvl_hit[k]) (void)hipFree(W.lvl_hit[k]);
+            if (W.lvl_col[k]) (void)hipFree(W.lvl_col[k]);
+        }
+        for (void *e : d.evpool) if (e) (void)hipEventDestroy((hipEvent_t)e);
+        for (void *e : d.band_done) if (e) (void)hipEventDestroy((hipEvent_t)e);
+        if (d.stream) (void)hipStreamDestroy((hipStream_t)d.stream);
+        if (d.copy_stream) (void)hipStreamDestroy((hipStream_t)d.copy_stream);
+        if (d.copy_stream2) (void)hipStreamDestroy((hipStream_t)d.copy_stream2);
+    }
+    if (cur >= 0) (void)hipSetDevice(cur);
+    delete s;
 }
 
 int rt_render_device(rt_scene *s, int w, int h, int depth, int spp, uint64_t seed, int row0, int nrows,
                      void *d_rgba, void *d_hit_id, void *stream) {
-    return render_rows(s, w, h, depth, spp, seed, row0, nrows, d_rgba, d_hit_id, stream, false);
+    int rc;
+    if ((rc = check_render_args(s, w, h, depth, spp, row0, nrows))) return rc;
+    if ((rc = enter())) return rc;
+    return render_band(s, t_device, w, h, depth, spp, seed, row0, nrows, d_rgba, d_hit_id, (hipStream_t)stream, false);
 }
 
 int rt_render(rt_scene *s, int w, int h, int depth, int spp, uint64_t seed, int row0, int nrows,
               uint8_t *rgba_out, int32_t *hit_id_out) {
-    if (!s) { set_error("rt_render: scene is NULL"); return RT_ERR_ARG; }
-    if (w <= 0 || h <= 0 || nrows < 0 || row0 < 0 || row0 + nrows > h) { set_error("rt_render: bad image size or row band"); return RT_ERR_ARG; }
-    if (s->npoint > 32) { set_error("rt_render: more than 32 point lights are not supported yet"); return RT_ERR_UNSUPPORTED; }
     int rc;
-    if ((rc = ensure_init())) return rc;
+    if ((rc = check_render_args(s, w, h, depth, spp, row0, nrows))) return rc;
+    if ((rc = enter())) return rc;
+    DeviceScene &D = s->dev[t_device];
     const size_t npix = (size_t)w * (size_t)nrows;
     if (npix == 0) return RT_OK;
-    if ((rc = ensure(s->dev.rgba, s->dev.rgba_cap, 4 * npix))) return rc;
-    if ((rc = ensure(s->dev.hit_out, s->dev.hit_out_cap, npix))) return rc;
+    if ((rc = device_prepare(*s, D, t_device, w, h))) return rc;
+    if ((rc = ensure(D.rgba, D.rgba_cap, 4 * npix))) return rc;
+    if ((rc = ensure(D.hit_out, D.hit_out_cap, npix))) return rc;
+    hipStream_t st = (hipStream_t)D.stream, cst = (hipStream_t)D.copy_stream;
     // The frame is enqueued as up to RT_HOST_BANDS_MAX row bands of at least ~2 Mi pixels; band k's copy to the
     // caller's memory runs on its own stream behind the render of band k+1, so only the last band's copy is exposed.
     // Into rt_host_alloc'ed (page-locked) memory the copies are DMA at PCIe rate; into pageable memory they stage
     // through the runtime's bounce buffers and block this thread, which is why every band is enqueued first.
-    int nb = (int)(npix >> 21);
-    if (const char *e = getenv("RT_HOST_BANDS")) nb = atoi(e);
+    int nb = s->opt_host_bands > 0 ? s->opt_host_bands : (int)(npix >> 21);
     nb = nb < 1 ? 1 : (nb > RT_HOST_BANDS_MAX ? RT_HOST_BANDS_MAX : nb);
     int brows = (nrows + nb - 1) / nb;
     brows = (brows + RT_TILE_H - 1) / RT_TILE_H * RT_TILE_H;
@@ -2146,28 +2374,28 @@ int rt_render(rt_scene *s, int w, int h, int depth, int spp, uint64_t seed, int 
     for (int r = 0; r < nrows && rc == RT_OK; r += brows, ++used) {
         const int rows = nrows - r < brows ? nrows - r : brows;
         const size_t off = (size_t)r * (size_t)w;
-        rc = render_rows(s, w, h, depth, spp, seed, row0 + r, rows, rgba_out ? s->dev.rgba + 4 * off : nullptr,
-                         s->dev.hit_out + off, g_stream, r > 0);
-        if (rc == RT_OK && !hip_ok(hipEventRecord(g_band_done[used], g_stream), "hipEventRecord")) rc = RT_ERR_HIP;
+        rc = render_band(s, t_device, w, h, depth, spp, seed, row0 + r, rows, rgba_out ? D.rgba + 4 * off : nullptr,
+                         D.hit_out + off, st, r > 0);
+        if (rc == RT_OK && !hip_ok(hipEventRecord((hipEvent_t)D.band_done[used], st), "hipEventRecord")) rc = RT_ERR_HIP;
     }
     int band = 0;
     for (int r = 0; r < nrows && rc == RT_OK; r += brows, ++band) {
         const int rows = nrows - r < brows ? nrows - r : brows;
         const size_t off = (size_t)r * (size_t)w, n = (size_t)rows * (size_t)w;
-        if (!hip_ok(hipStreamWaitEvent(g_copy_stream, g_band_done[band], 0), "hipStreamWaitEvent")) { rc = RT_ERR_HIP; break; }
-        if (rgba_out && !hip_ok(hipMemcpyAsync(rgba_out + 4 * off, s->dev.rgba + 4 * off, 4 * n, hipMemcpyDeviceToHost, g_copy_stream), "hipMemcpyAsync")) rc = RT_ERR_HIP;
-        if (rc == RT_OK && hit_id_out && !hip_ok(hipMemcpyAsync(hit_id_out + off, s->dev.hit_out + off, n * sizeof(int32_t), hipMemcpyDeviceToHost, g_copy_stream), "hipMemcpyAsync")) rc = RT_ERR_HIP;
+        if (!hip_ok(hipStreamWaitEvent(cst, (hipEvent_t)D.band_done[band], 0), "hipStreamWaitEvent")) { rc = RT_ERR_HIP; break; }
+        if (rgba_out && !hip_ok(hipMemcpyAsync(rgba_out + 4 * off, D.rgba + 4 * off, 4 * n, hipMemcpyDeviceToHost, cst), "hipMemcpyAsync")) rc = RT_ERR_HIP;
+        if (rc == RT_OK && hit_id_out && !hip_ok(hipMemcpyAsync(hit_id_out + off, D.hit_out + off, n * sizeof(int32_t), hipMemcpyDeviceToHost, cst), "hipMemcpyAsync")) rc = RT_ERR_HIP;
     }
     // always drain both streams, also after an error: nothing may still be writing the caller's buffers on return
-    if (!hip_ok(hipStreamSynchronize(g_copy_stream), "hipStreamSynchronize") && rc == RT_OK) rc = RT_ERR_HIP;
-    if (!hip_ok(hipStreamSynchronize(g_stream), "hipStreamSynchronize") && rc == RT_OK) rc = RT_ERR_HIP;
+    if (!hip_ok(hipStreamSynchronize(cst), "hipStreamSynchronize") && rc == RT_OK) rc = RT_ERR_HIP;
+    if (!hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize") && rc == RT_OK) rc = RT_ERR_HIP;
     return rc;
 }
 
 void *rt_host_alloc(size_t bytes) {
-    if (ensure_init() != RT_OK) return nullptr;
+    if (enter() != RT_OK) return nullptr;
     void *p = nullptr;
-    if (!hip_ok(hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault), "hipHostMalloc")) return nullptr;
+    if (!hip_ok(hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable), "hipHostMalloc")) return nullptr;
     return p;
 }
 
@@ -2176,44 +2404,255 @@ void rt_host_free(void *p) {
 }
 
 int rt_synchronize(void) {
-    if (g_device < 0) return RT_OK;
-    HIP_TRY(hipStreamSynchronize(g_stream));
-    return RT_OK;
-}
-
-int rt_get_stats(rt_scene *s, rt_stats *out) {
-    if (!s || !out) { set_error("rt_get_stats: NULL argument"); return RT_ERR_ARG; }
-    if (s->stats_pending && s->ev_used > 0) {
-        HIP_TRY(hipEventSynchronize((hipEvent_t)s->evpool[s->ev_used - 1]));
-        static thread_local std::vector<unsigned long long> all(RT_STAT_SLOTS * 16);
-        HIP_TRY(hipMemcpy(all.data(), s->dev.counters, all.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-        unsigned long long c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int slot = 0; slot < RT_STAT_SLOTS; ++slot) for (int k = 0; k < 8; ++k) c[k] += all[(size_t)slot * 16 + k];
-        double ms[5] = {0, 0, 0, 0, 0};
-        for (int i = 1; i < s->ev_used; ++i) {
-            float t = 0;
-            HIP_TRY(hipEventElapsedTime(&t, (hipEvent_t)s->evpool[i - 1], (hipEvent_t)s->evpool[i]));
-            ms[s->evkind[i]] += t;
-        }
-        float tot = 0;
-        HIP_TRY(hipEventElapsedTime(&tot, (hipEvent_t)s->evpool[0], (hipEvent_t)s->evpool[s->ev_used - 1]));
-        rt_stats st{};
-        st.primary_rays = s->last_primary;
-        st.shadow_rays = c[0];
-        st.tri_tests = (st.primary_rays + st.shadow_rays) * (uint64_t)s->tri_gid.size();
-        st.rect_tests = (st.primary_rays + st.shadow_rays) * (uint64_t)s->rect_gid.size();
-        st.exact_evals = c[1] + c[2];
-        st.mfma_blocks_primary = c[6];
-        st.mfma_blocks_shadow = c[7];
-#ifdef RT_COUNT_EVENTS
-        fprintf(stderr, "[rt] primary: true hits among the exact evaluations %llu, FP32 record tests %llu; exact evals primary %llu shadow %llu\n", c[3], c[4], c[1], c[2]);
-#endif
-        st.ms_primary = ms[1]; st.ms_setup = ms[2]; st.ms_shadow = ms[3]; st.ms_final = ms[4]; st.ms_total = tot;
-        s->stats = st;
-        s->stats_pending = false;
-    }
-    *out = s->stats;
+    if (t_device < 0) return RT_OK;
+    int rc;
+    if ((rc = enter())) return rc;
+    HIP_TRY(hipDeviceSynchronize());
     return RT_OK;
 }
 
 } // extern "C"
+
+namespace {
+// statistics of the last render of the (scene, device) pair; synchronises with it
+int device_stats(rt_scene *s, DeviceScene &D, rt_stats *out) {
+    if (D.stats_pending) {
+        static thread_local std::vector<unsigned long long> all(RT_STAT_SLOTS * 16);
+        if (D.ev_used > 0) HIP_TRY(hipEventSynchronize((hipEvent_t)D.evpool[D.ev_used - 1]));
+        else HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(all.data(), D.last_counters, all.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        unsigned long long c[16] = {0};
+        for (int slot = 0; slot < RT_STAT_SLOTS; ++slot) for (int k = 0; k < 16; ++k) c[k] += all[(size_t)slot * 16 + k];
+        double ms[5] = {0, 0, 0, 0, 0};
+        for (int i = 1; i < D.ev_used; ++i) {
+            float t = 0;
+            HIP_TRY(hipEventElapsedTime(&t, (hipEvent_t)D.evpool[i - 1], (hipEvent_t)D.evpool[i]));
+            ms[D.evkind[i]] += t;
+        }
+        float tot = 0;
+        if (D.ev_used > 1) HIP_TRY(hipEventElapsedTime(&tot, (hipEvent_t)D.evpool[0], (hipEvent_t)D.evpool[D.ev_used - 1]));
+        rt_stats st{};
+        st.primary_rays = D.last_primary;
+        st.shadow_rays = c[0];
+        st.bounce_rays = c[5];
+        const uint64_t rays = st.primary_rays + st.shadow_rays + st.bounce_rays;
+        st.tri_pairs = rays * (uint64_t)s->tri_gid.size();
+        st.rect_pairs = rays * (uint64_t)s->rect_gid.size();
+        st.exact_evals = c[1] + c[2];
+        st.record_tests = c[4];
+        st.mfma_blocks_primary = c[6];
+        st.mfma_blocks_shadow = c[7];
+#ifdef RT_COUNT_EVENTS
+        fprintf(stderr, "[rt] primary: true hits among the exact evaluations %llu; exact evals primary %llu shadow %llu\n", c[3], c[1], c[2]);
+#endif
+        st.ms_primary = ms[1]; st.ms_setup = ms[2]; st.ms_shadow = ms[3]; st.ms_final = ms[4]; st.ms_total = tot;
+        st.upload_ms = D.stats.upload_ms;
+        D.stats = st;
+        D.stats_pending = false;
+    }
+    *out = D.stats;
+    out->prepare_ms = s->prepare_ms;
+    return RT_OK;
+}
+} // namespace
+
+extern "C" int rt_get_stats(rt_scene *s, rt_stats *out) {
+    if (!s || !out) { set_error("rt_get_stats: NULL argument"); return RT_ERR_ARG; }
+    if (s->multi_stats) { *out = s->stats_multi; return RT_OK; }
+    int rc;
+    if ((rc = enter())) return rc;
+    const int dev = s->last_device >= 0 ? s->last_device : t_device;
+    if (dev != t_device) HIP_TRY(hipSetDevice(dev));
+    rc = device_stats(s, s->dev[dev], out);
+    if (dev != t_device) (void)hipSetDevice(t_device);
+    return rc;
+}
+
+namespace {
+
+// Relative cost of `ncost` equal horizontal strips of the w x h frame, measured: the strips are rendered one by one at
+// a reduced scale (a quarter or half the width and height while a strip keeps >= 256 Ki pixels, else full scale) and
+// timed with HIP events, the better of two passes.  The bands of a multi-GPU render are cut from this (split_rows).
+int row_costs(rt_scene *s, int device, int w, int h, int depth, int spp, int ncost, double *cost) {
+    int q = 4;
+    while (q > 1 && ((size_t)(w / q) * (size_t)(h / q)) / (size_t)ncost < (256u << 10)) q >>= 1;
+    const int sw = std::max(1, w / q), sh = std::max(ncost, h / q);
+    int rc;
+    DeviceScene &D = s->dev[device];
+    if ((rc = device_prepare(*s, D, device, sw, sh))) return rc;
+    const int maxrows = (sh + ncost - 1) / ncost + 1;
+    if ((rc = ensure(D.stage_rgba, D.stage_rgba_cap, 4 * (size_t)sw * (size_t)maxrows))) return rc;
+    for (int k = 0; k < ncost; ++k) cost[k] = 1e300;
+    for (int pass = 0; pass < 2; ++pass)
+        for (int k = 0; k < ncost; ++k) {
+            const int r0 = (int)((long long)sh * k / ncost), r1 = (int)((long long)sh * (k + 1) / ncost);
+            if (r1 <= r0) { cost[k] = 0; continue; }
+            if ((rc = render_band(s, device, sw, sh, depth, spp, 0, r0, r1 - r0, D.stage_rgba, nullptr, (hipStream_t)D.stream, false))) return rc;
+            rt_stats st;
+            if ((rc = device_stats(s, D, &st))) return rc;
+            cost[k] = std::min(cost[k], st.ms_total);
+        }
+    return RT_OK;
+}
+
+void sub_bands(int r0, int nr, int parts, int align, int *p0, int *pn) {   // port of raytrace_amd/distributed.py: sub_bands
+    const int units = (nr + align - 1) / align;
+    int done = 0;
+    for (int k = 0; k < parts; ++k) {
+        const int upto = k + 1 < parts ? std::min(nr, (int)((long long)units * (k + 1) / parts) * align) : nr;
+        p0[k] = r0 + done; pn[k] = upto - done;
+        done = upto;
+    }
+}
+
+} // namespace
+
+extern "C" int rt_scene_row_costs(rt_scene *s, int w, int h, int depth, int spp, int ncost, double *cost) {
+    int rc;
+    if ((rc = check_render_args(s, w, h, depth, spp, 0, h))) return rc;
+    if (!cost || ncost < 1 || ncost > h) { set_error("rt_scene_row_costs: bad argument"); return RT_ERR_ARG; }
+    if ((rc = enter())) return rc;
+    return row_costs(s, t_device, w, h, depth, spp, ncost, cost);
+}
+
+extern "C" int rt_render_multi(rt_scene *s, int w, int h, int depth, int spp, uint64_t seed, int ngpus, const int *devices,
+                               uint8_t *rgba_out, int32_t *hit_id_out) {
+    int rc;
+    if ((rc = check_render_args(s, w, h, depth, spp, 0, h))) return rc;
+    if (ngpus < 1 || ngpus > RT_MAX_DEVICES) { set_error("rt_render_multi: ngpus must be between 1 and 16"); return RT_ERR_ARG; }
+    int ndev = 0;
+    if (!hip_ok(hipGetDeviceCount(&ndev), "hipGetDeviceCount") || ndev <= 0) {
+        set_error("rt_render_multi: no HIP device available (this library has no CPU fallback)"); return RT_ERR_HIP;
+    }
+    int devs[RT_MAX_DEVICES];
+    for (int k = 0; k < ngpus; ++k) {
+        devs[k] = devices ? devices[k] : k;
+        if (devs[k] < 0 || devs[k] >= ndev || devs[k] >= RT_MAX_DEVICES) { set_error("rt_render_multi: device index out of range"); return RT_ERR_ARG; }
+    }
+    const int caller = t_device, home = devs[0];
+    const size_t npix = (size_t)w * (size_t)h;
+    constexpr int PIECES = 4;
+    struct Band { int dev, row0, nrows; size_t stage_off; bool staged; int p0[PIECES], pn[PIECES]; };
+    Band band[RT_MAX_DEVICES];
+    std::vector<hipEvent_t> ev;            // per (band, piece): rendered, arrived on the home device
+    bool first_on[RT_MAX_DEVICES];
+    for (bool &f : first_on) f = true;
+    auto finish = [&](int code) {          // drain every stream that was used, restore the caller's device
+        for (int k = 0; k < ngpus; ++k) {
+            DeviceScene &D = s->dev[devs[k]];
+            if (hipSetDevice(devs[k]) != hipSuccess) continue;
+            if (D.stream && !hip_ok(hipStreamSynchronize((hipStream_t)D.stream), "hipStreamSynchronize") && code == RT_OK) code = RT_ERR_HIP;
+            if (D.copy_stream && !hip_ok(hipStreamSynchronize((hipStream_t)D.copy_stream), "hipStreamSynchronize") && code == RT_OK) code = RT_ERR_HIP;
+        }
+        for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+        if (caller >= 0) (void)hipSetDevice(caller);
+        t_device = caller;
+        return code;
+    };
+    if ((rc = device_init(home))) return finish(rc);
+    DeviceScene &H = s->dev[home];
+    if ((rc = device_prepare(*s, H, home, w, h))) return finish(rc);
+    // 1. bands of about equal measured cost
+    int b0[RT_MAX_DEVICES] = {0}, bn[RT_MAX_DEVICES] = {h};
+    if (ngpus > 1) {
+        const int ncost = std::min(32, std::max(1, h / 8));
+        if (s->multi_cost.size() != (size_t)ncost || s->multi_cost_key[0] != s->version || s->multi_cost_key[1] != (uint64_t)w ||
+            s->multi_cost_key[2] != (uint64_t)h || s->multi_cost_key[3] != (uint64_t)depth || s->multi_cost_key[4] != (uint64_t)spp) {
+            s->multi_cost.assign(ncost, 1.0);
+            if ((rc = row_costs(s, home, w, h, depth, spp, ncost, s->multi_cost.data()))) return finish(rc);
+            if ((rc = device_prepare(*s, H, home, w, h))) return finish(rc);
+            const uint64_t key[5] = {s->version, (uint64_t)w, (uint64_t)h, (uint64_t)depth, (uint64_t)spp};
+            std::copy(key, key + 5, s->multi_cost_key);
+        }
+        split_rows(s->multi_cost.data(), ncost, h, ngpus, RT_TILE_H, b0, bn);
+    }
+    // 2. buffers: the whole frame on the home device, a staging buffer per other device
+    if (rgba_out && (rc = ensure(H.rgba, H.rgba_cap, 4 * npix))) return finish(rc);
+    if ((rc = ensure(H.hit_out, H.hit_out_cap, npix))) return finish(rc);
+    size_t stage_pix[RT_MAX_DEVICES] = {0};
+    for (int k = 0; k < ngpus; ++k) {
+        Band &B = band[k];
+        B.dev = devs[k]; B.row0 = b0[k]; B.nrows = bn[k];
+        B.staged = B.dev != home || s->opt_multi_stage;
+        B.stage_off = stage_pix[B.dev];
+        if (B.staged) stage_pix[B.dev] += (size_t)w * (size_t)B.nrows;
+        sub_bands(B.row0, B.nrows, PIECES, RT_TILE_H, B.p0, B.pn);
+    }
+    for (int k = 0; k < ngpus; ++k) {
+        const int d = devs[k];
+        if (!stage_pix[d]) continue;
+        if ((rc = device_init(d))) return finish(rc);
+        DeviceScene &D = s->dev[d];
+        if ((rc = device_prepare(*s, D, d, w, h))) return finish(rc);
+        if (rgba_out && (rc = ensure(D.stage_rgba, D.stage_rgba_cap, 4 * stage_pix[d]))) return finish(rc);
+        if ((rc = ensure(D.stage_hit, D.stage_hit_cap, stage_pix[d]))) return finish(rc);
+        if (d != home) {                  // direct xGMI copies into the home device's memory
+            const hipError_t e = hipDeviceEnablePeerAccess(home, 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();   // falls back to staged copies
+            else (void)hipGetLastError();
+        }
+    }
+    // 3. piece p of every band is enqueued before piece p + 1 of any: all devices work at once, and a piece travels to
+    // the home device (peer-to-peer over xGMI, on the band's copy stream) while the next one renders
+    ev.assign((size_t)ngpus * PIECES * 2, nullptr);
+    for (int p = 0; p < PIECES; ++p)
+        for (int k = 0; k < ngpus; ++k) {
+            Band &B = band[k];
+            if (B.pn[p] <= 0) continue;
+            if ((rc = device_init(B.dev))) return finish(rc);
+            DeviceScene &D = s->dev[B.dev];
+            const size_t foff = (size_t)B.p0[p] * (size_t)w, n = (size_t)B.pn[p] * (size_t)w;
+            const size_t soff = B.stage_off + (size_t)(B.p0[p] - B.row0) * (size_t)w;
+            uint8_t *dst = !rgba_out ? nullptr : (B.staged ? D.stage_rgba + 4 * soff : H.rgba + 4 * foff);
+            int32_t *dhit = B.staged ? D.stage_hit + soff : H.hit_out + foff;
+            if ((rc = render_band(s, B.dev, w, h, depth, spp, seed, B.p0[p], B.pn[p], dst, dhit, (hipStream_t)D.stream, !first_on[B.dev]))) return finish(rc);
+            first_on[B.dev] = false;
+            hipEvent_t &er = ev[((size_t)k * PIECES + p) * 2], &ea = ev[((size_t)k * PIECES + p) * 2 + 1];
+            if (!hip_ok(hipEventCreateWithFlags(&er, hipEventDisableTiming), "hipEventCreate") ||
+                !hip_ok(hipEventRecord(er, (hipStream_t)D.stream), "hipEventRecord")) return finish(RT_ERR_HIP);
+            if (B.staged) {
+                hipStream_t cs = (hipStream_t)D.copy_stream;
+                if (!hip_ok(hipStreamWaitEvent(cs, er, 0), "hipStreamWaitEvent")) return finish(RT_ERR_HIP);
+                if (rgba_out && !hip_ok(hipMemcpyPeerAsync(H.rgba + 4 * foff, home, dst, B.dev, 4 * n, cs), "hipMemcpyPeerAsync")) return finish(RT_ERR_HIP);
+                if (!hip_ok(hipMemcpyPeerAsync(H.hit_out + foff, home, dhit, B.dev, n * sizeof(int32_t), cs), "hipMemcpyPeerAsync")) return finish(RT_ERR_HIP);
+                if (!hip_ok(hipEventCreateWithFlags(&ea, hipEventDisableTiming), "hipEventCreate") ||
+                    !hip_ok(hipEventRecord(ea, cs), "hipEventRecord")) return finish(RT_ERR_HIP);
+            }
+        }
+    // 4. from the home device to the caller's memory, piece by piece as they arrive
+    if ((rc = device_init(home))) return finish(rc);
+    for (int p = 0; p < PIECES; ++p)
+        for (int k = 0; k < ngpus; ++k) {
+            const Band &B = band[k];
+            if (B.pn[p] <= 0) continue;
+            const size_t foff = (size_t)B.p0[p] * (size_t)w, n = (size_t)B.pn[p] * (size_t)w;
+            hipEvent_t arrived = ev[((size_t)k * PIECES + p) * 2 + (B.staged ? 1 : 0)];
+            hipStream_t cs = (hipStream_t)H.copy_stream2;
+            if (!hip_ok(hipStreamWaitEvent(cs, arrived, 0), "hipStreamWaitEvent")) return finish(RT_ERR_HIP);
+            if (rgba_out && !hip_ok(hipMemcpyAsync(rgba_out + 4 * foff, H.rgba + 4 * foff, 4 * n, hipMemcpyDeviceToHost, cs), "hipMemcpyAsync")) return finish(RT_ERR_HIP);
+            if (hit_id_out && !hip_ok(hipMemcpyAsync(hit_id_out + foff, H.hit_out + foff, n * sizeof(int32_t), hipMemcpyDeviceToHost, cs), "hipMemcpyAsync")) return finish(RT_ERR_HIP);
+        }
+    if (!hip_ok(hipStreamSynchronize((hipStream_t)H.copy_stream2), "hipStreamSynchronize")) return finish(RT_ERR_HIP);
+    if ((rc = finish(RT_OK))) return rc;
+    // 5. statistics of the whole frame: counts summed over the devices, times = the slowest device
+    rt_stats tot{};
+    bool seen[RT_MAX_DEVICES] = {false};
+    for (int k = 0; k < ngpus; ++k) {
+        const int d = devs[k];
+        if (seen[d] || first_on[d]) continue;
+        seen[d] = true;
+        rt_stats st;
+        if (hipSetDevice(d) != hipSuccess || device_stats(s, s->dev[d], &st) != RT_OK) continue;
+        tot.primary_rays += st.primary_rays; tot.shadow_rays += st.shadow_rays; tot.bounce_rays += st.bounce_rays;
+        tot.tri_pairs += st.tri_pairs; tot.rect_pairs += st.rect_pairs; tot.exact_evals += st.exact_evals;
+        tot.record_tests += st.record_tests; tot.mfma_blocks_primary += st.mfma_blocks_primary; tot.mfma_blocks_shadow += st.mfma_blocks_shadow;
+        tot.ms_primary = std::max(tot.ms_primary, st.ms_primary); tot.ms_setup = std::max(tot.ms_setup, st.ms_setup);
+        tot.ms_shadow = std::max(tot.ms_shadow, st.ms_shadow); tot.ms_final = std::max(tot.ms_final, st.ms_final);
+        tot.ms_total = std::max(tot.ms_total, st.ms_total); tot.upload_ms = std::max(tot.upload_ms, st.upload_ms);
+    }
+    tot.prepare_ms = s->prepare_ms;
+    s->stats_multi = tot;
+    s->multi_stats = true;
+    if (caller >= 0) (void)hipSetDevice(caller);
+    return RT_OK;
+}

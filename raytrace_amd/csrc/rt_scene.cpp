@@ -11,6 +11,7 @@
 #endif
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <limits>
@@ -628,13 +629,10 @@ static GenRec make_gen_rec(const LeafD &L, const double omax[3]) {
     return r;
 }
 
-void build_filter_records(rt_scene &s, int w, int h) {
+void build_filter_records(rt_scene &s, int w, int h, bool eye_only) {
+    (void)w; (void)h;
     const size_t ntri = s.tri_gid.size(), nrect = s.rect_gid.size(), nsph = s.sph_gid.size();
     const int napex = 1 + s.npoint;
-    s.sph_rec.assign(nsph * (size_t)napex + 4, never_rec());
-    // four records of padding: the kernels prefetch up to record i + 2 while testing record i
-    s.tri_rec.assign(ntri * (size_t)napex + 4, never_rec());
-    s.rect_rec.assign(nrect * (size_t)napex + 4, never_rec());
     // scene extent (leaf corners), for the per-light bound on |D| = |hit - light|
     double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
     for (const LeafD &L : s.leaves) {
@@ -660,7 +658,6 @@ void build_filter_records(rt_scene &s, int w, int h) {
             for (int i = 0; i < 3; ++i)
                 if (std::isfinite(v[k][i])) { lo[i] = std::fmin(lo[i], v[k][i]); hi[i] = std::fmax(hi[i], v[k][i]); }
     }
-    const CameraD cam = fixed_camera(w, h);
     // MFMA stream: one row per planar leaf, 32 per block (see rt_types.h), in a per-apex order (direction_split), two
     // blocks of padding; live leaves first (padded to a whole block), then the "always" leaves, then the "never" ones
     std::vector<int32_t> planar;
@@ -669,18 +666,34 @@ void build_filter_records(rt_scene &s, int w, int h) {
     s.mf_groups = (int)((nplanar + MF_LEAVES - 1) / MF_LEAVES) + 1;          // + 1: the padding behind the live leaves
     s.mf_groups = (s.mf_groups + 2) / 3 * 3;               // the scan handles three blocks per loop iteration (padding: never rows)
     const size_t gstride = (size_t)s.mf_groups + 2;
-    s.mf_gid.assign(gstride * (size_t)napex * MF_LEAVES, -1);
-    s.mf_rows.assign(gstride * (size_t)napex * 32 * 8, 0);
-    s.mf_rec.assign(gstride * (size_t)napex * MF_LEAVES, never_rec());
-    s.mf_cone.assign(gstride * (size_t)napex * 8, 0.f);
-    for (FilterRec &r : s.mf_rec) { const int32_t none = -1; std::memcpy(&r.c[15], &none, 4); }
-    {
+    if (!eye_only) {
+        // four records of padding: the kernels prefetch up to record i + 2 while testing record i
+        s.sph_rec.assign(nsph * (size_t)napex + 4, never_rec());
+        s.tri_rec.assign(ntri * (size_t)napex + 4, never_rec());
+        s.rect_rec.assign(nrect * (size_t)napex + 4, never_rec());
+        s.mf_gid.assign(gstride * (size_t)napex * MF_LEAVES, -1);
+        s.mf_rows.assign(gstride * (size_t)napex * 32 * 8, 0);
+        s.mf_rec.assign(gstride * (size_t)napex * MF_LEAVES, never_rec());
+        s.mf_cone.assign(gstride * (size_t)napex * 8, 0.f);
+    }
+    // an apex's slices start out as padding: never rows, never records, no leaf
+    auto reset_apex = [&](int apex) {
         uint16_t never[8];
         const_row(never, -1.0f);
-        for (size_t r = 0; r < gstride * (size_t)napex * 32; ++r) std::memcpy(&s.mf_rows[r * 8], never, 16);
-    }
+        FilterRec none = never_rec();
+        const int32_t minus1 = -1;
+        std::memcpy(&none.c[15], &minus1, 4);
+        const size_t base = (size_t)apex * gstride * MF_LEAVES;
+        for (size_t k = 0; k < gstride * MF_LEAVES; ++k) {
+            s.mf_gid[base + k] = -1;
+            s.mf_rec[base + k] = none;
+            std::memcpy(&s.mf_rows[(base + k) * 8], never, 16);
+        }
+        for (size_t k = 0; k < gstride * 8; ++k) s.mf_cone[(size_t)apex * gstride * 8 + k] = 0.f;
+    };
     int apex = 0;
     auto fill = [&](const double A[3], const double dmax[3], double eye_d) {
+        reset_apex(apex);
         std::vector<LeafCone> cone(nplanar);
         std::vector<double> cu(nplanar), cv(nplanar);
         std::vector<int> live, always, never;
@@ -725,38 +738,96 @@ void build_filter_records(rt_scene &s, int w, int h) {
         for (size_t k = 0; k < nsph; ++k) s.sph_rec[(size_t)apex * nsph + k] = make_sphere_rec(s.leaves[s.sph_gid[k]], A, dmax);
         ++apex;
     };
-    {   // the eye: every primary ray o = (posX, posY, 0), D = (posX, posY, d) passes through o - D
+    {   // the eye: every primary ray o = (posX, posY, 0), D = (posX, posY, d) passes through o - D.  The apex does not
+        // depend on the image size (d = -tan(fov/2)/2); only the bound on |posX|, |posY| does, through the margins.
+        const CameraD cam = fixed_camera(1, 1);
         const double A[3] = {0.0, 0.0, -cam.d};
-        // |posX| <= |dX| (+ half a pixel of jitter), |posY| <= |dY| (+ ...), D.z = d
-        const double dmax[3] = {std::fabs(cam.dX) + 2 * std::fabs(cam.scaleX),
-                                std::fabs(cam.dY) + 2 * std::fabs(cam.scaleY), std::fabs(cam.d)};
-        fill(A, dmax, cam.d);
+        fill(A, s.eye_dmax, cam.d);
     }
-    for (LightD &Lt : s.lights) {
-        if (Lt.kind != 0) continue;
-        Lt.rec_offset = apex;
-        const double A[3] = {Lt.px, Lt.py, Lt.pz};
-        double dmax[3];
-        for (int i = 0; i < 3; ++i) {
-            const double a = std::fabs(lo[i] - A[i]), b = std::fabs(hi[i] - A[i]);
-            dmax[i] = (s.leaves.empty() ? 1.0 : std::fmax(a, b)) * 1.001 + 1e-3;
+    if (!eye_only) {
+        for (LightD &Lt : s.lights) {
+            if (Lt.kind != 0) continue;
+            Lt.rec_offset = apex;
+            const double A[3] = {Lt.px, Lt.py, Lt.pz};
+            double dmax[3];
+            for (int i = 0; i < 3; ++i) {
+                const double a = std::fabs(lo[i] - A[i]), b = std::fabs(hi[i] - A[i]);
+                dmax[i] = (s.leaves.empty() ? 1.0 : std::fmax(a, b)) * 1.001 + 1e-3;
+            }
+            fill(A, dmax, 0.0);
         }
-        fill(A, dmax, 0.0);
+        s.reflective = false;
+        for (const MaterialD &m : s.mats) if (m.reflectivity > 0) s.reflective = true;
+        s.gen_tri.clear(); s.gen_rect.clear(); s.gen_sph.clear();
+        if (s.reflective) {
+            double omax[3];
+            for (int i = 0; i < 3; ++i) omax[i] = (s.leaves.empty() ? 1.0 : std::fmax(std::fabs(lo[i]), std::fabs(hi[i]))) * 1.001 + 1e-3;
+            GenRec never{}; never.c[12] = 1.0f;
+            s.gen_tri.assign(ntri + 1, never); s.gen_rect.assign(nrect + 1, never);
+            for (size_t k = 0; k < ntri; ++k) s.gen_tri[k] = make_gen_rec(s.leaves[s.tri_gid[k]], omax);
+            for (size_t k = 0; k < nrect; ++k) s.gen_rect[k] = make_gen_rec(s.leaves[s.rect_gid[k]], omax);
+            s.gen_sph.assign(nsph + 1, never);
+            for (size_t k = 0; k < nsph; ++k) s.gen_sph[k] = make_sphere_gen_rec(s.leaves[s.sph_gid[k]], omax);
+        }
     }
-    s.reflective = false;
-    for (const MaterialD &m : s.mats) if (m.reflectivity > 0) s.reflective = true;
-    s.gen_tri.clear(); s.gen_rect.clear(); s.gen_sph.clear();
-    if (s.reflective) {
-        double omax[3];
-        for (int i = 0; i < 3; ++i) omax[i] = (s.leaves.empty() ? 1.0 : std::fmax(std::fabs(lo[i]), std::fabs(hi[i]))) * 1.001 + 1e-3;
-        GenRec never{}; never.c[12] = 1.0f;
-        s.gen_tri.assign(ntri + 1, never); s.gen_rect.assign(nrect + 1, never);
-        for (size_t k = 0; k < ntri; ++k) s.gen_tri[k] = make_gen_rec(s.leaves[s.tri_gid[k]], omax);
-        for (size_t k = 0; k < nrect; ++k) s.gen_rect[k] = make_gen_rec(s.leaves[s.rect_gid[k]], omax);
-        s.gen_sph.assign(nsph + 1, never);
-        for (size_t k = 0; k < nsph; ++k) s.gen_sph[k] = make_sphere_gen_rec(s.leaves[s.sph_gid[k]], omax);
-    }
+}
+
+// The eye-apex records hold for every camera whose |posX|, |posY| stay inside eye_dmax (half a pixel of jitter and a
+// pixel of slack included), so most changes of the image size rebuild nothing; a scene change rebuilds everything.
+bool prepare_host(rt_scene &s, int w, int h) {
+    const CameraD cam = fixed_camera(w, h);
+    const double need[3] = {std::fabs(cam.dX) + 2 * std::fabs(cam.scaleX), std::fabs(cam.dY) + 2 * std::fabs(cam.scaleY), std::fabs(cam.d)};
+    bool grow = false;
+    for (int i = 0; i < 3; ++i) if (!(need[i] <= s.eye_dmax[i])) grow = true;
     s.rec_w = w; s.rec_h = h;
+    if (!s.dirty && !grow) return true;
+    const auto t0 = std::chrono::steady_clock::now();
+    // built for every image at least 16 pixels wide and no taller than wide; narrower or taller ones widen the bound
+    const double floor_[3] = {0.625, 0.625, 0.5};
+    if (grow) for (int i = 0; i < 3; ++i) s.eye_dmax[i] = std::fmax(std::fmax(need[i], floor_[i]), s.eye_dmax[i]);
+    if (s.dirty) {
+        if (!compute_guards(s)) return false;
+        build_filter_records(s, w, h, false);
+        ++s.version; ++s.eye_version;
+        s.dirty = false;
+    } else {
+        build_filter_records(s, w, h, true);
+        ++s.eye_version;
+    }
+    s.prepare_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return true;
+}
+
+// C port of raytrace_amd/distributed.py: split_rows (the two must agree; tests/test_host_scene.py compares them).
+void split_rows(const double *cost_in, int ncost, int h, int n, int align, int *row0, int *nrows) {
+    std::vector<double> cost(cost_in, cost_in + ncost);
+    double tot = 0;
+    for (double c : cost) tot += c;
+    if (!(tot > 0)) { cost.assign(ncost, 1.0); }
+    std::vector<double> cum(ncost + 1, 0.0);
+    for (int i = 0; i < ncost; ++i) cum[i + 1] = cum[i] + cost[i];
+    const double total = cum[ncost];
+    for (double &c : cum) c /= total;
+    std::vector<int> cuts(1, 0);
+    for (int k = 1; k < n; ++k) {
+        const double x = (double)k / (double)n;
+        // numpy.interp(x, cum, 0..ncost): the last j with cum[j] <= x, linear inside [cum[j], cum[j+1]]
+        double pos;
+        if (x >= cum[ncost]) pos = (double)ncost;
+        else {
+            int j = (int)(std::upper_bound(cum.begin(), cum.end(), x) - cum.begin()) - 1;
+            if (j < 0) j = 0;
+            const double slope = 1.0 / (cum[j + 1] - cum[j]);
+            pos = slope * (x - cum[j]) + (double)j;
+        }
+        long long r = (long long)std::nearbyint(pos * (double)h / (double)ncost);      // Python's round: half to even
+        r = (r / align) * align;
+        const long long lo = std::min<long long>(h, (long long)cuts.back() + align);
+        const long long hi = std::max<long long>(lo, (long long)h - (long long)(n - k) * align);
+        cuts.push_back((int)std::min(std::max(r, lo), hi));
+    }
+    cuts.push_back(h);
+    for (int i = 0; i < n; ++i) { row0[i] = cuts[i]; nrows[i] = cuts[i + 1] - cuts[i]; }
 }
 
 } // namespace rt
@@ -775,6 +846,32 @@ int rt_scene_create(rt_scene **out) {
     if (!out) { set_error("rt_scene_create: out is NULL"); return RT_ERR_ARG; }
     *out = new (std::nothrow) rt_scene();
     if (!*out) { set_error("rt_scene_create: out of memory"); return RT_ERR_NOMEM; }
+    return RT_OK;
+}
+
+int rt_scene_set_option(rt_scene *s, int option, int value) {
+    if (!s) { set_error("rt_scene_set_option: NULL scene"); return RT_ERR_ARG; }
+    switch (option) {
+    case RT_OPT_CULL: s->opt_cull = value != 0; return RT_OK;
+    case RT_OPT_FILTER:
+        if (value != 0 && value != 1) { set_error("rt_scene_set_option: RT_OPT_FILTER takes 0 (matrix cores) or 1 (vector ALU)"); return RT_ERR_ARG; }
+#ifndef RT_VALU_FILTER
+        if (value == 1) { set_error("rt_scene_set_option: the FP32 vector-ALU kernels exist only in the cross-check build libraytrace_gpu_valu.so"); return RT_ERR_UNSUPPORTED; }
+#endif
+        s->opt_filter = value; return RT_OK;
+    case RT_OPT_HOST_BANDS:
+        if (value < 0) { set_error("rt_scene_set_option: RT_OPT_HOST_BANDS must be >= 0"); return RT_ERR_ARG; }
+        s->opt_host_bands = value; return RT_OK;
+    case RT_OPT_MULTI_STAGE: s->opt_multi_stage = value != 0; return RT_OK;
+    }
+    set_error("rt_scene_set_option: unknown option");
+    return RT_ERR_ARG;
+}
+
+int rt_split_rows(const double *cost, int ncost, int h, int n, int align, int *row0, int *nrows) {
+    if (!cost || !row0 || !nrows || ncost < 1 || h < 0 || n < 1 || align < 1) { set_error("rt_split_rows: bad argument"); return RT_ERR_ARG; }
+    for (int i = 0; i < ncost; ++i) if (!(cost[i] >= 0)) { set_error("rt_split_rows: cost must be non-negative"); return RT_ERR_ARG; }
+    split_rows(cost, ncost, h, n, align, row0, nrows);
     return RT_OK;
 }
 
@@ -896,6 +993,23 @@ int rt_set_normal_mode(rt_scene *s, int first_leaf, int nleaves, int mode, const
     return RT_OK;
 }
 
+int rt_set_normal_callback(rt_scene *s, int first_leaf, int nleaves, const double params[4], rt_normal_fn fn, void *user) {
+    if (!s || first_leaf < 0 || nleaves < 0 || (size_t)first_leaf + (size_t)nleaves > s->leaves.size()) {
+        set_error("rt_set_normal_callback: leaf range out of bounds"); return RT_ERR_ARG;
+    }
+    if (!params || !fn) { set_error("rt_set_normal_callback: NULL argument"); return RT_ERR_ARG; }
+    AuxD a{};
+    for (int i = 0; i < 4; ++i) a.a[i] = params[i];
+    a.a[4] = (double)s->normal_fn.size();                 // which callback
+    s->normal_fn.push_back(fn);
+    s->normal_user.push_back(user);
+    s->aux.push_back(a);
+    const int aux = (int)s->aux.size() - 1;
+    for (int i = first_leaf; i < first_leaf + nleaves; ++i) { s->leaves[i].nmode = RT_NORMAL_CALLBACK; s->leaves[i].aux = aux; }
+    s->dirty = true;
+    return RT_OK;
+}
+
 int rt_add_point_light(rt_scene *s, double diffuse, double specular, const double pos[3]) {
     if (!s || !pos) { set_error("rt_add_point_light: NULL argument"); return RT_ERR_ARG; }
     LightD L{};
@@ -930,9 +1044,7 @@ int rt_scene_get_leaf(const rt_scene *s, int leaf, double out[20]) {
 
 int rt_scene_prepare_host(rt_scene *s, int w, int h) {
     if (!s || w <= 0 || h <= 0) { set_error("rt_scene_prepare_host: bad argument"); return RT_ERR_ARG; }
-    if (!compute_guards(*s)) return RT_ERR_ARG;
-    build_filter_records(*s, w, h);
-    s->dirty = true;    // the device copy (if any) is stale
+    if (!prepare_host(*s, w, h)) return RT_ERR_ARG;
     return (int)s->guards.size();
 }
 

@@ -13,41 +13,66 @@
 
 namespace rt {
 
-struct DeviceScene {          // device copies (HBM), owned by the scene
-    LeafD *leaves = nullptr;
-    AuxD *aux = nullptr;
-    GuardD *guards = nullptr;
-    MaterialD *mats = nullptr;
-    LightD *lights = nullptr;
-    FilterRec *tri_rec = nullptr;    // (1 + npoint) blocks of ntri records: eye, then each point light
-    FilterRec *rect_rec = nullptr;   // (1 + npoint) blocks of nrect records
-    int32_t *tri_gid = nullptr;      // per-type slot -> leaf index
-    int32_t *rect_gid = nullptr;
-    FilterRec *sph_rec = nullptr;    // (1 + npoint) blocks of nsph sphere records
-    GenRec *gen_sph = nullptr;
-    int32_t *sph_gid = nullptr;
-    uint16_t *mf_rows = nullptr;     // MFMA row blocks (rt_types.h), per apex
-    int32_t *mf_gid = nullptr;
-    float *mf_cone = nullptr;        // per apex and block: {axis xyz, cos T, sin T, 0, 0, 0}
-    FilterRec *mf_rec = nullptr;
-    unsigned long long *counters = nullptr;  // 8 x u64
-    // work buffers, grown on demand
-    int32_t *hit_id = nullptr;  size_t hit_id_cap = 0;     // per band pixel
-    uint32_t *accum = nullptr;  size_t accum_cap = 0;      // spp > 1: 3 x u32 per pixel
-    uint8_t *rgba = nullptr;    size_t rgba_cap = 0;       // rt_render (host buffers) staging
-    int32_t *hit_out = nullptr; size_t hit_out_cap = 0;    // rt_render (host buffers) staging
-    char *hitrec = nullptr;     size_t hitrec_cap = 0;     // per chunk pixel: 48-byte HitRec (capacity in bytes)
-    uint32_t *queue = nullptr;  size_t queue_cap = 0;      // shadow-job queues, npoint x chunk pixels
-    uint32_t *qsparse = nullptr; size_t qsparse_cap = 0;   // k_setup's per-block runs of shadow jobs, before compaction
-    unsigned *tcount = nullptr; size_t tcount_cap = 0;     // shadow jobs per (light, k_setup block) -> offsets
-    uint32_t *lit = nullptr;    size_t lit_cap = 0;        // per chunk pixel: lit-by-light bit mask
-    unsigned *qcount = nullptr;                            // shadow jobs per point light; [32..39] rays per bounce level
-    GenRec *gen_tri = nullptr, *gen_rect = nullptr;        // general-ray filter records (reflective scenes only)
-    // bounce levels 1..7 (reflective scenes only): rays, hit ids and colours per slot; [0] = colour of level 0
-    RayRec *lvl_rays[8] = {};   size_t lvl_rays_cap[8] = {};
-    int32_t *lvl_hit[8] = {};   size_t lvl_hit_cap[8] = {};
-    uint32_t *lvl_col[8] = {};  size_t lvl_col_cap[8] = {};
+constexpr int RT_MAX_DEVICES = 16;       // HIP devices one process may render on (rt_init / rt_render_multi)
+constexpr int RT_HOST_BANDS_MAX = 8;     // copy bands of rt_render
+constexpr int RT_MAX_LEVELS = 64;        // bounce levels kept for the fold of the colours (trace depth with mirrors)
+
+// One uploaded array: capacity is kept, so a re-upload of the same size neither frees nor allocates.
+struct DevBuf { void *p = nullptr; size_t cap = 0; };
+
+// Device memory of one render beyond its inputs and outputs.  rt_render / rt_render_device grow it on demand
+// (hipMalloc, kept in the DeviceScene); rt_render_device_noalloc carves it out of the library's static device
+// array instead (rt_kernels.hip: `scratch`).
+struct Workspace {
+    unsigned long long *counters = nullptr;  // RT_STAT_SLOTS x 16 x u64
+    unsigned *qcount = nullptr;              // shadow jobs per point light [0..31]; rays per bounce level [32..63]
+    int32_t *hit_id = nullptr;               // per band pixel (only when the caller gives no buffer, or spp > 1)
+    uint32_t *accum = nullptr;               // spp > 1: 3 x u32 per band pixel
+    char *hitrec = nullptr;                  // per chunk pixel: 48-byte HitRec
+    uint32_t *queue = nullptr;               // shadow-job queues, npoint x chunk pixels
+    uint32_t *qsparse = nullptr;             // k_setup's per-block runs of shadow jobs, before compaction
+    unsigned *tcount = nullptr;              // shadow jobs per (light, k_setup block) -> offsets
+    uint32_t *lit = nullptr;                 // per chunk pixel: lit-by-light bit mask
+    RayRec *lvl_rays[RT_MAX_LEVELS] = {};    // bounce levels 1.. (reflective scenes only): rays, hit ids, colours per slot
+    int32_t *lvl_hit[RT_MAX_LEVELS] = {};
+    uint32_t *lvl_col[RT_MAX_LEVELS] = {};   // [0] = colour of level 0
+    uint32_t *cb_slot = nullptr;             // RT_NORMAL_CALLBACK: per chunk slot, index into the list of hit points
+    double *cb_xy = nullptr;                 // per list entry: the arguments of fnorm
+    int32_t *cb_group = nullptr;             // per list entry: which callback
+    double *cb_normal = nullptr;             // per list entry: fnorm x y (from the host)
+};
+
+struct DeviceScene {          // the scene on ONE device (HBM), owned by the rt_scene
     int device = -1;
+    uint64_t version = 0;            // rt_scene::version of the uploaded copy (0: nothing uploaded)
+    uint64_t eye_version = 0;        // rt_scene::eye_version of the uploaded eye-apex records
+    DevBuf leaves, aux, guards, mats, lights;
+    DevBuf tri_rec, rect_rec;        // (1 + npoint) blocks of ntri / nrect records: eye, then each point light (VALU filter build)
+    DevBuf tri_gid, rect_gid;        // per-type slot -> leaf index
+    DevBuf sph_rec, gen_sph, sph_gid;
+    DevBuf mf_rows, mf_gid, mf_cone, mf_rec;   // MFMA stream per apex (rt_types.h)
+    DevBuf gen_tri, gen_rect;        // general-ray records (reflective scenes only)
+    void *stream = nullptr;          // hipStream_t: renders of this scene on this device (when the caller passes none)
+    void *copy_stream = nullptr;     // hipStream_t: rt_render's copies to host memory, band by band; rt_render_multi's peer copies
+    void *copy_stream2 = nullptr;    // hipStream_t: rt_render_multi's copies from the home device to host memory
+    void *band_done[RT_HOST_BANDS_MAX] = {};   // hipEvent_t
+    // work buffers of rt_render / rt_render_device, grown on demand
+    Workspace ws;
+    size_t hit_id_cap = 0, accum_cap = 0, hitrec_cap = 0, queue_cap = 0, qsparse_cap = 0, tcount_cap = 0, lit_cap = 0;
+    size_t lvl_rays_cap[RT_MAX_LEVELS] = {}, lvl_hit_cap[RT_MAX_LEVELS] = {}, lvl_col_cap[RT_MAX_LEVELS] = {};
+    size_t cb_cap[4] = {};
+    uint8_t *rgba = nullptr;    size_t rgba_cap = 0;       // rt_render (host buffers) staging
+    int32_t *hit_out = nullptr; size_t hit_out_cap = 0;
+    uint8_t *stage_rgba = nullptr; size_t stage_rgba_cap = 0;   // rt_render_multi: this device's bands before the peer copy
+    int32_t *stage_hit = nullptr;  size_t stage_hit_cap = 0;
+    // statistics of the last render on this device
+    const unsigned long long *last_counters = nullptr;     // where that render's counters live
+    std::vector<void *> evpool;      // hipEvent_t, one per kernel boundary of the last render
+    std::vector<int> evkind;         // which kernel ended at that event (1 primary .. 4 final)
+    int ev_used = 0;
+    bool stats_pending = false;
+    uint64_t last_primary = 0;
+    rt_stats stats{};
 };
 
 } // namespace rt
@@ -80,16 +105,28 @@ struct rt_scene {
     std::vector<float> mf_cone;           // per apex and block: bounding cone of the block's leaves, 8 floats (rt_scene.cpp: block_cone)
     std::vector<rt::FilterRec> mf_rec;    // FP32 records in MFMA stream order, per apex; c[14] = kind, c[15] = leaf index (bits)
     int mf_groups = 0;
+    double scene_lo[3] = {0, 0, 0}, scene_hi[3] = {0, 0, 0};   // extent of the leaves (build_filter_records)
     bool reflective = false;
-    int rec_w = -1, rec_h = -1;
-    bool dirty = true;                    // host scene changed since the last upload
-    rt::DeviceScene dev;
-    rt_stats stats{};
-    std::vector<void *> evpool;           // hipEvent_t, one per kernel boundary of the last render
-    std::vector<int> evkind;              // which kernel ended at that event (1 primary .. 4 final)
-    int ev_used = 0;
-    bool stats_pending = false;
-    uint64_t last_primary = 0;
+    int rec_w = -1, rec_h = -1;           // image size of the last host preparation (-1: none yet)
+    double eye_dmax[3] = {0, 0, 0};       // bound on |posX|, |posY|, |d| the eye-apex records were built for
+    bool dirty = true;                    // host scene changed since the records were built
+    uint64_t version = 0;                 // bumped whenever the records are rebuilt from a changed scene
+    uint64_t eye_version = 0;             // bumped whenever the eye-apex records are rebuilt (scene or camera bound changed)
+    double prepare_ms = 0;                // host time of the last rebuild of the records (guards, cones, sort)
+    // per-scene options (rt_scene_set_option)
+    int opt_cull = 1;                     // 0: every wave scans every block of the leaf stream
+    int opt_filter = 0;                   // 0: matrix-core first stage; 1: FP32 vector-ALU kernels (test build only)
+    int opt_host_bands = 0;               // copy bands of rt_render (0: one per 2 Mi pixels)
+    int opt_multi_stage = 0;              // rt_render_multi: also the home device's bands go through a staging buffer + peer copy
+    // arbitrary `fnorm` closures (Main.hs:956-965): per callback group, the caller's function
+    std::vector<rt_normal_fn> normal_fn;
+    std::vector<void *> normal_user;
+    rt::DeviceScene dev[rt::RT_MAX_DEVICES];
+    int last_device = -1;                 // device of the last render (rt_get_stats)
+    std::vector<double> multi_cost;       // rt_render_multi: measured strip costs, valid for multi_cost_key
+    uint64_t multi_cost_key[5] = {0, 0, 0, 0, 0};   // version, w, h, depth, spp
+    bool multi_stats = false;             // stats_multi holds the merged statistics of the last rt_render_multi
+    rt_stats stats_multi{};
 };
 
 namespace rt {
@@ -97,8 +134,13 @@ namespace rt {
 void set_error(const std::string &msg);
 CameraD fixed_camera(int w, int h);                       // Main.hs:506-527
 double ray_eps();                                         // Main.hs:114
+// (Re)build what a w x h render uploads: guard chains and every apex's records when the scene changed, the eye
+// apex's records alone when only the camera bound grew.  Returns false (and sets the error) on an open bracket.
+bool prepare_host(rt_scene &s, int w, int h);
 // (Re)build the FP32 filter records for the eye of a w x h camera and for every point light.
-void build_filter_records(rt_scene &s, int w, int h);
+void build_filter_records(rt_scene &s, int w, int h, bool eye_only = false);
+// Contiguous row bands of about equal cost (C port of raytrace_amd/distributed.py: split_rows).
+void split_rows(const double *cost, int ncost, int h, int n, int align, int *row0, int *nrows);
 // Compute every leaf's guard box from the bracket tree; false (and set_error) on an open bracket.
 bool compute_guards(rt_scene &s);
 

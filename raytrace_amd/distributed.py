@@ -25,7 +25,8 @@ def split_rows(cost: Sequence[float], h: int, n: int, align: int = 8) -> List[Tu
     if cost.sum() <= 0:
         cost = np.ones_like(cost)
     sh = len(cost)
-    cum = np.concatenate([[0.0], np.cumsum(cost)]) / cost.sum()
+    cum = np.concatenate([[0.0], np.cumsum(cost)])
+    cum = cum / cum[-1]              # (sequential sums, so that the C port rt_split_rows agrees bit for bit)
     cuts = [0]
     for k in range(1, n):
         r = int(round(float(np.interp(k / n, cum, np.arange(sh + 1))) * h / sh))   # cost is piecewise constant per row

@@ -4,6 +4,8 @@ and the synthetic benchmark scenes of BASELINE.json / SURVEY.md §8(d).
 Every function returns (world, lights).  Scenes for which the reference's `main` gives no lights use
 the commented-out light set of Main.hs:607-609.
 """
+import math
+
 import numpy as np
 
 from .api import (GAUSSIAN_FNORM, COLOURS, ambient, aquamarine, black, blue, colorcube, colorcuboid, cube, cyan,
@@ -127,7 +129,7 @@ def spheres():                                       # Main.hs:670-690
 
 def mirror_room():
     """The planar part of `spheres` (Main.hs:670-690): mirror floor strip and walls, lights of that scene.
-    (The spheres themselves are a "next" primitive.)  Exercises trace's reflection recursion, Main.hs:546-556."""
+    Exercises trace's reflection recursion, Main.hs:546-556, without the spheres."""
     mirror = black.replace(reflectivity=0.9, specular=(255, 255, 255), specularity=100)
     world = mconcat([
         colorcube([red, green, blue], (-2, -3.5, -7), 2.0),
@@ -141,10 +143,68 @@ def mirror_room():
     return world, lights
 
 
+def _normalize(v):
+    n = math.sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2])
+    return (v[0] / n, v[1] / n, v[2] / n)
+
+
+def _cross(a, b):                                    # Main.hs:68-69
+    return (a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - b[0] * a[1])
+
+
+def sine_cosine(with_normals=False):                 # Main.hs:598-605 (commented world): 3D sine-cosine waveform
+    """`linearInterpolation f Nothing (-2*pi,-pi/2) (2*pi,pi/2) (pi/10) origin 7`; with_normals=True passes the fnorm the
+    reference defines beside it (`Just fnorm`) instead of Nothing: an arbitrary closure, evaluated on the host."""
+    def f(x, y):
+        return math.sin(x) * math.sin(y) + 2
+
+    def fnorm(x, y):
+        dfdx = math.cos(x) * math.sin(y)
+        dfdy = math.sin(x) * math.cos(y)
+        return _normalize(_cross((1.0, dfdx, 0.0), (0.0, dfdy, 1.0)))
+    return linearInterpolation(f, fnorm if with_normals else None, (-2 * math.pi, -math.pi / 2), (2 * math.pi, math.pi / 2),
+                               math.pi / 10, (0.0, -30.0, -70.0), 7.0)
+
+
+def sinc(with_normals=True):                         # Main.hs:586-597 (commented world): 3D sinc function
+    def f(x, y):
+        if x == 0 and y == 0:
+            return 4.0
+        if x == 0:
+            return 1 + math.sin(y) / y + 2
+        if y == 0:
+            return 1 + math.sin(x) / x + 2
+        return math.sin(x) / x + math.sin(y) / y + 2
+
+    def fnorm(x, y):
+        if x == 0 and y == 0:
+            return (0.0, 1.0, 0.0)
+        # (the reference's fnorm uses dfdy for both tangent vectors, Main.hs:593, and divides by y*y: a NaN normal on
+        # the line y = 0, reproduced as written)
+        dfdy = (y * math.cos(y) - math.sin(y)) / (y * y) if y != 0 else float("nan")
+        v = _cross((1.0, dfdy, 0.0), (0.0, dfdy, 1.0))
+        n = math.sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2])
+        return (v[0] / n, v[1] / n, v[2] / n)
+    return linearInterpolation(f, fnorm if with_normals else None, (-4 * math.pi, -2 * math.pi), (4 * math.pi, 2 * math.pi),
+                               math.pi / 4, (0.01, -10.0, -20.0), 1.0)
+
+
+def viewport_plane():
+    """A rectangle IN the viewport plane z = 0, where every camera ray starts (Main.hs:528-531): it is hit at
+    t = (0 - 0) * recip = -0.0, which passes `t >= 0` (Main.hs:257) and must win against everything behind it
+    (`-0.0 <= t2`, Main.hs:213), also when it is the right operand of the monoid."""
+    return mconcat([
+        rectangle(red, (0, 0, -3), (4, 0, 0), (0, 4, 0)),
+        rectangle(green, (0.1, 0.02, 0), (0.3, 0, 0), (0, 0.1, 0)),
+        rectangle(blue, (-0.2, -0.05, 0), (0, 0.1, 0), (0.2, 0, 0)),
+        cube(yellow, (0, 0, -2), 0.5)]), main_lights()
+
+
 REFERENCE_SCENES = {
     "default": default_scene, "planes": planes, "axes": axes, "cubes": cubes, "stacked_cubes": stacked_cubes,
     "triangle_example": triangle_example, "spec_test": spec_test, "intersection": intersection,
     "cylinder_axes": cylinder_axes, "talk_main2": talk_main2, "talkhs_main2": talkhs_main2, "mirror_room": mirror_room, "spheres": spheres,
+    "sine_cosine": sine_cosine, "viewport_plane": viewport_plane,
 }
 
 
@@ -188,6 +248,24 @@ def synthetic(ntri=10000, ncuboid=1000, seed=SYNTH_SEED, specularities=(1, 20, 1
                              [(-6.0, 10.0, -10.0), (6.0, 10.0, -10.0), (-6.0, 10.0, -26.0), (6.0, 10.0, -26.0)]]
                             + [ambient(0.1)])
     return mconcat(shapes), lights
+
+
+def mirror_bench(ntri=4000, ncuboid=400):
+    """`bench.py --workload mirror`: the mirrors of the reference's `spheres` scene (Main.hs:670-690: the reflective
+    sphere, the mirror strip under the ceiling) and a mirror wall, around the synthetic triangles and cuboids, lit by
+    that scene's two point lights.  Reflected rays (trace depth 4, Main.hs:546-556) see thousands of leaves."""
+    mirror = black.replace(reflectivity=0.9, specular=(255, 255, 255), specularity=100)
+    clutter, _ = synthetic(ntri=ntri, ncuboid=ncuboid)
+    world = mconcat([
+        clutter,
+        sphere(mirror, (-2, 1, -4), 1),
+        rectangle(orange, (0, -7, -18), (0, 0, 40), (40, 0, 0)),
+        rectangle(green, (0, 0, -32), (40, 0, 0), (0, 40, 0)),
+        rectangle(mirror, (0, 6.5, -18), (40, 0, 0), (0, 0, 40)),
+        rectangle(mirror, (-9, 0, -18), (0, 20, 0), (0, 0, 40)),                          # normal +x: faces the room
+        rectangle(mirror.replace(reflectivity=0.5), (9, 0, -18), (0, 0, 40), (0, 20, 0))])   # normal -x
+    lights = mconcat_lights([pointLight(0.8, 0.1, (0, 3, -10)), pointLight(0.8, 0.8, (0, 3, 0)), ambient(0.2)])
+    return world, lights
 
 
 def synthetic_cylinders(ncyl=200, ncuboid=500, seed=SYNTH_SEED + 1, specularities=(100, 400)):

@@ -20,6 +20,7 @@ class orc_material(C.Structure):
 
 
 _D3 = C.POINTER(C.c_double)
+ORC_FNORM = C.CFUNCTYPE(None, C.c_double, C.c_double, _D3, C.c_void_p)
 _lib = None
 
 
@@ -40,6 +41,7 @@ def lib():
         L.orc_cylinder.argtypes = [C.c_void_p, C.POINTER(orc_material), C.POINTER(orc_material), C.POINTER(orc_material),
                                    _D3, C.c_int, C.c_double, C.c_double]
         L.orc_normals_gaussian.argtypes = [C.c_void_p, C.c_int, C.c_double, _D3]
+        L.orc_normals_callback.argtypes = [C.c_void_p, C.c_int, C.c_double, _D3, ORC_FNORM, C.c_void_p]
         L.orc_linear_interpolation_gaussian.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double,
                                                         C.c_double, _D3, C.c_double]
         L.orc_point_light.argtypes = [C.c_void_p, C.c_double, C.c_double, _D3]
@@ -73,6 +75,7 @@ class OracleScene:
     def __init__(self, world, lights):
         self.L = lib()
         self.h = C.c_void_p(self.L.orc_scene_new())
+        self._callbacks = []
         if isinstance(world, api.TalkDialect):        # src/Talk.hs rules
             assert self.L.orc_scene_set_talk(self.h, 1) == 0
             world = world.child
@@ -105,6 +108,16 @@ class OracleScene:
             return L.orc_mconcat(h, (C.c_int * max(1, len(kids)))(*kids), len(kids))
         if isinstance(s, api.GaussianNormals):
             return L.orc_normals_gaussian(h, self._node(s.child), s.scale_inv, _v(s.offset))
+        if isinstance(s, api.CallbackNormals):
+            fnorm = s.fnorm
+
+            def thunk(x, y, out, _user, fnorm=fnorm):
+                v = fnorm(x, y)
+                out[0], out[1], out[2] = float(v[0]), float(v[1]), float(v[2])
+
+            cb = ORC_FNORM(thunk)
+            self._callbacks.append(cb)
+            return L.orc_normals_callback(h, self._node(s.child), s.scale_inv, _v(s.offset), cb, None)
         raise TypeError(s)
 
     @property

@@ -16,7 +16,8 @@ pytestmark = pytest.mark.gpu
 
 SIZES = {"default": (256, 256), "planes": (160, 120), "axes": (200, 200), "cubes": (256, 144),
          "stacked_cubes": (256, 256), "triangle_example": (250, 130), "spec_test": (192, 192),
-         "intersection": (256, 256), "cylinder_axes": (200, 160), "talk_main2": (128, 128), "talkhs_main2": (512, 512), "mirror_room": (256, 192), "spheres": (256, 256)}
+         "intersection": (256, 256), "cylinder_axes": (200, 160), "talk_main2": (128, 128), "talkhs_main2": (512, 512), "mirror_room": (256, 192), "spheres": (256, 256),
+         "sine_cosine": (240, 160), "viewport_plane": (200, 160)}
 
 
 def compare(world, lights, w, h, depth=4, label=""):
@@ -151,20 +152,136 @@ def test_default_scene_4k_full_frame_against_oracle(gpu_lib):
 
 
 def test_synthetic_4k_rows_against_oracle(gpu_lib):
-    """configs[2]: 10k triangles + 1k cuboids, 4 lights, 3840x2160 (the benchmark frame): two rows on the oracle."""
+    """configs[2]: 10k triangles + 1k cuboids, 4 lights, 3840x2160 (the benchmark frame, as bench.py renders it): 64
+    stratified rows on the oracle — 48 evenly spaced and 16 drawn at random; every row crosses the columns beneath all
+    four lights (x = +-6 at z = -10 and -26), where the shadow bundles are widest and the block test has the most to lose."""
     world, lights = scenes.synthetic()
     w, h = 3840, 2160
     sc = api.Scene(world, lights)
     rgba, hit = sc.render(w, h)
     st = sc.stats()
     sc.close()
-    assert st["primary_rays"] == w * h and st["tri_tests"] == (w * h + st["shadow_rays"]) * 10000
+    rows = sorted(set(int(r) for r in np.linspace(3, h - 4, 48)) | set(int(r) for r in np.random.default_rng(2160).integers(0, h, 16)))
+    assert len(rows) >= 60
+    assert st["primary_rays"] == w * h and st["bounce_rays"] == 0
+    # counted in the kernels: every primary hit costs at least one record test and one exact evaluation
+    assert st["record_tests"] >= st["exact_evals"] >= int((hit >= 0).sum())
     osc = ob.OracleScene(world, lights)
-    for r0 in (540, 1080):
+    for r0 in rows:
         ref = osc.render(w, h, row0=r0, nrows=1, nthreads=16)
         assert (hit[r0] == ref["hit_id"][0]).all(), f"row {r0}"
         assert (rgba[r0, :, :3] == ref["rgb"][0]).all(), f"row {r0}"
     assert 0.3 < (hit >= 0).mean() < 0.95
+
+
+def test_block_test_on_and_off_agree_on_whole_frames(gpu_lib):
+    """The block test (stage -1) and the guard proofs are conservative filters whose failure would be a silently
+    dropped hit.  With RT_OPT_CULL = 0 every wave scans every block and evaluates every guard box, so whole frames of
+    the two must agree bit for bit: the benchmark frame, a band of the 16384-wide frame, the default scene, the
+    adversarial scene, and a band of configs[4] at its full 7680 x 4320 x 16 spp (two of its rows also on the oracle)."""
+    from raytrace_amd import _lib
+    cases = [("synthetic 4K", scenes.synthetic(), 3840, 2160, 1, 0, 2160),
+             ("synthetic 16K band", scenes.synthetic(), 16384, 16384, 1, 8000, 64),
+             ("default 4K", scenes.default_scene(), 3840, 2160, 1, 0, 2160),
+             ("adversarial", scenes.adversarial(), 1600, 1200, 1, 0, 1200),
+             ("cylinders 8K x 16 spp band", scenes.synthetic_cylinders(), 7680, 4320, 16, 2000, 64)]
+    for label, (world, lights), w, h, spp, row0, nrows in cases:
+        sc = api.Scene(world, lights)
+        on = sc.render(w, h, spp=spp, seed=20260355, row0=row0, nrows=nrows)
+        st_on = sc.stats()
+        sc.set_option(_lib.RT_OPT_CULL, 0)
+        off = sc.render(w, h, spp=spp, seed=20260355, row0=row0, nrows=nrows)
+        st_off = sc.stats()
+        sc.close()
+        assert (on[1] == off[1]).all(), label
+        assert (on[0] == off[0]).all(), label
+        assert st_on["shadow_rays"] == st_off["shadow_rays"]
+        assert st_on["mfma_blocks_primary"] < st_off["mfma_blocks_primary"]      # the switch does switch something
+        if spp == 16:
+            osc = ob.OracleScene(world, lights)
+            for r in (row0 + 5, row0 + 40):
+                ref = osc.render(w, h, spp=spp, seed=20260355, row0=r, nrows=1, nthreads=16)
+                assert (on[1][r - row0] == ref["hit_id"][0]).all() and (on[0][r - row0, :, :3] == ref["rgb"][0]).all(), f"{label} row {r}"
+
+
+def test_arbitrary_fnorm_closures(gpu_lib):
+    """linearInterpolation with `Just fnorm` for fnorms other than main's gaussian (Main.hs:586-605: the sinc and the
+    sine-cosine surfaces): the closure is a host callback on both sides, so results stay bit-identical."""
+    for (world, lights), w, h in ((scenes.sine_cosine(True), 200, 120), (scenes.sinc(True), 160, 100)):
+        ref, hit, rgb = compare(world, lights, w, h, label="fnorm-callback")
+        assert (rgb == ref["rgb"]).all()
+    world, lights = scenes.sine_cosine(True)
+    plain = api.Scene(*scenes.sine_cosine(False)).render(200, 120)
+    with_n = api.Scene(world, lights).render(200, 120)
+    assert (plain[1] == with_n[1]).all() and (plain[0] != with_n[0]).any()      # same hits, other shading
+    osc = ob.OracleScene(world, lights)
+    sc = api.Scene(world, lights)
+    ref = osc.render(90, 60, spp=4, seed=5, nthreads=2)
+    rgba, hit = sc.render(90, 60, spp=4, seed=5)
+    assert (hit == ref["hit_id"]).all() and (rgba[:, :, :3] == ref["rgb"]).all()
+    rgba2, hit2 = sc.render(90, 60, spp=4, seed=5, row0=13, nrows=30)            # a band, as a rank renders it
+    assert (hit2 == hit[13:43]).all() and (rgba2 == rgba[13:43]).all()
+    sc.close()
+
+
+def test_render_multi_equals_single_render(gpu_lib):
+    """rt_render_multi on one device: 1, 3 and 5 bands of measured-cost rows, rendered in place and through the
+    staging buffer + peer copy path, give the bytes of rt_render; statistics cover the whole frame."""
+    from raytrace_amd import _lib
+    world, lights = scenes.synthetic(ntri=600, ncuboid=60)
+    sc = api.Scene(world, lights)
+    w, h = 1000, 531
+    ref_rgba, ref_hit = sc.render(w, h)
+    one = sc.stats()
+    for devices in ([0], [0, 0, 0], [0] * 5):
+        for stage in (0, 1):
+            sc.set_option(_lib.RT_OPT_MULTI_STAGE, stage)
+            rgba, hit = sc.render_multi(w, h, devices)
+            assert (rgba == ref_rgba).all() and (hit == ref_hit).all(), (devices, stage)
+            st = sc.stats()
+            assert st["primary_rays"] == w * h and st["shadow_rays"] == one["shadow_rays"]
+    rgba, none = sc.render_multi(w, h, [0, 0], want_hit=False)
+    assert none is None and (rgba == ref_rgba).all()
+    ref4 = sc.render(w, h, spp=4, seed=3)
+    got4 = sc.render_multi(w, h, [0, 0, 0], spp=4, seed=3)
+    assert (ref4[0] == got4[0]).all() and (ref4[1] == got4[1]).all()
+    with pytest.raises(RuntimeError, match="out of range"):
+        sc.render_multi(w, h, [0, 99])
+    sc.close()
+    world, lights = scenes.mirror_room()
+    sc = api.Scene(world, lights).set_option(_lib.RT_OPT_MULTI_STAGE, 1)
+    ref = sc.render(300, 200, depth=4)
+    got = sc.render_multi(300, 200, [0, 0, 0], depth=4)
+    assert (ref[0] == got[0]).all() and (ref[1] == got[1]).all()
+    sc.close()
+
+
+def test_two_threads_render_distinct_scenes(gpu_lib):
+    """Distinct scenes may be rendered from different threads at once: every (scene, device) pair has
+    its own streams, events and work buffers."""
+    import threading
+    jobs = [(scenes.stacked_cubes(), 320, 240), (scenes.cylinder_axes(), 300, 200), (scenes.synthetic(ntri=600, ncuboid=60), 640, 360)]
+    refs = [api.Scene(w_, l_).render(w, h) for (w_, l_), w, h in jobs]
+    errors = []
+
+    def work(k):
+        try:
+            (world, lights), w, h = jobs[k]
+            sc = api.Scene(world, lights)
+            for _ in range(6):
+                rgba, hit = sc.render(w, h)
+                if not ((rgba == refs[k][0]).all() and (hit == refs[k][1]).all()):
+                    errors.append(f"thread {k}: frame differs")
+            sc.close()
+        except Exception as e:                               # noqa: BLE001
+            errors.append(f"thread {k}: {e!r}")
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(len(jobs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
 
 
 def test_reflection_depths(gpu_lib):
@@ -208,25 +325,24 @@ def test_cpp_main_matches_oracle(gpu_lib, tmp_path):
 
 def test_matrix_core_and_valu_filters_agree_full_size(gpu_lib):
     """Size-independent check at the benchmark sizes: the two first stages are independent conservative filters
-    (bounding cones on the matrix cores; per-leaf linear forms on the vector ALU, RT_FILTER=valu), and the exact
+    (bounding cones on the matrix cores; per-leaf linear forms on the vector ALU, in libraytrace_gpu_valu.so), and the exact
     FP64 stage decides — so whole frames must agree bit for bit, hit IDs and colours."""
     from raytrace_amd import _lib
+    V = _lib.valu_lib()                     # the cross-check build: same sources + the vector-ALU kernel family
+    _lib.check(V.rt_init(0), "rt_init", V)
     cases = [(scenes.synthetic(), 3840, 2160, 1), (scenes.synthetic_cylinders(), 1920, 1080, 4), (scenes.default_scene(), 3840, 2160, 1),
              (scenes.adversarial(), 2048, 1536, 1)]
-    try:
-        for (world, lights), w, h, spp in cases:
-            out = {}
-            for mode in ("mfma", "valu"):
-                os.environ["RT_FILTER"] = mode
-                _lib.check(_lib.lib().rt_init(0), "rt_init")
-                sc = api.Scene(world, lights)
-                out[mode] = sc.render(w, h, spp=spp, seed=7)
-                sc.close()
-            assert (out["mfma"][1] == out["valu"][1]).all()
-            assert (out["mfma"][0] == out["valu"][0]).all()
-    finally:
-        os.environ.pop("RT_FILTER", None)
-        _lib.check(_lib.lib().rt_init(0), "rt_init")
+    for (world, lights), w, h, spp in cases:
+        sc = api.Scene(world, lights)
+        mfma = sc.render(w, h, spp=spp, seed=7)
+        sc.close()
+        sc = api.Scene(world, lights, lib=V).set_option(_lib.RT_OPT_FILTER, 1)
+        valu = sc.render(w, h, spp=spp, seed=7)
+        sc.close()
+        assert (mfma[1] == valu[1]).all()
+        assert (mfma[0] == valu[0]).all()
+    with pytest.raises(RuntimeError):       # the product library has no second kernel family
+        api.Scene(*scenes.planes()).set_option(_lib.RT_OPT_FILTER, 1)
 
 
 def test_adversarial_scene(gpu_lib):
@@ -284,13 +400,13 @@ def test_fuzzed_scenes_against_oracle(gpu_lib):
         assert f"{n} scenes (seed 42" in r.stdout and "), 0 with a mismatch" in r.stdout
 
 
-def test_band_larger_than_one_chunk(gpu_lib, monkeypatch):
+def test_band_larger_than_one_chunk(gpu_lib):
     """A band of more than 16 Mi pixels is rendered in chunks of rows (rt_render_device): rows on both sides of the chunk
     boundary, and the last ragged chunk, against the oracle; a mirror scene too (its chunks are a quarter of the size)."""
-    monkeypatch.setenv("RT_HOST_BANDS", "1")      # rt_render would otherwise cut the frame into copy bands smaller than a chunk
+    from raytrace_amd import _lib
     world, lights = scenes.default_scene()
     w, h = 16384, 4000
-    sc = api.Scene(world, lights)
+    sc = api.Scene(world, lights).set_option(_lib.RT_OPT_HOST_BANDS, 1)   # rt_render would otherwise cut the frame into copy bands smaller than a chunk
     rgba, hit = sc.render(w, h, row0=1500, nrows=1100)             # 18.0 M pixels: chunks of 1024 and 76 rows
     sc.close()
     osc = ob.OracleScene(world, lights)
@@ -299,7 +415,7 @@ def test_band_larger_than_one_chunk(gpu_lib, monkeypatch):
         assert (hit[r - 1500] == ref["hit_id"][0]).all() and (rgba[r - 1500, :, :3] == ref["rgb"][0]).all(), f"row {r}"
     world, lights = scenes.mirror_room()
     w, h = 4096, 1100                                              # 4.5 M pixels: chunks of 1024 and 76 rows when reflective
-    sc = api.Scene(world, lights)
+    sc = api.Scene(world, lights).set_option(_lib.RT_OPT_HOST_BANDS, 1)
     rgba, hit = sc.render(w, h, depth=3)
     sc.close()
     osc = ob.OracleScene(world, lights)
@@ -322,14 +438,15 @@ def test_two_live_scenes_interleaved(gpu_lib):
     a.close(); b.close()
 
 
-def test_host_render_copy_bands_and_page_locked_buffers(gpu_lib, monkeypatch):
+def test_host_render_copy_bands_and_page_locked_buffers(gpu_lib):
     """rt_render enqueues the frame as row bands whose copies to the caller's memory overlap the next band's render:
     every band count gives the same bytes, into pageable and into rt_host_alloc'ed memory, with either output alone,
     with supersampling and with a reflective scene, and the statistics describe the whole frame."""
     world, lights = scenes.synthetic(ntri=600, ncuboid=60)
     sc = api.Scene(world, lights)
+    from raytrace_amd import _lib
     w, h = 1000, 531                                   # ragged: 531 rows are not a multiple of the 8-row tiles
-    monkeypatch.setenv("RT_HOST_BANDS", "1")
+    sc.set_option(_lib.RT_OPT_HOST_BANDS, 1)
     ref_rgba, ref_hit = sc.render(w, h)
     one = sc.stats()
     ref4_rgba, ref4_hit = sc.render(w, h, spp=4, seed=7)
@@ -337,8 +454,8 @@ def test_host_render_copy_bands_and_page_locked_buffers(gpu_lib, monkeypatch):
     ref = osc.render(w, h, row0=300, nrows=8, nthreads=16)
     assert (ref_hit[300:308] == ref["hit_id"]).all() and (ref_rgba[300:308, :, :3] == ref["rgb"]).all()
     pin_rgba, pin_hit = api.host_buffer((h, w, 4), np.uint8), api.host_buffer((h, w), np.int32)
-    for bands in ("2", "3", "5", "8", "100"):
-        monkeypatch.setenv("RT_HOST_BANDS", bands)
+    for bands in (2, 3, 5, 8, 100):
+        sc.set_option(_lib.RT_OPT_HOST_BANDS, bands)
         rgba, hit = sc.render(w, h)
         st = sc.stats()
         assert (rgba == ref_rgba).all() and (hit == ref_hit).all(), bands
@@ -359,12 +476,11 @@ def test_host_render_copy_bands_and_page_locked_buffers(gpu_lib, monkeypatch):
     sc.close()
     world, lights = scenes.mirror_room()
     sc = api.Scene(world, lights)
-    monkeypatch.setenv("RT_HOST_BANDS", "1")
+    sc.set_option(_lib.RT_OPT_HOST_BANDS, 1)
     ref_rgba, ref_hit = sc.render(300, 200, depth=4)
-    monkeypatch.setenv("RT_HOST_BANDS", "4")
+    sc.set_option(_lib.RT_OPT_HOST_BANDS, 4)
     rgba, hit = sc.render(300, 200, depth=4)
     assert (rgba == ref_rgba).all() and (hit == ref_hit).all()
     sc.close()
-    monkeypatch.delenv("RT_HOST_BANDS")
     with pytest.raises(ValueError):
         api.Scene(*scenes.stacked_cubes()).render(64, 64, out_rgba=np.zeros((64, 64, 3), np.uint8))

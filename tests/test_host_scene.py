@@ -209,3 +209,89 @@ def test_limits_and_dialect_errors():
     assert L.rt_scene_prepare_host(h, 16, 16) == 0
     assert L.rt_scene_get_guards(h, 0, None, 0) == 0
     L.rt_scene_destroy(h)
+
+
+def test_c_band_splitter_agrees_with_split_rows():
+    """rt_split_rows (what rt_render_multi cuts its bands with) is a port of distributed.split_rows: same bands."""
+    from raytrace_amd.distributed import split_rows
+    L = _lib.lib()
+    rng = np.random.default_rng(11)
+    for trial in range(300):
+        ncost = int(rng.integers(1, 70))
+        cost = rng.uniform(0, 1, ncost) ** int(rng.integers(1, 4))
+        if trial % 5 == 0:
+            cost[rng.random(ncost) < 0.5] = 0.0                 # plateaus of the cumulative cost
+        if trial % 17 == 0:
+            cost[:] = 0.0                                       # all zero: equal bands
+        h = int(rng.integers(1, 20000))
+        n = int(rng.integers(1, 17))
+        align = int(rng.choice([1, 8, 16]))
+        r0, nr = (C.c_int * n)(), (C.c_int * n)()
+        assert L.rt_split_rows((C.c_double * ncost)(*cost), ncost, h, n, align, r0, nr) == 0
+        assert list(zip(r0, nr)) == split_rows(cost, h, n, align), (trial, ncost, h, n, align)
+        assert sum(nr) == h and r0[0] == 0 and all(r0[k] + nr[k] == r0[k + 1] for k in range(n - 1))
+    assert L.rt_split_rows((C.c_double * 2)(1.0, -1.0), 2, 10, 2, 8, (C.c_int * 2)(), (C.c_int * 2)()) == -1
+
+
+def test_scene_options_and_the_cross_check_build():
+    """Options are per scene (nothing is read from the environment); the vector-ALU kernel family exists in the
+    cross-check build only."""
+    sc = api.Scene(*scenes.planes())
+    sc.set_option(_lib.RT_OPT_CULL, 0).set_option(_lib.RT_OPT_CULL, 1).set_option(_lib.RT_OPT_HOST_BANDS, 3)
+    with pytest.raises(RuntimeError, match="cross-check build"):
+        sc.set_option(_lib.RT_OPT_FILTER, 1)
+    with pytest.raises(RuntimeError, match="unknown option"):
+        sc.set_option(99, 1)
+    with pytest.raises(RuntimeError, match=">= 0"):
+        sc.set_option(_lib.RT_OPT_HOST_BANDS, -1)
+    sc.close()
+    V = _lib.valu_lib()
+    sv = api.Scene(*scenes.planes(), lib=V)
+    sv.set_option(_lib.RT_OPT_FILTER, 1).set_option(_lib.RT_OPT_FILTER, 0)
+    sv.close()
+    assert set(_lib.SYMBOLS) <= {n for n in _lib.SYMBOLS if hasattr(V, n)}
+
+
+def test_changing_the_image_size_rebuilds_the_eye_records_only_when_the_camera_bound_grows():
+    L = _lib.lib()
+    world, lights = scenes.stacked_cubes()
+    sc = api.Scene(world, lights)
+    h = sc.handle
+
+    def records(apex):
+        out = (C.c_float * 16)()
+        rows = []
+        for leaf in range(sc.num_leaves):
+            assert L.rt_scene_get_filter_record(h, apex, leaf, out) == 0
+            rows.append(tuple(out))
+        return rows
+
+    assert L.rt_scene_prepare_host(h, 64, 64) > 0
+    eye, light = records(0), records(1)
+    for w, hh in ((3840, 2160), (1024, 1024), (16, 16), (100, 40)):      # all inside the bound the records were built for
+        assert L.rt_scene_prepare_host(h, w, hh) > 0
+        assert records(0) == eye and records(1) == light
+    assert L.rt_scene_prepare_host(h, 40, 200) > 0                       # a tall image: |posY| goes up to 2.5
+    eye2 = records(0)
+    assert records(1) == light                                           # the light apexes do not depend on the camera
+    assert eye2 != eye
+    margins = [(a[9], b[9]) for a, b in zip(eye, eye2)]
+    assert all(b <= a for a, b in margins)                               # only the margins widen
+    assert all(a[:9] == b[:9] for a, b in zip(eye, eye2))
+    sc.close()
+
+
+def test_normal_callback_registration():
+    L = _lib.lib()
+    seen = []
+    world, lights = api.linearInterpolation(lambda x, y: 0.0, lambda x, y: (seen.append((x, y)) or (0.0, 1.0, 0.0)),
+                                            (-1.0, -1.0), (1.0, 1.0), 0.5, (0.0, -2.0, -10.0), 2.0)
+    sc = api.Scene(world, lights)
+    assert sc.num_leaves == 16 * 2 + 1
+    assert [sc.leaf(i)[1] for i in range(sc.num_leaves)] == [3.0] * 32 + [0.0]      # RT_NORMAL_CALLBACK, then the floor
+    assert seen == []                                                               # only a render calls it
+    assert L.rt_set_normal_callback(sc.handle, 0, 99, (C.c_double * 4)(1, 0, 0, 0), _lib.NORMAL_FN(lambda *a: None), None) == -1
+    assert b"out of bounds" in L.rt_last_error()
+    sc.close()
+    with pytest.raises(TypeError):
+        api.linearInterpolation(lambda x, y: 0.0, "sinc", (-1.0, -1.0), (1.0, 1.0), 0.5, (0.0, -2.0, -10.0), 2.0)

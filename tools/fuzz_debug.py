@@ -25,9 +25,11 @@ ref = osc.render(w, h, depth=depth, spp=spp, seed=K, flags=(spp == 1), want_t=Tr
 refnb = osc.render(w, h, depth=depth, spp=spp, seed=K, use_bbox=0)
 out = {}
 for mode in ("mfma", "valu"):
-    os.environ["RT_FILTER"] = mode
-    _lib.check(_lib.lib().rt_init(0))
-    sc = api.Scene(world, lights)
+    L = _lib.valu_lib() if mode == "valu" else _lib.lib()
+    _lib.check(L.rt_init(0))
+    sc = api.Scene(world, lights, lib=L)
+    if mode == "valu":
+        sc.set_option(_lib.RT_OPT_FILTER, 1)
     out[mode] = sc.render(w, h, depth=depth, spp=spp, seed=K)
     if mode == "mfma":
         for li in range(min(sc.num_leaves, 4)):

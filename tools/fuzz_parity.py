@@ -2,7 +2,7 @@
 """Differential fuzzing of the GPU path against the CPU oracle: random small scenes (triangles, rectangles with arbitrary edge
 vectors, cuboids, cylinders, spheres, mirrors; lights anywhere, also inside and on geometry), random image sizes, depths
 and sample counts.  usage: tools/fuzz_parity.py [nscenes] [seed] [mode]   (GPU box; one line per scene, fails on a mismatch)
-mode: "main" (default), "valu" (the vector-ALU kernels, RT_FILTER=valu), "talk" (Talk.hs dialect: rectangles only),
+mode: "main" (default), "valu" (the vector-ALU kernels of the cross-check build libraytrace_gpu_valu.so), "talk" (Talk.hs dialect: rectangles only),
 "extreme" (scales from 1e-3 to 1e3, geometry around the eye and the viewport plane, degenerate leaves, lights on vertices),
 "big" (90 to 3000 leaves in nested lists, small images), "height" (linearInterpolation height fields with the gaussian
 normals, up to 32 point lights).  Every mode also renders random row bands."""
@@ -163,10 +163,9 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     mode = sys.argv[3] if len(sys.argv) > 3 else "main"
-    if mode == "valu":
-        os.environ["RT_FILTER"] = "valu"
+    L = _lib.valu_lib() if mode == "valu" else _lib.lib()       # "valu": the cross-check build, vector-ALU first stage
     gen = {"main": random_scene, "valu": random_scene, "talk": talk_scene, "extreme": extreme_scene, "big": big_scene, "height": height_scene}[mode]
-    _lib.check(_lib.lib().rt_init(0))
+    _lib.check(L.rt_init(0))
     rng = np.random.default_rng(seed)
     bad = 0
     for i in range(n):
@@ -179,7 +178,9 @@ def main():
         row0 = int(rng.integers(0, h)) if rng.random() < 0.3 else 0          # sometimes a row band, as a rank renders it
         nrows = int(rng.integers(1, h - row0 + 1)) if row0 or rng.random() < 0.2 else h
         ref = ob.OracleScene(world, lights).render(w, h, depth=depth, spp=spp, seed=i, row0=row0, nrows=nrows, flags=(spp == 1))
-        sc = api.Scene(world, lights)
+        sc = api.Scene(world, lights, lib=L)
+        if mode == "valu":
+            sc.set_option(_lib.RT_OPT_FILTER, 1)
         rgba, hit = sc.render(w, h, depth=depth, spp=spp, seed=i, row0=row0, nrows=nrows)
         leaves = sc.num_leaves
         sc.close()

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """PCIe-inclusive timing of rt_render (host buffers) on the benchmark frame, for DESIGN.md §8 (never bench.py's value).
 
-Usage: host_render_timing.py [bands ...]   -- RT_HOST_BANDS values to try (default: the library's own choice)
+Usage: host_render_timing.py [bands ...]   -- RT_OPT_HOST_BANDS values to try (default: the library's own choice)
 Reports pageable (numpy) and page-locked (rt_host_alloc) destinations, buffers allocated once and reused."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -16,7 +16,7 @@ dests = {"pageable": (np.zeros((h, w, 4), np.uint8), np.zeros((h, w), np.int32))
          "page-locked": (api.host_buffer((h, w, 4), np.uint8), api.host_buffer((h, w), np.int32))}
 for bands in (sys.argv[1:] or [""]):
     if bands:
-        os.environ["RT_HOST_BANDS"] = bands
+        sc.set_option(_lib.RT_OPT_HOST_BANDS, int(bands))
     for name, (rgba, hit) in dests.items():
         rgba[:] = 0; hit[:] = 0
         ts = []
