@@ -2137,6 +2137,7 @@ int render_rows(rt_scene *s, DeviceScene &D, const Workspace &W, size_t crow, in
     s->last_device = D.device;
     s->multi_stats = false;
     if (npix == 0) return RT_OK;
+    (void)hipGetLastError();       // kernel launches report through the sticky error: start from a clean one
     // bounce levels: trace n reflects at most n - 1 times (trace 0 = black, Main.hs:542); only scenes with a
     // reflective material ever spawn a reflected ray (Main.hs:553)
     const int levels = render_levels(s, depth);
@@ -2544,7 +2545,7 @@ extern "C" int rt_render_multi(rt_scene *s, int w, int h, int depth, int spp, ui
             if (D.stream && !hip_ok(hipStreamSynchronize((hipStream_t)D.stream), "hipStreamSynchronize") && code == RT_OK) code = RT_ERR_HIP;
             if (D.copy_stream && !hip_ok(hipStreamSynchronize((hipStream_t)D.copy_stream), "hipStreamSynchronize") && code == RT_OK) code = RT_ERR_HIP;
         }
-        for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+        for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
         if (caller >= 0) (void)hipSetDevice(caller);
         t_device = caller;
         return code;

@@ -196,7 +196,9 @@ def test_block_test_on_and_off_agree_on_whole_frames(gpu_lib):
         assert (on[1] == off[1]).all(), label
         assert (on[0] == off[0]).all(), label
         assert st_on["shadow_rays"] == st_off["shadow_rays"]
-        assert st_on["mfma_blocks_primary"] < st_off["mfma_blocks_primary"]      # the switch does switch something
+        assert st_on["mfma_blocks_primary"] <= st_off["mfma_blocks_primary"]
+        if label.startswith("synthetic"):                                        # the switch does switch something
+            assert 20 * st_on["mfma_blocks_primary"] < st_off["mfma_blocks_primary"]
         if spp == 16:
             osc = ob.OracleScene(world, lights)
             for r in (row0 + 5, row0 + 40):
