@@ -212,6 +212,17 @@ int  rt_render_multi(rt_scene *, int w, int h, int depth, int spp, uint64_t seed
  * HIP events on a reduced-scale render of each strip (what rt_render_multi and bench.py cut their bands from). */
 int  rt_scene_row_costs(rt_scene *, int w, int h, int depth, int spp, int ncost, double *cost);
 int  rt_split_rows(const double *cost, int ncost, int h, int n, int align, int *row0, int *nrows);
+/* rt_render_device that ALLOCATES NOTHING.  No counterpart in the reference: it is for callers that cannot call
+ * hipMalloc — code under HIP graph capture, tight serving loops, harnesses that forbid allocation.  Same arguments and
+ * same pixels as rt_render_device; differences: the scene must already be resident on the calling thread's device for
+ * this image size (rt_scene_prepare_device; RT_ERR_ARG otherwise), rt_init must have been called on this thread, and
+ * every work buffer comes from a 64 MiB array in static device memory that each GPU the library runs on holds until
+ * the process ends.  A band whose buffers exceed it is rendered as consecutive sub-bands that fit; an image so wide
+ * that 16 rows of it do not fit (about 45 000 pixels with 4 point lights) is refused with RT_ERR_UNSUPPORTED, as are
+ * scenes with fnorm callbacks.  No kernel times in rt_get_stats (no events are created).  All calls on one GPU share
+ * the array: calls that overlap in time on one GPU race, whatever their streams. */
+int  rt_render_device_noalloc(rt_scene *, int w, int h, int depth, int spp, uint64_t seed,
+                              int row0, int nrows, void *d_rgba, void *d_hit_id, void *stream);
 int  rt_synchronize(void);                      /* waits for everything enqueued on the calling thread's device */
 /* Page-locked host memory for rt_render's output buffers, in place of the reference's storable-vector
  * allocation behind `generateImage` (Main.hs:621 builds the image rt_render now fills).  Optional: any

@@ -73,6 +73,8 @@ SYMBOLS = {
                             C.c_void_p, C.c_void_p]),
     "rt_render_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int,
                                    C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rt_render_device_noalloc": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int,
+                                           C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rt_synchronize": (C.c_int, []),
     "rt_get_stats": (C.c_int, [C.c_void_p, C.POINTER(rt_stats)]),
     "rt_write_bmp": (C.c_int, [C.c_char_p, C.c_void_p, C.c_int, C.c_int]),

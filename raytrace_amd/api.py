@@ -472,6 +472,13 @@ class Scene:
         _lib.check(self._L.rt_render_device(self._h, w, h, depth, spp, seed, row0, nrows, d_rgba, d_hit, stream),
                    "rt_render_device", self._L)
 
+    def render_device_noalloc(self, w, h, d_rgba, d_hit, depth=4, spp=1, seed=0, row0=0, nrows=None, stream=None):
+        """rt_render_device_noalloc: as render_device, but allocates nothing (static device scratch); the scene must
+        have been made resident with prepare(w, h)."""
+        nrows = h - row0 if nrows is None else nrows
+        _lib.check(self._L.rt_render_device_noalloc(self._h, w, h, depth, spp, seed, row0, nrows, d_rgba, d_hit, stream),
+                   "rt_render_device_noalloc", self._L)
+
     def stats(self):
         st = _lib.rt_stats()
         _lib.check(self._L.rt_get_stats(self._h, C.byref(st)))

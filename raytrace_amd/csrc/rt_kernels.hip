@@ -24,6 +24,7 @@
 #include <chrono>
 #include <cmath>
 #include <mutex>
+#include <type_traits>
 #include <cstdio>
 #include <string>
 #include <vector>
@@ -1882,12 +1883,26 @@ __global__ void __launch_bounds__(256) k_cb_gather(const RenderParams P) {
     }
 }
 
+} // namespace
+
+// Scratch of rt_render_device_noalloc (for callers that cannot allocate: HIP graph capture, tight serving loops):
+// every buffer a render needs beyond its inputs and outputs is carved out of this array instead of hipMalloc'ed.
+// Each GPU the library runs on holds its own copy, at its own address, until the process ends.  On the host the name
+// is only a stand-in for HIP_SYMBOL(): the device address comes from hipGetSymbolAddress (device_init), once per device.
+constexpr size_t RT_STATIC_SCRATCH_BYTES = 64u << 20;
+static __device__ __align__(256) unsigned char scratch[RT_STATIC_SCRATCH_BYTES];
+
+namespace {
+
 // ------------------------------------------------------------------------------------------
 // Host side
 
 // Library state per device and per thread.  Everything else lives in the (scene, device) pair: streams, events,
 // uploaded records, work buffers — so distinct scenes can be rendered from different threads.
-struct DeviceCtx { bool ready = false; };
+struct DeviceCtx {
+    bool ready = false;
+    unsigned char *scratch = nullptr;    // this device's copy of `scratch` (hipGetSymbolAddress, with the device current)
+};
 DeviceCtx g_ctx[RT_MAX_DEVICES];
 std::mutex g_ctx_mutex;
 thread_local int t_device = -1;          // the device this thread renders on (rt_init)
@@ -1915,7 +1930,12 @@ int device_init(int device) {
     {
         std::lock_guard<std::mutex> lock(g_ctx_mutex);
         DeviceCtx &C = g_ctx[device];
-        if (!C.ready) C.ready = true;
+        if (!C.ready) {
+            unsigned char *ptr = nullptr;
+            if (!hip_ok(hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch)), "hipGetSymbolAddress(scratch)") || !ptr) return RT_ERR_HIP;
+            C.scratch = ptr;
+            C.ready = true;
+        }
     }
     t_device = device;
     return RT_OK;
@@ -2655,5 +2675,85 @@ extern "C" int rt_render_multi(rt_scene *s, int w, int h, int depth, int spp, ui
     s->stats_multi = tot;
     s->multi_stats = true;
     if (caller >= 0) (void)hipSetDevice(caller);
+    return RT_OK;
+}
+
+namespace {
+
+// Carves the buffers of `n` out of [base, base + cap); returns the bytes used, or 0 if they do not fit.
+size_t ws_carve(unsigned char *base, size_t cap, const WsNeeds &n, Workspace &W) {
+    size_t used = 0;
+    bool fits = true;
+    auto take = [&](auto *&ptr, size_t count) {
+        using T = std::remove_reference_t<decltype(*ptr)>;
+        used = (used + 255) & ~(size_t)255;
+        if (used + count * sizeof(T) > cap) { fits = false; return; }
+        ptr = reinterpret_cast<T *>(base + used);
+        used += count * sizeof(T);
+    };
+    W = Workspace{};
+    take(W.counters, (size_t)RT_STAT_SLOTS * 16);
+    take(W.qcount, (size_t)RT_QCOUNT_WORDS);
+    if (n.hit_id) take(W.hit_id, n.hit_id);
+    if (n.accum) take(W.accum, n.accum);
+    if (n.hitrec) take(W.hitrec, n.hitrec);
+    if (n.lit) take(W.lit, n.lit);
+    if (n.queue) take(W.queue, n.queue);
+    if (n.qsparse) take(W.qsparse, n.qsparse);
+    if (n.tcount) take(W.tcount, n.tcount);
+    if (n.lvl) {
+        take(W.lvl_col[0], n.lvl);
+        for (int k = 1; k < n.levels && k < RT_MAX_LEVELS; ++k) { take(W.lvl_rays[k], n.lvl); take(W.lvl_hit[k], n.lvl); take(W.lvl_col[k], n.lvl); }
+    }
+    return fits ? used : 0;
+}
+
+} // namespace
+
+// rt_render_device without a single allocation: no hipMalloc / hipFree, no event or stream creation.  The scene must be
+// resident already (rt_scene_prepare_device); work buffers come from the static device array `scratch` (64 MiB per GPU).
+// A band that needs more than that is rendered as consecutive sub-bands that each fit; only a frame so wide that 16 rows
+// do not fit is refused.  All calls on one GPU share the array: calls that overlap in time race.
+extern "C" int rt_render_device_noalloc(rt_scene *s, int w, int h, int depth, int spp, uint64_t seed, int row0, int nrows,
+                                        void *d_rgba, void *d_hit_id, void *stream) {
+    int rc;
+    if ((rc = check_render_args(s, w, h, depth, spp, row0, nrows))) return rc;
+    if (t_device < 0) { set_error("rt_render_device_noalloc: call rt_init(device) on this thread first"); return RT_ERR_ARG; }
+    HIP_TRY(hipSetDevice(t_device));
+    DeviceScene &D = s->dev[t_device];
+    if (!host_ready(*s, w, h) || !D.stream || D.version != s->version || D.eye_version != s->eye_version) {
+        set_error("rt_render_device_noalloc: the scene is not resident on this device for this image size: call rt_scene_prepare_device(scene, w, h) first");
+        return RT_ERR_ARG;
+    }
+    if (!s->normal_fn.empty()) { set_error("rt_render_device_noalloc: scenes with fnorm callbacks need host staging and are not supported here"); return RT_ERR_UNSUPPORTED; }
+    if (!levels_supported(s, depth)) return RT_ERR_UNSUPPORTED;
+    if (!d_rgba && !d_hit_id) { set_error("rt_render_device_noalloc: no output buffer"); return RT_ERR_ARG; }
+    const int levels = render_levels(s, depth);
+    unsigned char *base = g_ctx[t_device].scratch;       // the device address, never the array's name
+    // the most rows (all of them, or a multiple of the 16-row set-up tiles) whose buffers fit
+    Workspace W;
+    auto fits = [&](int rows) {
+        return ws_carve(base, RT_STATIC_SCRATCH_BYTES, ws_needs(w, rows, (size_t)rows, s->npoint, levels, spp, d_hit_id == nullptr, d_rgba != nullptr, false), W) != 0;
+    };
+    int rows_fit = nrows;
+    if (nrows > 0 && !fits(nrows)) {
+        int lo = 0, hi = nrows / 16;                       // in units of 16 rows: lo fits (0 = nothing), hi may not
+        while (lo < hi) { const int mid = (lo + hi + 1) / 2; if (fits(mid * 16)) lo = mid; else hi = mid - 1; }
+        rows_fit = lo * 16;
+        if (rows_fit == 0) {
+            set_error("rt_render_device_noalloc: the image is too wide: 16 rows of it need more than the 64 MiB of static scratch");
+            return RT_ERR_UNSUPPORTED;
+        }
+        (void)fits(rows_fit);                              // W = the layout that is used
+    }
+    hipStream_t st = stream ? (hipStream_t)stream : (hipStream_t)D.stream;
+    for (int r = 0; r < nrows; r += rows_fit) {
+        const int rows = nrows - r < rows_fit ? nrows - r : rows_fit;
+        const size_t off = (size_t)r * (size_t)w;
+        if ((rc = render_rows(s, D, W, (size_t)rows, w, h, depth, spp, seed, row0 + r, rows,
+                              d_rgba ? (uint8_t *)d_rgba + 4 * off : nullptr, d_hit_id ? (int32_t *)d_hit_id + off : nullptr,
+                              st, r > 0, false))) return rc;
+    }
+    if (nrows == 0) { D.last_primary = 0; D.ev_used = 0; D.stats_pending = false; }
     return RT_OK;
 }

@@ -798,6 +798,15 @@ bool prepare_host(rt_scene &s, int w, int h) {
     return true;
 }
 
+// Are the records on the host valid for a w x h render as they stand (nothing to rebuild)?
+bool host_ready(const rt_scene &s, int w, int h) {
+    if (s.dirty || s.version == 0) return false;
+    const CameraD cam = fixed_camera(w, h);
+    const double need[3] = {std::fabs(cam.dX) + 2 * std::fabs(cam.scaleX), std::fabs(cam.dY) + 2 * std::fabs(cam.scaleY), std::fabs(cam.d)};
+    for (int i = 0; i < 3; ++i) if (!(need[i] <= s.eye_dmax[i])) return false;
+    return true;
+}
+
 // C port of raytrace_amd/distributed.py: split_rows (the two must agree; tests/test_host_scene.py compares them).
 void split_rows(const double *cost_in, int ncost, int h, int n, int align, int *row0, int *nrows) {
     std::vector<double> cost(cost_in, cost_in + ncost);

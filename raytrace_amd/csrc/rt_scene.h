@@ -137,6 +137,7 @@ double ray_eps();                                         // Main.hs:114
 // (Re)build what a w x h render uploads: guard chains and every apex's records when the scene changed, the eye
 // apex's records alone when only the camera bound grew.  Returns false (and sets the error) on an open bracket.
 bool prepare_host(rt_scene &s, int w, int h);
+bool host_ready(const rt_scene &s, int w, int h);
 // (Re)build the FP32 filter records for the eye of a w x h camera and for every point light.
 void build_filter_records(rt_scene &s, int w, int h, bool eye_only = false);
 // Contiguous row bands of about equal cost (C port of raytrace_amd/distributed.py: split_rows).
