@@ -77,6 +77,7 @@ typedef struct {
     uint64_t mfma_blocks_shadow;  /* the same for k_shadow_mfma, all lights                        */
     uint64_t record_tests;        /* FP32 record tests (second stage), counted in the kernels       */
     uint64_t bounce_rays;         /* reflected rays traced (all levels)                             */
+    uint64_t bounce_blocks;       /* (wave of 256 reflected rays) x (block of 32 leaves) pairs k_general looked at */
     double   prepare_ms;          /* host time of the last rebuild of guard chains and filter records */
     double   upload_ms;           /* host time of the last upload of the scene to this device       */
 } rt_stats;

@@ -21,7 +21,7 @@ class rt_stats(C.Structure):
                 ("rect_pairs", C.c_uint64), ("exact_evals", C.c_uint64), ("ms_primary", C.c_double),
                 ("ms_setup", C.c_double), ("ms_shadow", C.c_double), ("ms_final", C.c_double), ("ms_total", C.c_double),
                 ("mfma_blocks_primary", C.c_uint64), ("mfma_blocks_shadow", C.c_uint64),
-                ("record_tests", C.c_uint64), ("bounce_rays", C.c_uint64), ("prepare_ms", C.c_double), ("upload_ms", C.c_double)]
+                ("record_tests", C.c_uint64), ("bounce_rays", C.c_uint64), ("bounce_blocks", C.c_uint64), ("prepare_ms", C.c_double), ("upload_ms", C.c_double)]
 
 
 # an `fnorm` closure as a C callback: void fn(int n, const double *xy, double *normals, void *user)

@@ -42,7 +42,12 @@ typedef const int32_t RT_CONST *CIntPtr;
 
 #define RT_TILE_W 32
 #define RT_TILE_H 8
-#define RT_WAVES_PER_BLOCK 4
+// One wave per work-group: the wave slots of a 4-wave group only came free when its slowest wave had finished, and the
+// waves of these kernels take between 10 and 200 us; measured on the benchmark frame, a third of the slots sat empty
+// (tools/wave_times.py), 9 % of the frame time.
+#ifndef RT_WAVES_PER_BLOCK
+#define RT_WAVES_PER_BLOCK 1
+#endif
 #ifndef RT_SHADOW_CLIP
 #define RT_SHADOW_CLIP 0       // 1: shadow filter tests "not beyond the ray origin" per leaf (6 more VALU per 4 rays)
 #endif
@@ -103,6 +108,7 @@ struct RenderParams {
     int32_t *cb_group;              // per list entry: which callback
     const double *cb_normal;        // per list entry: fnorm x y
     unsigned *cb_count;             // entries in the list
+    unsigned long long *dbg;        // -DRT_WAVE_TIMES builds only (tools/wave_times.py): per-wave timeline records
     // bounce levels (reflective scenes, trace depth > 1; Main.hs:546-556).  A "slot" is a pixel of the chunk at
     // level 0 and an entry of the level's ray list above it.
     const RayRec *rays;             // this level's rays (nullptr at level 0: camera rays)
@@ -110,8 +116,12 @@ struct RenderParams {
     RayRec *next_rays;              // where k_final appends the reflected rays (nullptr: none)
     unsigned *next_count;
     uint32_t *colour;               // per-slot colour of this level (nullptr: write RGBA8 / accum directly)
-    const GenRec *gen_tri;          // general-ray filter records
+    const GenRec *gen_tri;          // general-ray filter records, in a space-filling order of the leaves (rt_scene.cpp: spatial_order)
     const GenRec *gen_rect;
+    const int32_t *gen_tri_gid;     // position in that order -> leaf index
+    const int32_t *gen_rect_gid;
+    const float *gen_tri_sph;       // bounding sphere of every block of 32 consecutive records: centre xyz, radius (inf: always scan)
+    const float *gen_rect_sph;
     CameraD cam;
     double eps;
     int ntri, nrect, nsph, nlights, nleaves, npoint;
@@ -122,6 +132,7 @@ struct RenderParams {
     int row0, nrows;                // this chunk: first absolute image row, rows
     long long out_off;              // index of the chunk's first pixel inside the band-local outputs
     int qcap;                       // pixels in the chunk = capacity of one shadow queue
+    int lcap;                       // capacity of a bounce level's ray list: the chunk's pixels padded to whole 32 x 8 tiles
     int spp, sample;
     int talk;                       // 1: the rules of src/Talk.hs (rt_scene_set_dialect)
     uint32_t seed_lo, seed_hi;
@@ -193,10 +204,31 @@ __device__ __forceinline__ void stat_add(const RenderParams &P, int k, unsigned 
     const unsigned wave = (blockIdx.x + blockIdx.y * gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
     atomicAdd(&P.counters[(size_t)(wave % RT_STAT_SLOTS) * 16 + k], v);
 }
+#ifdef RT_WAVE_TIMES
+// measurement builds: one record per wave {kernel | light << 8, wave, start, end (100 MHz wall clock), blocks scanned,
+// record tests, exact evaluations, hardware id}; dbg[0] counts the records
+__device__ __forceinline__ void wave_record(const RenderParams &P, unsigned kernel, unsigned wave, unsigned long long t0,
+                                            unsigned nblocks, unsigned nrec, unsigned nexact, const unsigned long long (&ph)[3]) {
+    if (!P.dbg || (threadIdx.x & 63u) != 0u) return;
+    const unsigned long long t1 = wall_clock64();
+    const unsigned long long k = atomicAdd(&P.dbg[0], 1ull);
+    if (k >= (1ull << 20)) return;
+    unsigned long long *r = P.dbg + 8 + 8 * k;
+    r[0] = kernel; r[1] = wave; r[2] = t0; r[3] = t1;
+    r[4] = (unsigned long long)nblocks | ((unsigned long long)nrec << 16) | ((unsigned long long)nexact << 40);
+    r[5] = ph[0]; r[6] = ph[1]; r[7] = ph[2];      // phase boundaries: after the ray set-up, after bound + guard proofs, after the scan
+}
+#define RT_WAVE_T0 const unsigned long long wave_t0 = wall_clock64(); unsigned long long wave_ph[3] = {0, 0, 0};
+#define RT_WAVE_PHASE(k) wave_ph[k] = wall_clock64();
+#else
+#define RT_WAVE_T0
+#define RT_WAVE_PHASE(k)
+#endif
+
 __device__ __forceinline__ unsigned num_slots(const RenderParams &P) {
     if (!P.count_ptr) return (unsigned)P.qcap;
     const unsigned c = *P.count_ptr;
-    return c < (unsigned)P.qcap ? c : (unsigned)P.qcap;
+    return c < (unsigned)P.lcap ? c : (unsigned)P.lcap;
 }
 // the ray of a slot: `cast camera x y` at level 0, `mkray (ipos + 1e-5 rdir) rdir` (Main.hs:552) above
 __device__ __forceinline__ RayD slot_ray(const RenderParams &P, int slot) {
@@ -1063,20 +1095,40 @@ __device__ __forceinline__ unsigned step_bits(const f32x16 acc) {
 // are taken off 64 at a time, so that every lane of the wave works on one: stage1 (the FP32 record test) sends its
 // survivors to a second queue, whose entries go through the exact FP64 evaluation, again 64 at a time.  Without the
 // queues those two stages ran on the few lanes that happened to hold a candidate (5 % of the lanes on average).
-// entry = (position in the MFMA leaf stream << 8) | ray of the wave (0..255).  The counts are wave-uniform.
+//   q1 entry = (position in the MFMA leaf stream << 8) | ray of the wave (0..255); q1 only ever holds entries of the
+//   block whose records are staged in `rec` (it is emptied before the next block with candidates is looked at);
+//   q2 entry = (leaf index << 9) | (leaf kind << 8) | ray: everything the exact stage needs, so it survives the block.
+// The counts are wave-uniform.
+// `rec`: the FP32 records of the 32 leaves of the current block, structure-of-arrays (c[k] of row r at rec[32 k + r]).
+// They arrive with ONE coalesced 2 KiB load per block (32 bytes per lane) instead of a 64-byte gather per candidate:
+// a gather of 64 different lines costs the CU's address path about 64 cycles per instruction, and with four of them
+// per batch of 64 candidates that path, shared by all waves of the CU, was what the kernels were waiting for.  Read
+// back, lanes with different rows hit different LDS banks and lanes with the same row share a broadcast.
 constexpr int RT_Q1_CAP = 128, RT_Q2_CAP = 128;
 struct WaveQueues {
     uint32_t *q1, *q2;
     unsigned n1, n2;
     unsigned nrec;                  // FP32 record tests so far (statistics)
+    float *rec;                     // 16 x 32 floats
+#ifdef RT_WAVE_TIMES
+    unsigned long long t_s1 = 0, t_ex = 0, t_bits = 0, t_loop = 0;   // 100 MHz ticks spent in stage 1, exact, bit extraction, queueing loop
+#endif
 };
+#ifdef RT_WAVE_TIMES
+#define RT_TICK(var) const unsigned long long var = wall_clock64();
+#define RT_TOCK(acc, var) acc += wall_clock64() - var;
+#else
+#define RT_TICK(var)
+#define RT_TOCK(acc, var)
+#endif
 __device__ __forceinline__ void q_push(uint32_t *q, unsigned &n, bool pred, uint32_t entry) {
     const unsigned long long m = __builtin_amdgcn_ballot_w64(pred);
     if (pred) q[n + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = entry;
     n += (unsigned)__popcll(m);
 }
+// Works q1 down to `keep` entries; flush2: also the exact stage's last partial batch (end of the scan).
 template <class S1, class EX>
-__device__ __forceinline__ void q_drain(WaveQueues &Q, unsigned keep, S1 &&stage1, EX &&exact) {
+__device__ __forceinline__ void q_drain(WaveQueues &Q, unsigned keep, bool flush2, S1 &&stage1, EX &&exact) {
     const unsigned lane = threadIdx.x & 63u;
     while (Q.n1 > keep) {
         const unsigned take = Q.n1 < 64u ? Q.n1 : 64u;
@@ -1084,18 +1136,25 @@ __device__ __forceinline__ void q_drain(WaveQueues &Q, unsigned keep, S1 &&stage
         Q.nrec += take;
         const bool have = lane < take;
         const uint32_t entry = have ? Q.q1[Q.n1 + lane] : 0u;
-        const bool pass = have && stage1(entry);
-        q_push(Q.q2, Q.n2, pass, entry);
+        uint32_t entry2 = 0u;
+        RT_TICK(ts)
+        const bool pass = have && stage1(entry, entry2);
+        q_push(Q.q2, Q.n2, pass, entry2);
+        RT_TOCK(Q.t_s1, ts)
         if (Q.n2 >= 64u) {
             Q.n2 -= 64u;
+            RT_TICK(te)
             exact(Q.q2[Q.n2 + lane]);
+            RT_TOCK(Q.t_ex, te)
         }
     }
-    if (keep == 0u && Q.n2 > 0u) {
+    if (flush2 && Q.n2 > 0u) {
         const bool have = lane < Q.n2;
         const uint32_t entry = have ? Q.q2[lane] : 0u;
         Q.n2 = 0u;
+        RT_TICK(te)
         if (have) exact(entry);
+        RT_TOCK(Q.t_ex, te)
     }
 }
 // Scans the n blocks (a multiple of 3) whose indices are list[0..n-1]; list[n] and list[n + 1] must name a block too (the
@@ -1104,7 +1163,7 @@ __device__ __forceinline__ void q_drain(WaveQueues &Q, unsigned keep, S1 &&stage
 // The A fragments live in a ring of three registers (in use, next, in flight) and the loop body is written out three
 // times, so a fragment is loaded straight into the register it is used from: no copies, two blocks of prefetch.
 template <class S1, class EX>
-__device__ __forceinline__ void mfma_scan(const i32x4 *base, const uint16_t *list, int n, const f16x8 (&B)[8], WaveQueues &Q, int c, int h,
+__device__ __forceinline__ void mfma_scan(const i32x4 *base, const FilterRec *recs, const uint16_t *list, int n, const f16x8 (&B)[8], WaveQueues &Q, int c, int h,
                                           S1 &&stage1, EX &&exact) {
     auto idx = [&](int k) { return __builtin_amdgcn_readfirstlane((int)list[k]); };      // the same for every lane
     auto blk = [&](int g) { return (base + (size_t)g * 32)[c]; };      // uniform base + lane offset
@@ -1131,6 +1190,12 @@ __device__ __forceinline__ void mfma_scan(const i32x4 *base, const uint16_t *lis
         if (mx == 0x7fffffff)
 #endif
         if (__builtin_amdgcn_ballot_w64(mx > 0)) {       // wave-uniform: every lane takes part in the MFMAs below
+            // the records of this block's 32 leaves: 2 KiB, 32 bytes per lane (lane l: half l & 1 of record l >> 1); the
+            // load is in flight while the pass bits are worked out
+            const int ln = (int)(threadIdx.x & 63u);
+            const float4 *rsrc = reinterpret_cast<const float4 *>(recs + (size_t)g * MF_LEAVES) + 2 * ln;
+            const float4 r0 = rsrc[0], r1 = rsrc[1];
+            RT_TICK(tb)
             unsigned long long lo = 0, hi = 0;      // bit 16 b + q: ray block b passes the leaf of accumulator register q
 #pragma unroll
             for (int b = 0; b < 8; ++b)
@@ -1138,6 +1203,14 @@ __device__ __forceinline__ void mfma_scan(const i32x4 *base, const uint16_t *lis
                     const unsigned long long sb = (unsigned long long)step_bits(mfma0(a_use, B[b])) << (16 * (b & 3));
                     if (b < 4) lo |= sb; else hi |= sb;
                 }
+            {
+                float *dst = Q.rec + (ln & 1) * 8 * 32 + (ln >> 1);
+                dst[0 * 32] = r0.x; dst[1 * 32] = r0.y; dst[2 * 32] = r0.z; dst[3 * 32] = r0.w;
+                dst[4 * 32] = r1.x; dst[5 * 32] = r1.y; dst[6 * 32] = r1.z; dst[7 * 32] = r1.w;
+                __builtin_amdgcn_wave_barrier();
+            }
+            RT_TOCK(Q.t_bits, tb)
+            RT_TICK(tl)
             // one entry per lane and round; register q of lane half h is row (q & 3) + 8 (q >> 2) + 4 h of the block
             const uint32_t k0 = (uint32_t)(g * MF_LEAVES + 4 * h);
             while (__builtin_amdgcn_ballot_w64((lo | hi) != 0ull)) {
@@ -1147,8 +1220,11 @@ __device__ __forceinline__ void mfma_scan(const i32x4 *base, const uint16_t *lis
                 const int b = (k >> 4) + (first ? 0 : 4), q = k & 15;
                 q_push(Q.q1, Q.n1, any, ((k0 + (uint32_t)((q & 3) + 8 * (q >> 2))) << 8) | (uint32_t)(b * 32 + c));
                 if (first) lo &= lo - 1ull; else hi &= hi - 1ull;
-                q_drain(Q, 63u, stage1, exact);
+                q_drain(Q, 63u, false, stage1, exact);
             }
+            q_drain(Q, 0u, false, stage1, exact);       // q1 is empty before `rec` is overwritten
+            __builtin_amdgcn_wave_barrier();
+            RT_TOCK(Q.t_loop, tl)
         }
     };
     for (int k = 0; k < n; k += 3) {
@@ -1188,46 +1264,70 @@ __device__ __forceinline__ void store_bundle(float *bun, const float p[3], const
 // `groups` is the first padding block (never rows): it fills the list up to a multiple of 3 and feeds the prefetch.
 constexpr int RT_LIST_CAP = 192;
 template <class S1, class EX>
-__device__ __forceinline__ void culled_scan(const i32x4 *base, const float *cones, int groups, const float *bun, uint16_t *list,
+__device__ __forceinline__ void culled_scan(const i32x4 *base, const FilterRec *recs, const float *cones, int groups, const float *bun, uint16_t *list,
                                             const f16x8 (&B)[8], WaveQueues &Q, int c, int h, unsigned &nblocks, S1 &&stage1, EX &&exact) {
     const int lane = (int)(threadIdx.x & 63u);
     int n = 0;                                                    // wave-uniform
-    for (int g0 = 0; g0 < groups; g0 += 64) {
-        const int g = g0 + lane;
-        bool pass = g < groups;
-        if (pass && bun[17] != 0.f) {
-            const float4 k = reinterpret_cast<const float4 *>(cones)[2 * g];
-            const float sT = cones[8 * g + 4], code = cones[8 * g + 5];          // code 1: never, 2: always
-            const float cr = bun[15], sr = bun[16];
-            // the block's cone (axis k.xyz, half-angle T) meets the capsule iff its axis lies within T + rho of the arc
-            const float cc = __builtin_fmaf(cr, k.w, -(sr * sT)) - 4e-6f;         // cos(T + rho), low side
-            const float ss = __builtin_fmaf(sr, k.w, cr * sT) + 4e-6f;            // sin(T + rho), high side
-            bool geo = cc <= 0.f;                                                  // T + rho >= 90 degrees
-            geo |= __builtin_fmaf(bun[0], k.x, __builtin_fmaf(bun[1], k.y, bun[2] * k.z)) >= cc;
-            if (bun[18] != 0.f) {
-                geo |= __builtin_fmaf(bun[3], k.x, __builtin_fmaf(bun[4], k.y, bun[5] * k.z)) >= cc;
-                // between the end points (taken generously: beyond them the great circle is nearer than the arc)
-                const bool between = __builtin_fmaf(bun[9], k.x, __builtin_fmaf(bun[10], k.y, bun[11] * k.z)) >= -1e-3f
-                                   && __builtin_fmaf(bun[12], k.x, __builtin_fmaf(bun[13], k.y, bun[14] * k.z)) >= -1e-3f;
-                geo |= between && __builtin_fabsf(__builtin_fmaf(bun[6], k.x, __builtin_fmaf(bun[7], k.y, bun[8] * k.z))) <= ss;
-            }
-            pass = code == 2.f || (code == 0.f && geo);
+    // the wave's bound, once, as scalars (it is the same for every lane)
+    float bn[19];
+#pragma unroll
+    for (int k = 0; k < 19; ++k) bn[k] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(bun[k])));
+    const bool test = bn[17] != 0.f, arc = bn[18] != 0.f;
+    const float cr = bn[15], sr = bn[16];
+    const float4 *cones4 = reinterpret_cast<const float4 *>(cones);
+    // Four rounds of 64 blocks at a time: their cones are loaded together (one trip to the L2 instead of four; with one
+    // round per trip the 8 rounds of a 500-block stream were 4 us of a 40 us wave), then tested and listed in order.
+    for (int g0 = 0; g0 < groups; g0 += 256) {
+        float4 ka[4], kb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int g = g0 + 64 * u + lane;
+            const int gg = g < groups ? g : 0;
+            ka[u] = cones4[2 * gg]; kb[u] = cones4[2 * gg + 1];          // {axis xyz, cos T}, {sin T, code, 0, 0}
         }
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
-        if (pass) list[n + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = (uint16_t)g;
-        n += (int)__popcll(m);
-        if (n > RT_LIST_CAP - 64 || g0 + 64 >= groups) {
-            nblocks += (unsigned)n;
-            if (n > 0) {
-                if (lane < 5) list[n + lane] = (uint16_t)groups;  // up to a multiple of 3, then two blocks of prefetch
-                __builtin_amdgcn_wave_barrier();
-                mfma_scan(base, list, (n + 2) / 3 * 3, B, Q, c, h, stage1, exact);
-                __builtin_amdgcn_wave_barrier();
+        unsigned long long mk[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int g = g0 + 64 * u + lane;
+            bool pass = g < groups;
+            if (pass && test) {
+                const float4 k = ka[u];
+                const float sT = kb[u].x, code = kb[u].y;              // code 1: never, 2: always
+                // the block's cone (axis k.xyz, half-angle T) meets the capsule iff its axis lies within T + rho of the arc
+                const float cc = __builtin_fmaf(cr, k.w, -(sr * sT)) - 4e-6f;         // cos(T + rho), low side
+                const float ss = __builtin_fmaf(sr, k.w, cr * sT) + 4e-6f;            // sin(T + rho), high side
+                bool geo = cc <= 0.f;                                                  // T + rho >= 90 degrees
+                geo |= __builtin_fmaf(bn[0], k.x, __builtin_fmaf(bn[1], k.y, bn[2] * k.z)) >= cc;
+                if (arc) {
+                    geo |= __builtin_fmaf(bn[3], k.x, __builtin_fmaf(bn[4], k.y, bn[5] * k.z)) >= cc;
+                    // between the end points (taken generously: beyond them the great circle is nearer than the arc)
+                    const bool between = __builtin_fmaf(bn[9], k.x, __builtin_fmaf(bn[10], k.y, bn[11] * k.z)) >= -1e-3f
+                                       && __builtin_fmaf(bn[12], k.x, __builtin_fmaf(bn[13], k.y, bn[14] * k.z)) >= -1e-3f;
+                    geo |= between && __builtin_fabsf(__builtin_fmaf(bn[6], k.x, __builtin_fmaf(bn[7], k.y, bn[8] * k.z))) <= ss;
+                }
+                pass = code == 2.f || (code == 0.f && geo);
             }
-            n = 0;
+            mk[u] = __builtin_amdgcn_ballot_w64(pass);
+        }
+#pragma unroll 1
+        for (int u = 0; u < 4 && g0 + 64 * u < groups; ++u) {          // (not unrolled: one copy of the scan)
+            const unsigned long long m = u == 0 ? mk[0] : (u == 1 ? mk[1] : (u == 2 ? mk[2] : mk[3]));
+            const int g = g0 + 64 * u + lane;
+            if ((m >> lane) & 1ull) list[n + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = (uint16_t)g;
+            n += (int)__popcll(m);
+            if (n > RT_LIST_CAP - 64 || g0 + 64 * u + 64 >= groups) {
+                nblocks += (unsigned)n;
+                if (n > 0) {
+                    if (lane < 5) list[n + lane] = (uint16_t)groups;  // up to a multiple of 3, then two blocks of prefetch
+                    __builtin_amdgcn_wave_barrier();
+                    mfma_scan(base, recs, list, (n + 2) / 3 * 3, B, Q, c, h, stage1, exact);
+                    __builtin_amdgcn_wave_barrier();
+                }
+                n = 0;
+            }
         }
     }
-    q_drain(Q, 0u, stage1, exact);
+    q_drain(Q, 0u, true, stage1, exact);
 }
 // FP32 record test of ONE ray (the second stage, rare path): the exact shape of the leaf, same margins as filter4.
 __device__ __forceinline__ bool record_test(const FilterRec *R, int kind, float x, float y, float z) {
@@ -1239,6 +1339,17 @@ __device__ __forceinline__ bool record_test(const FilterRec *R, int kind, float 
     return zz >= R->c[9];
 }
 
+// the same on a record staged in LDS (WaveQueues::rec), row = the leaf's row in its block
+__device__ __forceinline__ bool record_test_staged(const float *rec, int row, int kind, float x, float y, float z) {
+    const float *R = rec + row;
+    const float q1 = __builtin_fmaf(R[0 * 32], x, __builtin_fmaf(R[1 * 32], y, R[2 * 32] * z));
+    const float q2 = __builtin_fmaf(R[3 * 32], x, __builtin_fmaf(R[4 * 32], y, R[5 * 32] * z));
+    const float n = __builtin_fmaf(R[6 * 32], x, __builtin_fmaf(R[7 * 32], y, R[8 * 32] * z));
+    const float zz = kind == LEAF_TRI ? __builtin_fminf(__builtin_fminf(q1, q2), n)
+                                      : n - __builtin_fmaxf(__builtin_fabsf(q1), __builtin_fabsf(q2));
+    return zz >= R[9 * 32];
+}
+
 #ifndef RT_WAVES_EU_MFMA
 #define RT_WAVES_EU_MFMA 3
 #endif
@@ -1246,6 +1357,7 @@ __device__ __forceinline__ bool record_test(const FilterRec *R, int kind, float 
 // Kernel 3 on the matrix cores.  Lane (c = lane & 31, h = lane >> 5): ray column c of each of the wave's 8 ray
 // blocks, half of the leaves of each leaf block.
 __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_shadow_mfma(const RenderParams P) {
+    RT_WAVE_T0
     const int pl = (int)blockIdx.y;
     const unsigned count = P.qcount[pl];
     const unsigned wave = blockIdx.x * RT_WAVES_PER_BLOCK + (threadIdx.x >> 6);
@@ -1262,6 +1374,7 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_shadow_mfma(const RenderParams P) {
     __shared__ uint32_t s_q1[RT_WAVES_PER_BLOCK][RT_Q1_CAP], s_q2[RT_WAVES_PER_BLOCK][RT_Q2_CAP];
     __shared__ uint16_t s_list[RT_WAVES_PER_BLOCK][RT_LIST_CAP + 8];
     __shared__ float s_bun[RT_WAVES_PER_BLOCK][RT_BUNDLE_FLOATS];
+    __shared__ float s_rec[RT_WAVES_PER_BLOCK][16 * 32];
     const int wv = (int)(threadIdx.x >> 6);
     f16x8 B[8];
     float ux[8], uy[8], uz[8];              // unit directions of the lane's 8 rays (0: no ray), for the bundle cone
@@ -1304,6 +1417,7 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_shadow_mfma(const RenderParams P) {
         ux[b] = dx * rn; uy[b] = dy * rn; uz[b] = dz * rn;
     }
     __builtin_amdgcn_wave_barrier();
+    RT_WAVE_PHASE(0)
     // bound of the wave's directions (both lane halves hold the same rays): p = the ray farthest from the mean direction,
     // q = the ray farthest from p, rho = the largest distance of a ray from the arc p..q
     {
@@ -1378,29 +1492,30 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_shadow_mfma(const RenderParams P) {
             }
         passed = bundle_guard_mask(P, Lt, olo, ohi);
     }
+    RT_WAVE_PHASE(1)
     const size_t ro = (size_t)__builtin_amdgcn_readfirstlane(Lt.rec_offset);
     const size_t gstride = (size_t)(P.mf_groups + 2);
     const i32x4 *blocks = reinterpret_cast<const i32x4 *>(P.mf_rows) + ro * gstride * 32;
     const FilterRec *recs = P.mf_rec + ro * gstride * MF_LEAVES;
     unsigned nexact = 0, nblocks = 0;
-    WaveQueues Q = {s_q1[wv], s_q2[wv], 0u, 0u, 0u};
-    culled_scan(blocks, P.mf_cone + ro * gstride * 8, P.mf_groups, s_bun[wv], s_list[wv], B, Q, c, h, nblocks,
-        [&](uint32_t entry) -> bool {           // FP32 record test of one (ray, leaf) pair
-            const int e = (int)(entry & 255u);
-            const FilterRec *R = recs + (entry >> 8);
+    WaveQueues Q = {s_q1[wv], s_q2[wv], 0u, 0u, 0u, s_rec[wv]};
+    culled_scan(blocks, recs, P.mf_cone + ro * gstride * 8, P.mf_groups, s_bun[wv], s_list[wv], B, Q, c, h, nblocks,
+        [&](uint32_t entry, uint32_t &entry2) -> bool {           // FP32 record test of one (ray, leaf) pair
+            const int e = (int)(entry & 255u), row = (int)((entry >> 8) & 31u);
+            const float *R = Q.rec + row;
             if (s_occ[wv][e]) return false;
             const float dx = s_d[wv][0][e], dy = s_d[wv][1][e], dz = s_d[wv][2][e];
-            const int kind = __float_as_int(R->c[14]), gid = __float_as_int(R->c[15]);
-            if (gid < 0 || !record_test(R, kind, dx, dy, dz)) return false;
+            const int kind = __float_as_int(R[14 * 32]), gid = __float_as_int(R[15 * 32]);
+            if (gid < 0 || !record_test_staged(Q.rec, row, kind, dx, dy, dz)) return false;
             // only leaves between the light and the origin: N.D >= Kq (Main.hs:474 needs t <= distance)
-            if (!(__builtin_fmaf(R->c[11], dx, __builtin_fmaf(R->c[12], dy, R->c[13] * dz)) >= R->c[10])) return false;
+            if (!(__builtin_fmaf(R[11 * 32], dx, __builtin_fmaf(R[12 * 32], dy, R[13 * 32] * dz)) >= R[10 * 32])) return false;
+            entry2 = ((uint32_t)gid << 9) | ((uint32_t)kind << 8) | (uint32_t)e;
             // the hit leaf itself lies 1e-5 behind the shadow-ray origin (Main.hs:472): t < 0
             return s_own[wv][e] != gid;
         },
         [&](uint32_t entry) {                   // exact: intersect world ray_to_light, t <= distance (Main.hs:472-474)
             const int e = (int)(entry & 255u);
-            const FilterRec *R = recs + (entry >> 8);
-            const int kind = __float_as_int(R->c[14]), gid = __float_as_int(R->c[15]);
+            const int kind = (int)((entry >> 8) & 1u), gid = (int)(entry >> 9);
             const LeafD &L = P.leaves[gid];
             const HitRec H = P.hitrec[s_pix[wv][e]];
             double tx, ty, tz;
@@ -1417,6 +1532,7 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_shadow_mfma(const RenderParams P) {
             }
         });
     __builtin_amdgcn_wave_barrier();
+    RT_WAVE_PHASE(2)
     // lane (c, h) finishes the rays (4h + r, c): spheres with the scalar-record loop, then the lit bits
     uint32_t pix[4]; bool nd[4];
 #pragma unroll
@@ -1443,17 +1559,23 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_shadow_mfma(const RenderParams P) {
     if (lane == 0 && nexact) stat_add(P, 2, (unsigned long long)nexact);
     if (lane == 0) stat_add(P, 7, (unsigned long long)nblocks);
     if (lane == 0 && Q.nrec) stat_add(P, 4, (unsigned long long)Q.nrec);
+#ifdef RT_WAVE_TIMES
+    wave_ph[2] = (Q.t_s1 & 0xffff) | ((Q.t_ex & 0xffff) << 16) | ((Q.t_bits & 0xffff) << 32) | ((Q.t_loop & 0xffff) << 48);
+    wave_record(P, 1u | ((unsigned)pl << 8), wave, wave_t0, nblocks, Q.nrec, nexact, wave_ph);
+#endif
 }
 
 // Kernel 1 on the matrix cores.  One wave = 32 x 8 pixel tile; ray block b = tile row b, column c = lane & 31.
 // The nearest hit of every pixel of the tile lives in LDS: t as the bit pattern of the double (t >= 0, so the
 // patterns order like the values) and the leaf index.
 __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_primary_mfma(const RenderParams P) {
+    RT_WAVE_T0
     __shared__ unsigned long long s_bt[RT_WAVES_PER_BLOCK][256];
     __shared__ int s_bid[RT_WAVES_PER_BLOCK][256];
     __shared__ uint32_t s_q1[RT_WAVES_PER_BLOCK][RT_Q1_CAP], s_q2[RT_WAVES_PER_BLOCK][RT_Q2_CAP];
     __shared__ uint16_t s_list[RT_WAVES_PER_BLOCK][RT_LIST_CAP + 8];
     __shared__ float s_bun[RT_WAVES_PER_BLOCK][RT_BUNDLE_FLOATS];
+    __shared__ float s_rec[RT_WAVES_PER_BLOCK][16 * 32];
     const int wv = (int)(threadIdx.x >> 6);
     const int wave = (int)(blockIdx.x * RT_WAVES_PER_BLOCK) + wv;
     const int lane = (int)(threadIdx.x & 63), c = lane & 31, h = lane >> 5;
@@ -1476,6 +1598,7 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_primary_mfma(const RenderParams P) {
         if (h == 0) { bt[b * 32 + c] = ~0ull; bid[b * 32 + c] = -1; }
     }
     __builtin_amdgcn_wave_barrier();
+    RT_WAVE_PHASE(0)
     const i32x4 *blocks = reinterpret_cast<const i32x4 *>(P.mf_rows);          // apex 0 = the eye
     // bundle cone of the tile: axis through its centre, half-angle to the farthest corner (the directions inside a cone
     // cut the image plane in a convex region, so the corners decide); one pixel of slack all round covers the jitter
@@ -1496,28 +1619,29 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_primary_mfma(const RenderParams P) {
     }
     __builtin_amdgcn_wave_barrier();
     const unsigned long long passed = P.nguard_cached > 0 ? tile_guard_mask(P, x0, P.row0 + ly0) : 0ull;
+    RT_WAVE_PHASE(1)
     unsigned nexact = 0, nblocks = 0;
-    WaveQueues Q = {s_q1[wv], s_q2[wv], 0u, 0u, 0u};
+    WaveQueues Q = {s_q1[wv], s_q2[wv], 0u, 0u, 0u, s_rec[wv]};
 #ifdef RT_X_NOSCAN
     if (P.w < 0)
 #endif
-    culled_scan(blocks, P.mf_cone, P.mf_groups, s_bun[wv], s_list[wv], B, Q, c, h, nblocks,
-        [&](uint32_t entry) -> bool {           // FP32 record test of one (pixel, leaf) pair
-            const int e = (int)(entry & 255u);
-            const FilterRec *R = P.mf_rec + (entry >> 8);                         // apex 0 = the eye
+    culled_scan(blocks, P.mf_rec, P.mf_cone, P.mf_groups, s_bun[wv], s_list[wv], B, Q, c, h, nblocks,
+        [&](uint32_t entry, uint32_t &entry2) -> bool {           // FP32 record test of one (pixel, leaf) pair
+            const int e = (int)(entry & 255u), row = (int)((entry >> 8) & 31u);
+            const float *R = Q.rec + row;                                          // apex 0 = the eye
             const int xe = x0 + (e & 31), ye = P.row0 + ly0 + (e >> 5);
-            const int kind = __float_as_int(R->c[14]), gid = __float_as_int(R->c[15]);
+            const int kind = __float_as_int(R[14 * 32]), gid = __float_as_int(R[15 * 32]);
             double ox, oy;
             sample_offset(P, xe, ye, ox, oy);
             const float px = (float)(P.cam.scaleX * ((double)xe + ox) + P.cam.dX);
             const float py = (float)(P.cam.scaleY * ((double)ye + oy) + P.cam.dY);
+            entry2 = ((uint32_t)gid << 9) | ((uint32_t)kind << 8) | (uint32_t)e;
             // eye records are affine in (posX, posY): the z column already holds c_z * d
-            return gid >= 0 && record_test(R, kind, px, py, 1.0f);
+            return gid >= 0 && record_test_staged(Q.rec, row, kind, px, py, 1.0f);
         },
         [&](uint32_t entry) {                   // exact: intersect leaf (cast camera x y), Main.hs:543
             const int e = (int)(entry & 255u);
-            const FilterRec *R = P.mf_rec + (entry >> 8);
-            const int kind = __float_as_int(R->c[14]), gid = __float_as_int(R->c[15]);
+            const int kind = (int)((entry >> 8) & 1u), gid = (int)(entry >> 9);
             const LeafD &L = P.leaves[gid];
             const RayD ray = camera_ray(P, x0 + (e & 31), P.row0 + ly0 + (e >> 5));
             double ix, iy, iz, tt;
@@ -1542,6 +1666,7 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_primary_mfma(const RenderParams P) {
             if (win) atomicMin(&bid[e], gid);
         });
     __builtin_amdgcn_wave_barrier();
+    RT_WAVE_PHASE(2)
     // pixels (4h + r, c): the table, then spheres
     double mt[4]; int mid[4]; bool act[4];
 #pragma unroll
@@ -1595,6 +1720,10 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_primary_mfma(const RenderParams P) {
     if (lane == 0 && nexact) stat_add(P, 1, (unsigned long long)nexact);
     if (lane == 0) stat_add(P, 6, (unsigned long long)nblocks);
     if (lane == 0 && Q.nrec) stat_add(P, 4, (unsigned long long)Q.nrec);
+#ifdef RT_WAVE_TIMES
+    wave_ph[2] = (Q.t_s1 & 0xffff) | ((Q.t_ex & 0xffff) << 16) | ((Q.t_bits & 0xffff) << 32) | ((Q.t_loop & 0xffff) << 48);
+    wave_record(P, 0u, (unsigned)wave, wave_t0, nblocks, Q.nrec, nexact, wave_ph);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1648,15 +1777,18 @@ __global__ void __launch_bounds__(256) k_final(const RenderParams P) {
             }
         }
     }
-    if (P.next_rays) {          // append the reflected rays, one atomic per wave
+    if (P.next_rays) {
+        // The reflected rays of a wave (8 x 8 pixels at level 0) take a run of 64 slots of the next level, lane for lane
+        // (one atomic per wave); lanes that reflect nothing leave a padding entry (parent = ~0).  Kept together like
+        // this, the 64 rays k_general bounds at a time leave one patch of one surface: a narrow bundle.
         const int lane = (int)(threadIdx.x & 63);
         const unsigned long long m = __ballot(spawn);
         if (m) {
-            const int leader = __ffsll((long long)m) - 1;
             unsigned base = 0;
-            if (lane == leader) base = atomicAdd(P.next_count, (unsigned)__popcll(m));
-            base = __shfl(base, leader);
-            if (spawn) P.next_rays[base + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = child;
+            if (lane == 0) base = atomicAdd(P.next_count, 64u);
+            base = __shfl(base, 0);
+            if (!spawn) { child.dz = 1.0; child.parent = 0xffffffffu; }
+            P.next_rays[base + (unsigned)lane] = child;
         }
     }
     if (!act) return;
@@ -1771,21 +1903,107 @@ __device__ __forceinline__ void general_sphere_loop(const RenderParams &P, const
     }
 }
 
+// Bound of one run of 64 reflected rays (one per lane): the origins lie within ro of c, the directions within the cone
+// (a, cos rho) — the same in every lane.  Reflected rays of neighbouring pixels off the same mirror leave from
+// neighbouring points in similar directions, so most blocks of leaves (32 consecutive records of a space-filling
+// order, with their bounding sphere) can be skipped for the whole run: a point p of the sphere (C, R) can only be met
+// by a ray of the run if the angle between C - c and a is at most rho + asin((R + ro) / |C - c|).
+struct RunBound { float cx, cy, cz, ro, ax, ay, az, cr, sr; int mode; };     // mode 0: no rays, 1: test blocks, 2: scan every block
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = __builtin_fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ RunBound run_bound(bool act, float ox, float oy, float oz, float dx, float dy, float dz, bool cull) {
+    RunBound b = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(act);
+    if (!m) return b;
+    b.mode = 2;
+    if (!cull) return b;
+    const float cnt = (float)__popcll(m);
+    const float dd = __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, dz * dz));
+    const float rn = __builtin_amdgcn_rsqf(dd);
+    const float ux = dx * rn, uy = dy * rn, uz = dz * rn;
+    bool bad = act && !(dd > 1e-30f && dd < 1e30f && __builtin_fabsf(ox) < 1e18f && __builtin_fabsf(oy) < 1e18f && __builtin_fabsf(oz) < 1e18f);   // NaN, inf, zero direction
+    if (__builtin_amdgcn_ballot_w64(bad)) return b;
+    b.cx = wave_sum(act ? ox : 0.f) / cnt; b.cy = wave_sum(act ? oy : 0.f) / cnt; b.cz = wave_sum(act ? oz : 0.f) / cnt;
+    const float ex = ox - b.cx, ey = oy - b.cy, ez = oz - b.cz;
+    const float ro = wave_max(act ? __builtin_sqrtf(__builtin_fmaf(ex, ex, __builtin_fmaf(ey, ey, ez * ez))) : 0.f);
+    // (the rays were rounded from double to float: 2^-23 of their coordinates covers that twice over)
+    b.ro = ro * 1.00001f + 1.2e-7f * (__builtin_fabsf(b.cx) + __builtin_fabsf(b.cy) + __builtin_fabsf(b.cz) + ro) + 1e-30f;
+    const float sx = wave_sum(act ? ux : 0.f), sy = wave_sum(act ? uy : 0.f), sz = wave_sum(act ? uz : 0.f);
+    const float sn = __builtin_fmaf(sx, sx, __builtin_fmaf(sy, sy, sz * sz));
+    if (!(sn > 1e-6f * cnt * cnt)) return b;                     // directions all over the sphere
+    const float sr = __builtin_amdgcn_rsqf(sn);
+    b.ax = sx * sr; b.ay = sy * sr; b.az = sz * sr;
+    const float cmin = -wave_max(act ? -__builtin_fmaf(b.ax, ux, __builtin_fmaf(b.ay, uy, b.az * uz)) : -1.f);
+    b.cr = cmin - 1e-5f;
+    if (!(b.cr > 0.05f)) return b;                               // wider than 87 degrees: not worth a test
+    b.sr = __builtin_sqrtf(__builtin_fmaxf(0.f, (1.f - b.cr) * (1.f + b.cr)));
+    b.mode = 1;
+    return b;
+}
+__device__ __forceinline__ bool run_meets(const RunBound &b, float Cx, float Cy, float Cz, float R) {
+    if (b.mode != 1) return b.mode == 2;
+    const float vx = Cx - b.cx, vy = Cy - b.cy, vz = Cz - b.cz;
+    const float d2 = __builtin_fmaf(vx, vx, __builtin_fmaf(vy, vy, vz * vz));
+    const float rr = R + b.ro;
+    if (!(d2 > rr * rr * 1.0001f)) return true;                  // the origins reach into the sphere (or a NaN / inf sphere)
+    const float dist = __builtin_sqrtf(d2);
+    const float sa = __builtin_fminf(1.f, rr / dist * 1.00001f + 1e-6f);
+    const float ca = __builtin_sqrtf(__builtin_fmaxf(0.f, (1.f - sa) * (1.f + sa)));
+    const float c = __builtin_fmaf(b.cr, ca, -(b.sr * sa)) - 1e-5f;              // cos(rho + alpha), low side
+    return __builtin_fmaf(vx, b.ax, __builtin_fmaf(vy, b.ay, vz * b.az)) >= dist * c;
+}
+
+template <int KIND>
+__device__ __forceinline__ void general_blocks(const RenderParams &P, const GenRec *recs, const int32_t *gids, const float *spheres, int n,
+                                               const RunBound (&rb)[4], const Ray4 &G, const bool act[4], const uint32_t slot[4],
+                                               double bt[4], int bid[4], unsigned &nexact, unsigned &nblocks) {
+    const int lane = (int)(threadIdx.x & 63), nblk = (n + 31) / 32;
+    for (int g0 = 0; g0 < nblk; g0 += 64) {
+        const int g = g0 + lane;
+        bool pass = g < nblk;
+        if (pass) {
+            const float4 S = reinterpret_cast<const float4 *>(spheres)[g];
+            const bool m0 = run_meets(rb[0], S.x, S.y, S.z, S.w), m1 = run_meets(rb[1], S.x, S.y, S.z, S.w);
+            const bool m2 = run_meets(rb[2], S.x, S.y, S.z, S.w), m3 = run_meets(rb[3], S.x, S.y, S.z, S.w);
+            pass = m0 || m1 || m2 || m3;
+        }
+        unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
+        nblocks += (unsigned)__popcll(m);
+        while (m) {                                               // wave-uniform
+            const int i0 = (g0 + __ffsll((long long)m) - 1) * 32;
+            m &= m - 1ull;
+            general_loop<KIND>(P, as_const(recs + i0), as_const(gids + i0), min(32, n - i0), G, act, slot, bt, bid, nexact);
+        }
+    }
+}
+
 __global__ void RT_HOT(4) k_general(const RenderParams P) {
     const unsigned count = num_slots(P);
     const unsigned wave = blockIdx.x * RT_WAVES_PER_BLOCK + (threadIdx.x >> 6);
     if (wave * 256u >= count) return;
     const int lane = (int)(threadIdx.x & 63);
-    uint32_t slot[4]; bool act[4];
+    uint32_t slot[4]; bool act[4], inlist[4];
     float o[3][4], d[3][4];
+    RunBound rb[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         slot[r] = wave * 256u + (unsigned)(r * 64 + lane);
-        act[r] = slot[r] < count;
-        if (!act[r]) slot[r] = 0u;
+        inlist[r] = slot[r] < count;
+        if (!inlist[r]) slot[r] = 0u;
+        act[r] = inlist[r] && P.rays[slot[r]].parent != 0xffffffffu;       // (not a padding entry of k_final)
         const RayD ray = slot_ray(P, (int)slot[r]);
         o[0][r] = (float)ray.px; o[1][r] = (float)ray.py; o[2][r] = (float)ray.pz;
         d[0][r] = (float)ray.dx; d[1][r] = (float)ray.dy; d[2][r] = (float)ray.dz;
+        rb[r] = run_bound(act[r], o[0][r], o[1][r], o[2][r], d[0][r], d[1][r], d[2][r], P.cull != 0);
     }
     Ray4 G;
 #pragma unroll
@@ -1796,16 +2014,20 @@ __global__ void RT_HOT(4) k_general(const RenderParams P) {
     double bt[4]; int bid[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) { bt[r] = INFINITY; bid[r] = -1; }
-    unsigned nexact = 0;
-    general_loop<LEAF_TRI>(P, as_const(P.gen_tri), as_const(P.tri_gid), P.ntri, G, act, slot, bt, bid, nexact);
-    general_loop<LEAF_RECT>(P, as_const(P.gen_rect), as_const(P.rect_gid), P.nrect, G, act, slot, bt, bid, nexact);
+    unsigned nexact = 0, nblocks = 0;
+    general_blocks<LEAF_TRI>(P, P.gen_tri, P.gen_tri_gid, P.gen_tri_sph, P.ntri, rb, G, act, slot, bt, bid, nexact, nblocks);
+    general_blocks<LEAF_RECT>(P, P.gen_rect, P.gen_rect_gid, P.gen_rect_sph, P.nrect, rb, G, act, slot, bt, bid, nexact, nblocks);
     if (P.nsph > 0) general_sphere_loop(P, G, act, slot, bt, bid, nexact);
+    unsigned nrays = 0;
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-        if (act[r]) P.hit_id[P.out_off + slot[r]] = bid[r];
+    for (int r = 0; r < 4; ++r) {
+        if (inlist[r]) P.hit_id[P.out_off + slot[r]] = bid[r];                              // padding entries: -1 (a miss)
+        nrays += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(act[r]));
+    }
     for (int o2 = 32; o2 > 0; o2 >>= 1) nexact += __shfl_down(nexact, o2);
     if (lane == 0 && nexact) stat_add(P, 1, (unsigned long long)nexact);
-    if (lane == 0) stat_add(P, 5, (unsigned long long)min(256u, count - wave * 256u));     // reflected rays traced
+    if (lane == 0) stat_add(P, 5, (unsigned long long)nrays);                              // reflected rays traced
+    if (lane == 0) stat_add(P, 8, (unsigned long long)nblocks);                            // (wave, block of 32 leaves) pairs looked at
 }
 
 // colour of a level folded into the level below: addPixelRGB8 direct (scalePixelRGB8 reflectivity sub), Main.hs:545, 554
@@ -1815,6 +2037,7 @@ __global__ void __launch_bounds__(256) k_combine(const RayRec *__restrict__ rays
     const unsigned n = *count < cap ? *count : cap;
     if (i >= n) return;
     const RayRec R = rays[i];
+    if (R.parent == 0xffffffffu) return;        // padding entry
     const uint32_t c = col[i], pc = parent_col[R.parent];
     uint32_t out = 0;
 #pragma unroll
@@ -1914,6 +2137,10 @@ bool hip_ok(hipError_t e, const char *what) {
 }
 #define HIP_TRY(expr) do { if (!hip_ok((expr), #expr)) return RT_ERR_HIP; } while (0)
 
+#ifdef RT_WAVE_TIMES
+unsigned long long *g_wave_dbg = nullptr;
+#endif
+
 double now_ms() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
@@ -2011,6 +2238,10 @@ int device_prepare(rt_scene &s, DeviceScene &D, int device, int w, int h) {
             if ((rc = upload(D.gen_sph, s.gen_sph))) return rc;
             if ((rc = upload(D.gen_tri, s.gen_tri))) return rc;
             if ((rc = upload(D.gen_rect, s.gen_rect))) return rc;
+            if ((rc = upload(D.gen_tri_gid, s.gen_tri_gid))) return rc;
+            if ((rc = upload(D.gen_rect_gid, s.gen_rect_gid))) return rc;
+            if ((rc = upload(D.gen_tri_sph, s.gen_tri_sph))) return rc;
+            if ((rc = upload(D.gen_rect_sph, s.gen_rect_sph))) return rc;
         }
         if ((rc = upload(D.tri_gid, s.tri_gid))) return rc;
         if ((rc = upload(D.rect_gid, s.rect_gid))) return rc;
@@ -2061,14 +2292,20 @@ struct WsNeeds {
     size_t hit_id = 0, accum = 0, hitrec = 0, queue = 0, qsparse = 0, tcount = 0, lit = 0, lvl = 0, cb = 0;
     int levels = 1;
 };
-size_t setup_blocks_bound(int w, size_t crow) {   // k_setup blocks of a chunk: 32 x 16 pixel tiles at level 0, runs of slots above
-    const size_t cpix = crow * (size_t)w;
+// slots of a bounce level: k_final hands every wave of 8 x 8 pixels that reflects anything a run of 64 slots, so a level
+// can hold the chunk's pixels padded to whole 32 x 8 tiles (and no more: deeper levels never grow)
+size_t level_capacity(int w, size_t rows) {
+    return (size_t)((w + 31) / 32) * 32 * ((rows + 7) / 8) * 8;
+}
+size_t setup_blocks_bound(int w, size_t crow, bool levels) {   // k_setup blocks of a chunk: 32 x 16 pixel tiles at level 0, runs of slots above
+    const size_t slots = levels ? level_capacity(w, crow) : crow * (size_t)w;
     return std::max((size_t)((w + 31) / 32) * ((crow + RT_SETUP_THREADS / 32 - 1) / (RT_SETUP_THREADS / 32)),
-                    (cpix + RT_SETUP_THREADS - 1) / RT_SETUP_THREADS);
+                    (slots + RT_SETUP_THREADS - 1) / RT_SETUP_THREADS);
 }
 WsNeeds ws_needs(int w, int nrows, size_t crow, int npoint, int levels, int spp, bool own_hit, bool shade, bool callbacks) {
     WsNeeds n;
-    const size_t npix = (size_t)w * (size_t)nrows, cpix = crow * (size_t)w, np = (size_t)(npoint > 0 ? npoint : 1);
+    const size_t npix = (size_t)w * (size_t)nrows, np = (size_t)(npoint > 0 ? npoint : 1);
+    const size_t cpix = levels > 1 ? level_capacity(w, crow) : crow * (size_t)w;      // slots of a chunk (bounce levels: padded)
     n.levels = levels;
     if (own_hit || spp > 1) n.hit_id = npix;
     if (!shade) return n;
@@ -2076,7 +2313,7 @@ WsNeeds ws_needs(int w, int nrows, size_t crow, int npoint, int levels, int spp,
     n.hitrec = cpix * sizeof(HitRec);
     n.lit = cpix;
     n.queue = cpix * np;
-    const size_t ub = setup_blocks_bound(w, crow);
+    const size_t ub = setup_blocks_bound(w, crow, levels > 1);
     n.qsparse = ub * RT_SETUP_THREADS * np;
     n.tcount = (ub + 1) * np;
     if (levels > 1) n.lvl = cpix;
@@ -2182,6 +2419,8 @@ int render_rows(rt_scene *s, DeviceScene &D, const Workspace &W, size_t crow, in
     P.qsparse = W.qsparse; P.tcount = W.tcount;
     P.cb_slot = W.cb_slot; P.cb_xy = W.cb_xy; P.cb_group = W.cb_group; P.cb_normal = W.cb_normal; P.cb_count = W.qcount + RT_QCOUNT_CB;
     P.gen_tri = (const GenRec *)D.gen_tri.p; P.gen_rect = (const GenRec *)D.gen_rect.p;
+    P.gen_tri_gid = (const int32_t *)D.gen_tri_gid.p; P.gen_rect_gid = (const int32_t *)D.gen_rect_gid.p;
+    P.gen_tri_sph = (const float *)D.gen_tri_sph.p; P.gen_rect_sph = (const float *)D.gen_rect_sph.p;
     P.sph_rec = (const FilterRec *)D.sph_rec.p; P.gen_sph = (const GenRec *)D.gen_sph.p; P.sph_gid = (const int32_t *)D.sph_gid.p;
     P.nsph = (int)s->sph_gid.size();
     P.mf_rows = (const uint16_t *)D.mf_rows.p; P.mf_gid = (const int32_t *)D.mf_gid.p; P.mf_rec = (const FilterRec *)D.mf_rec.p;
@@ -2197,6 +2436,15 @@ int render_rows(rt_scene *s, DeviceScene &D, const Workspace &W, size_t crow, in
     P.talk = s->talk ? 1 : 0;
     P.spp = spp; P.seed_lo = (uint32_t)seed; P.seed_hi = (uint32_t)(seed >> 32);
     const bool callbacks = !s->normal_fn.empty();
+#ifdef RT_WAVE_TIMES
+    {
+        static unsigned long long *dbg = nullptr;
+        if (!dbg) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dbg), (8 + 8 * (1ull << 20)) * sizeof(unsigned long long)));
+        HIP_TRY(hipMemsetAsync(dbg, 0, 64, st));
+        P.dbg = dbg;
+        g_wave_dbg = dbg;
+    }
+#endif
 
     if (timed && (rc = next_event(D, st, 0))) return rc;
     for (int sample = 0; sample < spp; ++sample) {
@@ -2210,6 +2458,7 @@ int render_rows(rt_scene *s, DeviceScene &D, const Workspace &W, size_t crow, in
             P.row0 = row0 + (int)r; P.nrows = rows;
             P.out_off = (long long)r * w;
             P.qcap = rows * w;
+            P.lcap = (int)level_capacity(w, (size_t)rows);
             P.tiles_x = (w + RT_TILE_W - 1) / RT_TILE_W;
             P.tiles_y = (rows + RT_TILE_H - 1) / RT_TILE_H;
             const long long tiles = (long long)P.tiles_x * P.tiles_y;
@@ -2226,7 +2475,10 @@ int render_rows(rt_scene *s, DeviceScene &D, const Workspace &W, size_t crow, in
             }
             if (timed && (rc = next_event(D, st, 1))) return rc;
             if (!d_rgba) continue;
-            const unsigned sblocks = (unsigned)(((size_t)P.qcap + 256 * RT_WAVES_PER_BLOCK - 1) / (256 * RT_WAVES_PER_BLOCK));
+            // grids: shadow waves of 256 jobs, one thread per slot; bounce levels have up to lcap slots
+            const size_t slots_max = levels > 1 ? (size_t)P.lcap : (size_t)P.qcap;
+            const unsigned sblocks = (unsigned)((slots_max + 256 * RT_WAVES_PER_BLOCK - 1) / (256 * RT_WAVES_PER_BLOCK));
+            const unsigned lblocks = (unsigned)((slots_max + 255) / 256);
             int32_t *const hit0 = P.hit_id;
             const long long off0 = P.out_off;
             uint8_t *const rgba0 = P.rgba;
@@ -2244,9 +2496,9 @@ int render_rows(rt_scene *s, DeviceScene &D, const Workspace &W, size_t crow, in
                 P.next_rays = (lvl + 1 < levels) ? W.lvl_rays[lvl + 1] : nullptr;
                 P.next_count = lvl_count + lvl + 1;
                 P.colour = (levels > 1) ? W.lvl_col[lvl] : nullptr;
-                if (callbacks && (rc = run_normal_callbacks(*s, P, st, pblocks))) return rc;
+                if (callbacks && (rc = run_normal_callbacks(*s, P, st, lvl == 0 ? pblocks : lblocks))) return rc;
                 const unsigned ublocks = lvl == 0 ? (unsigned)P.tiles_x * (unsigned)((rows + RT_SETUP_THREADS / 32 - 1) / (RT_SETUP_THREADS / 32))
-                                                  : (unsigned)(((size_t)P.qcap + RT_SETUP_THREADS - 1) / RT_SETUP_THREADS);
+                                                  : (unsigned)((slots_max + RT_SETUP_THREADS - 1) / RT_SETUP_THREADS);
                 P.setup_blocks = (int)ublocks;
                 hipLaunchKernelGGL(k_setup, dim3(ublocks), dim3(RT_SETUP_THREADS), 0, st, P);
                 if (s->npoint > 0) {
@@ -2261,14 +2513,14 @@ int render_rows(rt_scene *s, DeviceScene &D, const Workspace &W, size_t crow, in
 #endif
                 }
                 if (timed && (rc = next_event(D, st, 3))) return rc;
-                hipLaunchKernelGGL(k_final, dim3(lvl == 0 ? (unsigned)P.tiles_x * (unsigned)((rows + 7) / 8) : pblocks), dim3(256), 0, st, P);
+                hipLaunchKernelGGL(k_final, dim3(lvl == 0 ? (unsigned)P.tiles_x * (unsigned)((rows + 7) / 8) : lblocks), dim3(256), 0, st, P);
                 if (timed && (rc = next_event(D, st, 4))) return rc;
             }
             P.rays = nullptr; P.count_ptr = nullptr; P.next_rays = nullptr; P.hit_id = hit0; P.out_off = off0;
             if (levels > 1) {       // fold the levels back: direct `addPixelRGB8` scaled reflection, deepest first
                 for (int lvl = levels - 1; lvl >= 1; --lvl)
-                    hipLaunchKernelGGL(k_combine, dim3(pblocks), dim3(256), 0, st, W.lvl_rays[lvl], W.lvl_col[lvl],
-                                       lvl_count + lvl, (unsigned)P.qcap, W.lvl_col[lvl - 1]);
+                    hipLaunchKernelGGL(k_combine, dim3(lblocks), dim3(256), 0, st, W.lvl_rays[lvl], W.lvl_col[lvl],
+                                       lvl_count + lvl, (unsigned)P.lcap, W.lvl_col[lvl - 1]);
                 P.colour = W.lvl_col[0]; P.rgba = rgba0; P.accum = accum0;
                 hipLaunchKernelGGL(k_store, dim3(pblocks), dim3(256), 0, st, P);
                 P.colour = nullptr;
@@ -2342,7 +2594,8 @@ void rt_scene_destroy(rt_scene *s) {
         if (d.stream) (void)hipStreamSynchronize((hipStream_t)d.stream);
         if (d.copy_stream) (void)hipStreamSynchronize((hipStream_t)d.copy_stream);
         DevBuf *bufs[] = {&d.leaves, &d.aux, &d.guards, &d.mats, &d.lights, &d.tri_rec, &d.rect_rec, &d.tri_gid, &d.rect_gid,
-                          &d.sph_rec, &d.gen_sph, &d.sph_gid, &d.mf_rows, &d.mf_gid, &d.mf_cone, &d.mf_rec, &d.gen_tri, &d.gen_rect};
+                          &d.sph_rec, &d.gen_sph, &d.sph_gid, &d.mf_rows, &d.mf_gid, &d.mf_cone, &d.mf_rec, &d.gen_tri, &d.gen_rect,
+                          &d.gen_tri_gid, &d.gen_rect_gid, &d.gen_tri_sph, &d.gen_rect_sph};
         for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
         Workspace &W = d.ws;
         void *ptrs[] = {W.counters, W.qcount, W.hit_id, W.accum, W.hitrec, W.queue, W.qsparse, W.tcount, W.lit,
@@ -2456,6 +2709,7 @@ int device_stats(rt_scene *s, DeviceScene &D, rt_stats *out) {
         st.primary_rays = D.last_primary;
         st.shadow_rays = c[0];
         st.bounce_rays = c[5];
+        st.bounce_blocks = c[8];
         const uint64_t rays = st.primary_rays + st.shadow_rays + st.bounce_rays;
         st.tri_pairs = rays * (uint64_t)s->tri_gid.size();
         st.rect_pairs = rays * (uint64_t)s->rect_gid.size();
@@ -2470,6 +2724,13 @@ int device_stats(rt_scene *s, DeviceScene &D, rt_stats *out) {
         st.upload_ms = D.stats.upload_ms;
         D.stats = st;
         D.stats_pending = false;
+#ifdef RT_WAVE_TIMES
+        if (const char *path = getenv("RT_WAVE_TIMES_FILE")) {
+            std::vector<unsigned long long> rec(8 + 8 * (1ull << 20));
+            HIP_TRY(hipMemcpy(rec.data(), g_wave_dbg, rec.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+            if (FILE *f = fopen(path, "wb")) { fwrite(rec.data(), 8, 8 + 8 * (size_t)std::min<unsigned long long>(rec[0], 1ull << 20), f); fclose(f); }
+        }
+#endif
     }
     *out = D.stats;
     out->prepare_ms = s->prepare_ms;

@@ -629,6 +629,71 @@ static GenRec make_gen_rec(const LeafD &L, const double omax[3]) {
     return r;
 }
 
+// Reflected rays have no common apex, so their leaf records are ordered in space instead: along a Morton curve through
+// the leaves' centroids, cut into blocks of 32 with a bounding sphere each (k_general skips the blocks no ray of a
+// 64-ray run can reach).  Any order gives the same image: the nearest hit is the minimum over (t, leaf index).
+static void spatial_order(const rt_scene &s, const std::vector<int32_t> &gids, const double lo[3], const double hi[3],
+                          std::vector<int32_t> &order, std::vector<float> &spheres) {
+    const size_t n = gids.size();
+    std::vector<std::pair<uint32_t, int32_t>> keyed(n);
+    std::vector<int> nv(n);
+    std::vector<double> verts(n * 12);
+    for (size_t k = 0; k < n; ++k) {
+        const LeafD &L = s.leaves[gids[k]];
+        double v[4][3];
+        nv[k] = leaf_polygon(L, v);
+        double c[3] = {0, 0, 0};
+        bool ok = nv[k] > 0;
+        for (int j = 0; j < nv[k]; ++j) for (int i = 0; i < 3; ++i) { verts[k * 12 + j * 3 + i] = v[j][i]; c[i] += v[j][i] / nv[k]; ok = ok && std::isfinite(v[j][i]); }
+        if (!ok) nv[k] = 0;
+        uint32_t key = 0xffffffffu;                             // degenerate leaves last
+        if (ok) {
+            key = 0;
+            for (int i = 0; i < 3; ++i) {
+                const double ext = hi[i] - lo[i];
+                double q = ext > 0 ? (c[i] - lo[i]) / ext : 0.0;
+                q = q < 0 ? 0 : (q > 1 ? 1 : q);
+                uint32_t u = (uint32_t)(q * 1023.0);
+                u = (u | (u << 16)) & 0x030000ffu; u = (u | (u << 8)) & 0x0300f00fu; u = (u | (u << 4)) & 0x030c30c3u; u = (u | (u << 2)) & 0x09249249u;
+                key |= u << i;
+            }
+        }
+        keyed[k] = {key, (int32_t)k};
+    }
+    std::stable_sort(keyed.begin(), keyed.end(), [](const std::pair<uint32_t, int32_t> &a, const std::pair<uint32_t, int32_t> &b) { return a.first < b.first; });
+    order.resize(n);
+    const size_t nblk = (n + 31) / 32;
+    spheres.assign((nblk + 1) * 4, 0.f);
+    for (size_t b = 0; b < nblk; ++b) {
+        double c[3] = {0, 0, 0};
+        size_t cnt = 0;
+        bool always = false;
+        for (size_t k = b * 32; k < std::min(n, b * 32 + 32); ++k) {
+            const size_t src = (size_t)keyed[k].second;
+            order[k] = gids[src];
+            if (nv[src] == 0) { always = true; continue; }
+            for (int j = 0; j < nv[src]; ++j) { for (int i = 0; i < 3; ++i) c[i] += verts[src * 12 + j * 3 + i]; ++cnt; }
+        }
+        float *S = &spheres[b * 4];
+        if (always || cnt == 0) { S[3] = INFINITY; continue; }
+        for (int i = 0; i < 3; ++i) c[i] /= (double)cnt;
+        double r2 = 0;
+        for (size_t k = b * 32; k < std::min(n, b * 32 + 32); ++k) {
+            const size_t src = (size_t)keyed[k].second;
+            for (int j = 0; j < nv[src]; ++j) {
+                double d2 = 0;
+                for (int i = 0; i < 3; ++i) { const double d = verts[src * 12 + j * 3 + i] - c[i]; d2 += d * d; }
+                r2 = std::fmax(r2, d2);
+            }
+        }
+        // (a convex polygon lies inside any sphere that holds its vertices)  centre rounded to float: the radius pays for it
+        const double r = std::sqrt(r2) * (1.0 + 1e-6) + 1e-6 * (std::fabs(c[0]) + std::fabs(c[1]) + std::fabs(c[2]) + 1.0);
+        S[0] = (float)c[0]; S[1] = (float)c[1]; S[2] = (float)c[2];
+        S[3] = std::nextafterf((float)r, INFINITY);
+        if (!std::isfinite(S[0]) || !std::isfinite(S[1]) || !std::isfinite(S[2]) || !std::isfinite(S[3])) { S[0] = S[1] = S[2] = 0.f; S[3] = INFINITY; }
+    }
+}
+
 void build_filter_records(rt_scene &s, int w, int h, bool eye_only) {
     (void)w; (void)h;
     const size_t ntri = s.tri_gid.size(), nrect = s.rect_gid.size(), nsph = s.sph_gid.size();
@@ -764,8 +829,10 @@ void build_filter_records(rt_scene &s, int w, int h, bool eye_only) {
             for (int i = 0; i < 3; ++i) omax[i] = (s.leaves.empty() ? 1.0 : std::fmax(std::fabs(lo[i]), std::fabs(hi[i]))) * 1.001 + 1e-3;
             GenRec never{}; never.c[12] = 1.0f;
             s.gen_tri.assign(ntri + 1, never); s.gen_rect.assign(nrect + 1, never);
-            for (size_t k = 0; k < ntri; ++k) s.gen_tri[k] = make_gen_rec(s.leaves[s.tri_gid[k]], omax);
-            for (size_t k = 0; k < nrect; ++k) s.gen_rect[k] = make_gen_rec(s.leaves[s.rect_gid[k]], omax);
+            spatial_order(s, s.tri_gid, lo, hi, s.gen_tri_gid, s.gen_tri_sph);
+            spatial_order(s, s.rect_gid, lo, hi, s.gen_rect_gid, s.gen_rect_sph);
+            for (size_t k = 0; k < ntri; ++k) s.gen_tri[k] = make_gen_rec(s.leaves[s.gen_tri_gid[k]], omax);
+            for (size_t k = 0; k < nrect; ++k) s.gen_rect[k] = make_gen_rec(s.leaves[s.gen_rect_gid[k]], omax);
             s.gen_sph.assign(nsph + 1, never);
             for (size_t k = 0; k < nsph; ++k) s.gen_sph[k] = make_sphere_gen_rec(s.leaves[s.sph_gid[k]], omax);
         }
