@@ -77,7 +77,7 @@ typedef struct {
     uint64_t mfma_blocks_shadow;  /* the same for k_shadow_mfma, all lights                        */
     uint64_t record_tests;        /* FP32 record tests (second stage), counted in the kernels       */
     uint64_t bounce_rays;         /* reflected rays traced (all levels)                             */
-    uint64_t bounce_blocks;       /* (wave of 256 reflected rays) x (block of 32 leaves) pairs k_general looked at */
+    uint64_t bounce_blocks;       /* (run of 64 reflected rays) x (block of 32 leaves) pairs k_general looked at */
     double   prepare_ms;          /* host time of the last rebuild of guard chains and filter records */
     double   upload_ms;           /* host time of the last upload of the scene to this device       */
 } rt_stats;
@@ -175,6 +175,12 @@ int  rt_scene_get_mfma_row(const rt_scene *, int apex, int leaf, uint16_t out[8]
  * code, 0, 0}; code 1 / 2 (zero axis, cos T = 1e30 / -1e30) = a block no ray / every ray has to look at.  A wave
  * skips the block when the cone misses the bound of its 256 ray directions.  Returns the number of blocks. */
 int  rt_scene_get_block_cone(const rt_scene *, int apex, int block, float out[8]);
+/* Reflected rays (trace depth > 1, Main.hs:546-556) have no common apex: their leaf records are kept in a space-filling
+ * order per leaf kind (0 rectangles, 1 triangles), in blocks of 32 with a bounding sphere each, and a run of 64 reflected
+ * rays skips the blocks its bound cannot reach.  Block `block` of that order, after rt_scene_prepare_host: sphere =
+ * {centre xyz, radius} (radius inf: always looked at), leaves = its leaf indices (-1: none).  Returns the number of blocks
+ * (0 for a scene without reflective materials: nothing is built). */
+int  rt_scene_get_general_block(const rt_scene *, int kind, int block, float sphere[4], int32_t leaves[32]);
 /* Guard chain of `leaf`: writes up to cap boxes {x0,y0,z0,x1,y1,z1}, innermost first; returns the count. */
 int  rt_scene_get_guards(const rt_scene *, int leaf, double *out, int cap);
 /* fixedCamera w h: out = {scaleX, scaleY, dX, dY, d}                      Main.hs:506-527 */

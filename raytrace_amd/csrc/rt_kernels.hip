@@ -1809,98 +1809,27 @@ __global__ void __launch_bounds__(256) k_final(const RenderParams P) {
 
 typedef const rt::GenRec RT_CONST *CGenPtr;
 __device__ __forceinline__ CGenPtr as_const(const GenRec *p) { return (CGenPtr)(const void *)p; }
-struct Ray4 { f2 ox[2], oy[2], oz[2], dx[2], dy[2], dz[2]; };
 
-// z[r] >= negm  <=>  ray r may hit the leaf.  q_k*a = e_k*a - b*f_k and t*a = -b must all carry the sign of a.
+// One ray (the lane's) against one leaf record (wave-uniform: scalar loads).  z >= negm  <=>  the ray may hit the leaf:
+// q_k*a = e_k*a - b*f_k and t*a = -b must all carry the sign of a (rt_scene.cpp: make_gen_rec).
 template <int KIND>
-__device__ __forceinline__ bool filter4_gen(CGenPtr R, const Ray4 &G, float z[4]) {
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const f2 a = pkfma(splat(R->c[0]), G.dx[p], pkfma(splat(R->c[1]), G.dy[p], splat(R->c[2]) * G.dz[p]));
-        const f2 b = pkfma(splat(R->c[0]), G.ox[p], pkfma(splat(R->c[1]), G.oy[p], pkfma(splat(R->c[2]), G.oz[p], splat(R->c[3]))));
-        const f2 e1 = pkfma(splat(R->c[4]), G.ox[p], pkfma(splat(R->c[5]), G.oy[p], pkfma(splat(R->c[6]), G.oz[p], splat(R->c[7]))));
-        const f2 f1 = pkfma(splat(R->c[4]), G.dx[p], pkfma(splat(R->c[5]), G.dy[p], splat(R->c[6]) * G.dz[p]));
-        const f2 e2 = pkfma(splat(R->c[8]), G.ox[p], pkfma(splat(R->c[9]), G.oy[p], pkfma(splat(R->c[10]), G.oz[p], splat(R->c[11]))));
-        const f2 f2_ = pkfma(splat(R->c[8]), G.dx[p], pkfma(splat(R->c[9]), G.dy[p], splat(R->c[10]) * G.dz[p]));
-        const f2 u = pkfma(e1, a, -(b * f1));
-        const f2 v = pkfma(e2, a, -(b * f2_));
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            if (KIND == LEAF_TRI) {
-                const float w = a[k] - u[k] - v[k], t = -b[k];
-                const float lo = __builtin_fminf(__builtin_fminf(__builtin_fminf(u[k], v[k]), w), t);
-                const float hi = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(u[k], v[k]), w), t);
-                z[2 * p + k] = __builtin_fmaxf(lo, -hi);
-            } else {
-                const float q = __builtin_fabsf(a[k]) - __builtin_fmaxf(__builtin_fabsf(u[k]), __builtin_fabsf(v[k]));
-                z[2 * p + k] = __builtin_fminf(q, -(b[k] * a[k]));
-            }
-        }
+__device__ __forceinline__ float filter_gen(CGenPtr R, float ox, float oy, float oz, float dx, float dy, float dz) {
+    const float a = __builtin_fmaf(R->c[0], dx, __builtin_fmaf(R->c[1], dy, R->c[2] * dz));
+    const float b = __builtin_fmaf(R->c[0], ox, __builtin_fmaf(R->c[1], oy, __builtin_fmaf(R->c[2], oz, R->c[3])));
+    const float e1 = __builtin_fmaf(R->c[4], ox, __builtin_fmaf(R->c[5], oy, __builtin_fmaf(R->c[6], oz, R->c[7])));
+    const float f1 = __builtin_fmaf(R->c[4], dx, __builtin_fmaf(R->c[5], dy, R->c[6] * dz));
+    const float e2 = __builtin_fmaf(R->c[8], ox, __builtin_fmaf(R->c[9], oy, __builtin_fmaf(R->c[10], oz, R->c[11])));
+    const float f2_ = __builtin_fmaf(R->c[8], dx, __builtin_fmaf(R->c[9], dy, R->c[10] * dz));
+    const float u = __builtin_fmaf(e1, a, -(b * f1));
+    const float v = __builtin_fmaf(e2, a, -(b * f2_));
+    if (KIND == LEAF_TRI) {
+        const float w = a - u - v, t = -b;
+        const float lo = __builtin_fminf(__builtin_fminf(__builtin_fminf(u, v), w), t);
+        const float hi = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(u, v), w), t);
+        return __builtin_fmaxf(lo, -hi);
     }
-    const float mx = __builtin_fmaxf(__builtin_fmaxf(z[0], z[1]), __builtin_fmaxf(z[2], z[3]));
-    return mx >= R->c[12];
-}
-
-template <int KIND>
-__device__ __forceinline__ void general_loop(const RenderParams &P, CGenPtr recs, CIntPtr gids, int n, const Ray4 &G,
-                                             const bool act[4], const uint32_t slot[4], double bt[4], int bid[4], unsigned &nexact) {
-    for (int i = 0; i < n; ++i) {
-        float z[4];
-        if (filter4_gen<KIND>(recs + i, G, z)) {
-            const int gid = gids[i];
-            const LeafD &L = P.leaves[gid];
-            const float negm = recs[i].c[12];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if ((z[r] >= negm) & act[r]) {
-                    uint32_t sr = slot[r];
-                    asm volatile("" : "+v"(sr));
-                    const RayD ray = slot_ray(P, (int)sr);
-                    double ix, iy, iz, t;
-                    ++nexact;
-                    if (leaf_isect<KIND>(L, ray, ix, iy, iz, t, RT_TALK(P)) && guards_ok(P.guards, L.guard, ray)) {
-                        if (t < bt[r] || (t == bt[r] && gid < bid[r]) || bid[r] < 0) { bt[r] = t; bid[r] = gid; }
-                    }
-                }
-            }
-        }
-    }
-}
-
-__device__ __forceinline__ void general_sphere_loop(const RenderParams &P, const Ray4 &G, const bool act[4], const uint32_t slot[4],
-                                                 double bt[4], int bid[4], unsigned &nexact) {
-    CGenPtr recs = as_const(P.gen_sph);
-    CIntPtr gids = as_const(P.sph_gid);
-    for (int i = 0; i < P.nsph; ++i) {
-        CGenPtr R = recs + i;
-        float z[4];
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {           // delta/4 = (d.o)^2 - (o.o - r^2) with o = origin - centre, Main.hs:396-400
-            const f2 ox = G.ox[p] - splat(R->c[0]), oy = G.oy[p] - splat(R->c[1]), oz = G.oz[p] - splat(R->c[2]);
-            const f2 b = pkfma(G.dx[p], ox, pkfma(G.dy[p], oy, G.dz[p] * oz));
-            const f2 c = pkfma(ox, ox, pkfma(oy, oy, pkfma(oz, oz, -splat(R->c[3]))));
-            const f2 zz = pkfma(b, b, -c);
-            z[2 * p] = zz[0]; z[2 * p + 1] = zz[1];
-        }
-        const float negm = R->c[12];
-        if (__builtin_fmaxf(__builtin_fmaxf(z[0], z[1]), __builtin_fmaxf(z[2], z[3])) >= negm) {
-            const int gid = gids[i];
-            const LeafD &L = P.leaves[gid];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if ((z[r] >= negm) & act[r]) {
-                    uint32_t sr = slot[r];
-                    asm volatile("" : "+v"(sr));
-                    const RayD ray = slot_ray(P, (int)sr);
-                    double ix, iy, iz, t;
-                    ++nexact;
-                    if (leaf_isect<LEAF_SPHERE>(L, ray, ix, iy, iz, t, RT_TALK(P)) && guards_ok(P.guards, L.guard, ray)) {
-                        if (t < bt[r] || (t == bt[r] && gid < bid[r]) || bid[r] < 0) { bt[r] = t; bid[r] = gid; }
-                    }
-                }
-            }
-        }
-    }
+    const float q = __builtin_fabsf(a) - __builtin_fmaxf(__builtin_fabsf(u), __builtin_fabsf(v));
+    return __builtin_fminf(q, -(b * a));
 }
 
 // Bound of one run of 64 reflected rays (one per lane): the origins lie within ro of c, the directions within the cone
@@ -1962,72 +1891,136 @@ __device__ __forceinline__ bool run_meets(const RunBound &b, float Cx, float Cy,
     return __builtin_fmaf(vx, b.ax, __builtin_fmaf(vy, b.ay, vz * b.az)) >= dist * c;
 }
 
-template <int KIND>
+// Kernel of the bounce levels.  One wave = one run of 64 reflected rays (what one wave of k_final left: one patch of one
+// surface), one ray per lane.
+//   1. the run's bound against the bounding sphere of every block of 32 leaves (a lane per block);
+//   2. for the blocks that are left, every leaf's record (scalar loads) against the 64 rays: FP32, conservative;
+//   3. pairs that pass go to a queue in LDS and through the exact FP64 evaluation 64 at a time, on all lanes, like the
+//      candidates of the matrix-core kernels; the nearest hit of every ray lives in LDS as (bits of t, leaf).
+struct GenWave {
+    unsigned long long *bt; int *bid; uint32_t *q; double *ray;      // LDS: nearest hit per ray, candidate queue, the 64 rays (9 x 64 doubles)
+    unsigned n, nexact;
+};
+template <class EX>
+__device__ __forceinline__ void gen_push(GenWave &Wv, bool cand, uint32_t entry, EX &&exact) {
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(cand);
+    if (!m) return;                                               // wave-uniform
+    if (cand) Wv.q[Wv.n + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = entry;
+    Wv.n += (unsigned)__popcll(m);
+    if (Wv.n >= 64u) {
+        Wv.n -= 64u;
+        exact(Wv.q[Wv.n + (threadIdx.x & 63u)], true);
+    }
+}
+
+template <int KIND, class EX>
 __device__ __forceinline__ void general_blocks(const RenderParams &P, const GenRec *recs, const int32_t *gids, const float *spheres, int n,
-                                               const RunBound (&rb)[4], const Ray4 &G, const bool act[4], const uint32_t slot[4],
-                                               double bt[4], int bid[4], unsigned &nexact, unsigned &nblocks) {
+                                               const RunBound &rb, bool act, float ox, float oy, float oz, float dx, float dy, float dz,
+                                               GenWave &Wv, unsigned &nblocks, EX &&exact) {
     const int lane = (int)(threadIdx.x & 63), nblk = (n + 31) / 32;
     for (int g0 = 0; g0 < nblk; g0 += 64) {
         const int g = g0 + lane;
         bool pass = g < nblk;
         if (pass) {
             const float4 S = reinterpret_cast<const float4 *>(spheres)[g];
-            const bool m0 = run_meets(rb[0], S.x, S.y, S.z, S.w), m1 = run_meets(rb[1], S.x, S.y, S.z, S.w);
-            const bool m2 = run_meets(rb[2], S.x, S.y, S.z, S.w), m3 = run_meets(rb[3], S.x, S.y, S.z, S.w);
-            pass = m0 || m1 || m2 || m3;
+            pass = run_meets(rb, S.x, S.y, S.z, S.w);
         }
         unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
         nblocks += (unsigned)__popcll(m);
         while (m) {                                               // wave-uniform
             const int i0 = (g0 + __ffsll((long long)m) - 1) * 32;
             m &= m - 1ull;
-            general_loop<KIND>(P, as_const(recs + i0), as_const(gids + i0), min(32, n - i0), G, act, slot, bt, bid, nexact);
+            CGenPtr R = as_const(recs + i0);
+            CIntPtr G = as_const(gids + i0);
+            const int cnt = min(32, n - i0);
+            for (int i = 0; i < cnt; ++i) {
+                const float z = filter_gen<KIND>(R + i, ox, oy, oz, dx, dy, dz);
+                gen_push(Wv, act && z >= R[i].c[12], ((uint32_t)G[i] << 8) | ((uint32_t)KIND << 6) | (uint32_t)lane, exact);
+            }
         }
     }
 }
 
-__global__ void RT_HOT(4) k_general(const RenderParams P) {
+__global__ void __attribute__((amdgpu_waves_per_eu(4, 8))) __launch_bounds__(64) k_general(const RenderParams P) {
+    __shared__ unsigned long long s_bt[64];
+    __shared__ int s_bid[64];
+    __shared__ uint32_t s_q[128];
+    __shared__ double s_ray[9 * 64];
     const unsigned count = num_slots(P);
-    const unsigned wave = blockIdx.x * RT_WAVES_PER_BLOCK + (threadIdx.x >> 6);
-    if (wave * 256u >= count) return;
+    const unsigned wave = blockIdx.x;
+    if (wave * 64u >= count) return;
     const int lane = (int)(threadIdx.x & 63);
-    uint32_t slot[4]; bool act[4], inlist[4];
-    float o[3][4], d[3][4];
-    RunBound rb[4];
+    const unsigned slot = wave * 64u + (unsigned)lane;
+    const bool inlist = slot < count;
+    const bool act = inlist && P.rays[slot].parent != 0xffffffffu;       // (not a padding entry of k_final)
+    const RayD ray = slot_ray(P, inlist ? (int)slot : 0);
+    {
+        const double r9[9] = {ray.px, ray.py, ray.pz, ray.dx, ray.dy, ray.dz, ray.rx, ray.ry, ray.rz};
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        slot[r] = wave * 256u + (unsigned)(r * 64 + lane);
-        inlist[r] = slot[r] < count;
-        if (!inlist[r]) slot[r] = 0u;
-        act[r] = inlist[r] && P.rays[slot[r]].parent != 0xffffffffu;       // (not a padding entry of k_final)
-        const RayD ray = slot_ray(P, (int)slot[r]);
-        o[0][r] = (float)ray.px; o[1][r] = (float)ray.py; o[2][r] = (float)ray.pz;
-        d[0][r] = (float)ray.dx; d[1][r] = (float)ray.dy; d[2][r] = (float)ray.dz;
-        rb[r] = run_bound(act[r], o[0][r], o[1][r], o[2][r], d[0][r], d[1][r], d[2][r], P.cull != 0);
+        for (int k = 0; k < 9; ++k) s_ray[k * 64 + lane] = r9[k];
     }
-    Ray4 G;
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        G.ox[p] = f2{o[0][2 * p], o[0][2 * p + 1]}; G.oy[p] = f2{o[1][2 * p], o[1][2 * p + 1]}; G.oz[p] = f2{o[2][2 * p], o[2][2 * p + 1]};
-        G.dx[p] = f2{d[0][2 * p], d[0][2 * p + 1]}; G.dy[p] = f2{d[1][2 * p], d[1][2 * p + 1]}; G.dz[p] = f2{d[2][2 * p], d[2][2 * p + 1]};
+    s_bt[lane] = ~0ull; s_bid[lane] = -1;
+    const float ox = (float)ray.px, oy = (float)ray.py, oz = (float)ray.pz;
+    const float dx = (float)ray.dx, dy = (float)ray.dy, dz = (float)ray.dz;
+    const RunBound rb = run_bound(act, ox, oy, oz, dx, dy, dz, P.cull != 0);
+    __builtin_amdgcn_wave_barrier();
+    GenWave Wv = {s_bt, s_bid, s_q, s_ray, 0u, 0u};
+    unsigned nblocks = 0;
+    // exact: intersect leaf reflected-ray (Main.hs:543 inside trace (n-1)), for the entry's ray; `all`: every lane holds one
+    auto exact = [&](uint32_t entry, bool have) {
+        const int e = (int)(entry & 63u), kind = (int)((entry >> 6) & 3u), gid = (int)(entry >> 8);
+        bool hit = false;
+        double tt = 0;
+        if (have) {
+            const LeafD &L = P.leaves[gid];
+            RayD r;
+            r.px = Wv.ray[0 * 64 + e]; r.py = Wv.ray[1 * 64 + e]; r.pz = Wv.ray[2 * 64 + e];
+            r.dx = Wv.ray[3 * 64 + e]; r.dy = Wv.ray[4 * 64 + e]; r.dz = Wv.ray[5 * 64 + e];
+            r.rx = Wv.ray[6 * 64 + e]; r.ry = Wv.ray[7 * 64 + e]; r.rz = Wv.ray[8 * 64 + e];
+            double ix, iy, iz;
+            ++Wv.nexact;
+            hit = (kind == LEAF_TRI ? leaf_isect<LEAF_TRI>(L, r, ix, iy, iz, tt, RT_TALK(P))
+                   : (kind == LEAF_RECT ? leaf_isect<LEAF_RECT>(L, r, ix, iy, iz, tt, RT_TALK(P)) : leaf_isect<LEAF_SPHERE>(L, r, ix, iy, iz, tt, RT_TALK(P))))
+                  && guards_ok(P.guards, L.guard, r);
+        }
+        // nearest wins; equal t -> the left-most leaf of the tree (Main.hs:213-214); the same four steps as in k_primary_mfma
+        const unsigned long long tb = (unsigned long long)__double_as_longlong(tt + 0.0);
+        unsigned long long old = 0;
+        if (hit) { old = Wv.bt[e]; atomicMin(&Wv.bt[e], tb); }
+        __builtin_amdgcn_wave_barrier();
+        const bool win = hit && Wv.bt[e] == tb;
+        if (win && tb < old) Wv.bid[e] = 0x7fffffff;
+        __builtin_amdgcn_wave_barrier();
+        if (win) atomicMin(&Wv.bid[e], gid);
+    };
+    general_blocks<LEAF_TRI>(P, P.gen_tri, P.gen_tri_gid, P.gen_tri_sph, P.ntri, rb, act, ox, oy, oz, dx, dy, dz, Wv, nblocks, exact);
+    general_blocks<LEAF_RECT>(P, P.gen_rect, P.gen_rect_gid, P.gen_rect_sph, P.nrect, rb, act, ox, oy, oz, dx, dy, dz, Wv, nblocks, exact);
+    if (P.nsph > 0) {           // spheres (few per scene): delta/4 = (d.o)^2 - (o.o - r^2) with o = origin - centre, Main.hs:396-400
+        CGenPtr recs = as_const(P.gen_sph);
+        CIntPtr gids = as_const(P.sph_gid);
+        for (int i = 0; i < P.nsph; ++i) {
+            CGenPtr R = recs + i;
+            const float sx = ox - R->c[0], sy = oy - R->c[1], sz = oz - R->c[2];
+            const float b = __builtin_fmaf(dx, sx, __builtin_fmaf(dy, sy, dz * sz));
+            const float c = __builtin_fmaf(sx, sx, __builtin_fmaf(sy, sy, __builtin_fmaf(sz, sz, -R->c[3])));
+            const float z = __builtin_fmaf(b, b, -c);
+            gen_push(Wv, act && z >= R->c[12], ((uint32_t)gids[i] << 8) | ((uint32_t)LEAF_SPHERE << 6) | (uint32_t)lane, exact);
+        }
     }
-    double bt[4]; int bid[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { bt[r] = INFINITY; bid[r] = -1; }
-    unsigned nexact = 0, nblocks = 0;
-    general_blocks<LEAF_TRI>(P, P.gen_tri, P.gen_tri_gid, P.gen_tri_sph, P.ntri, rb, G, act, slot, bt, bid, nexact, nblocks);
-    general_blocks<LEAF_RECT>(P, P.gen_rect, P.gen_rect_gid, P.gen_rect_sph, P.nrect, rb, G, act, slot, bt, bid, nexact, nblocks);
-    if (P.nsph > 0) general_sphere_loop(P, G, act, slot, bt, bid, nexact);
-    unsigned nrays = 0;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        if (inlist[r]) P.hit_id[P.out_off + slot[r]] = bid[r];                              // padding entries: -1 (a miss)
-        nrays += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(act[r]));
+    if (Wv.n > 0u) {                                              // the last, partial batch
+        const bool have = (unsigned)lane < Wv.n;
+        const uint32_t entry = have ? Wv.q[lane] : 0u;
+        Wv.n = 0u;
+        exact(entry, have);
     }
+    __builtin_amdgcn_wave_barrier();
+    if (inlist) P.hit_id[P.out_off + slot] = Wv.bid[lane];       // padding entries: -1 (a miss)
+    unsigned nexact = Wv.nexact;
     for (int o2 = 32; o2 > 0; o2 >>= 1) nexact += __shfl_down(nexact, o2);
     if (lane == 0 && nexact) stat_add(P, 1, (unsigned long long)nexact);
-    if (lane == 0) stat_add(P, 5, (unsigned long long)nrays);                              // reflected rays traced
-    if (lane == 0) stat_add(P, 8, (unsigned long long)nblocks);                            // (wave, block of 32 leaves) pairs looked at
+    const unsigned nrays = (unsigned)__popcll(__builtin_amdgcn_ballot_w64(act));
+    if (lane == 0) stat_add(P, 5, (unsigned long long)nrays);     // reflected rays traced
+    if (lane == 0) stat_add(P, 8, (unsigned long long)nblocks);   // (run of 64 rays, block of 32 leaves) pairs looked at
 }
 
 // colour of a level folded into the level below: addPixelRGB8 direct (scalePixelRGB8 reflectivity sub), Main.hs:545, 554
@@ -2490,7 +2483,7 @@ int render_rows(rt_scene *s, DeviceScene &D, const Workspace &W, size_t crow, in
                     HIP_TRY(hipMemsetAsync(W.qcount, 0, 32 * sizeof(unsigned), st));
                     P.rays = W.lvl_rays[lvl]; P.count_ptr = lvl_count + lvl;
                     P.hit_id = W.lvl_hit[lvl]; P.out_off = 0;
-                    hipLaunchKernelGGL(k_general, dim3(sblocks), dim3(RT_WAVES_PER_BLOCK * 64), 0, st, P);
+                    hipLaunchKernelGGL(k_general, dim3((unsigned)((slots_max + 63) / 64)), dim3(64), 0, st, P);
                     if (timed && (rc = next_event(D, st, 1))) return rc;
                 }
                 P.next_rays = (lvl + 1 < levels) ? W.lvl_rays[lvl + 1] : nullptr;

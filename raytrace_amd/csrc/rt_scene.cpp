@@ -660,6 +660,22 @@ static void spatial_order(const rt_scene &s, const std::vector<int32_t> &gids, c
         }
         keyed[k] = {key, (int32_t)k};
     }
+    // leaves much larger than the typical one (walls, floors) would blow up the sphere of whatever block they fall into
+    // and drag its 31 neighbours into every scan: they come first, in blocks of their own (but for the last of them)
+    {
+        std::vector<double> rad(n, 0.0);
+        for (size_t k = 0; k < n; ++k) {
+            double c[3] = {0, 0, 0}, r2 = 0;
+            for (int j = 0; j < nv[k]; ++j) for (int i = 0; i < 3; ++i) c[i] += verts[k * 12 + j * 3 + i] / nv[k];
+            for (int j = 0; j < nv[k]; ++j) { double d2 = 0; for (int i = 0; i < 3; ++i) { const double d = verts[k * 12 + j * 3 + i] - c[i]; d2 += d * d; } r2 = std::fmax(r2, d2); }
+            rad[k] = std::sqrt(r2);
+        }
+        std::vector<double> sorted(rad);
+        std::sort(sorted.begin(), sorted.end());
+        const double big = n ? 8.0 * sorted[n / 2] : 0.0;
+        for (size_t k = 0; k < n; ++k)
+            if (!(nv[k] > 0 && rad[k] > big) && keyed[k].first != 0xffffffffu) keyed[k].first |= 0x40000000u;   // (Morton keys use 30 bits)
+    }
     std::stable_sort(keyed.begin(), keyed.end(), [](const std::pair<uint32_t, int32_t> &a, const std::pair<uint32_t, int32_t> &b) { return a.first < b.first; });
     order.resize(n);
     const size_t nblk = (n + 31) / 32;
@@ -1155,6 +1171,20 @@ int rt_scene_get_block_cone(const rt_scene *s, int apex, int block, float out[8]
     }
     std::memcpy(out, &s->mf_cone[((size_t)apex * ((size_t)s->mf_groups + 2) + (size_t)block) * 8], 32);
     return s->mf_groups;
+}
+
+int rt_scene_get_general_block(const rt_scene *s, int kind, int block, float sphere[4], int32_t leaves[32]) {
+    if (!s || !sphere || !leaves || (kind != LEAF_RECT && kind != LEAF_TRI) || s->rec_w < 0) {
+        set_error("rt_scene_get_general_block: bad argument (call rt_scene_prepare_host first)"); return RT_ERR_ARG;
+    }
+    const std::vector<int32_t> &gid = kind == LEAF_TRI ? s->gen_tri_gid : s->gen_rect_gid;
+    const std::vector<float> &sph = kind == LEAF_TRI ? s->gen_tri_sph : s->gen_rect_sph;
+    const int nblk = (int)((gid.size() + 31) / 32);
+    if (!s->reflective) return 0;
+    if (block < 0 || block >= nblk) { set_error("rt_scene_get_general_block: block out of range"); return RT_ERR_ARG; }
+    for (int k = 0; k < 4; ++k) sphere[k] = sph[(size_t)block * 4 + k];
+    for (int k = 0; k < 32; ++k) { const size_t i = (size_t)block * 32 + k; leaves[k] = i < gid.size() ? gid[i] : -1; }
+    return nblk;
 }
 
 int rt_scene_get_guards(const rt_scene *s, int leaf, double *out, int cap) {

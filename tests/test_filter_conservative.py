@@ -584,3 +584,45 @@ def test_shadow_bundles_that_certainly_pass_a_guard_box_do():
                 said_yes += 1
                 assert all(intersect_bb(box, r) for r in rays), f"trial {trial}: box {box} light {lp}"
     assert said_yes > 500
+
+
+def test_general_ray_blocks_cover_every_leaf_and_their_spheres_hold_them():
+    """Reflected rays: every planar leaf sits in exactly one block of the spatial order of its kind, and the block's
+    bounding sphere holds the whole accepting region of each of its leaves (triangle / parallelogram corners, in double)."""
+    L = _lib.lib()
+    finite = 0
+    for world, lights in (scenes.mirror_room(), scenes.mirror_bench(ntri=700, ncuboid=60), scenes.adversarial()):
+        sc = api.Scene(world, lights)
+        assert L.rt_scene_prepare_host(sc.handle, 320, 200) >= 0
+        seen = []
+        for kind in (0, 1):
+            sph, ids = (C.c_float * 4)(), (C.c_int32 * 32)()
+            nblk = L.rt_scene_get_general_block(sc.handle, kind, 0, sph, ids)
+            if nblk <= 0:
+                continue
+            for b in range(nblk):
+                assert L.rt_scene_get_general_block(sc.handle, kind, b, sph, ids) == nblk
+                centre, radius = np.array(sph[:3], np.float64), float(sph[3])
+                for g in ids:
+                    if g < 0:
+                        continue
+                    seen.append(g)
+                    leaf = sc.leaf(g)
+                    assert int(leaf[0]) == kind
+                    if not np.isfinite(radius):
+                        continue
+                    finite += 1
+                    p0, e1, e2 = np.array(leaf[6:9]), np.array(leaf[9:12]), np.array(leaf[12:15])
+                    if kind == 1:
+                        corners = [p0, p0 + e1, p0 + e2]
+                    else:       # the parallelogram 0 <= dV.w <= ww, 0 <= dV.h <= hh (w, h need not be orthogonal)
+                        ww, hh, wh = e1 @ e1, e2 @ e2, e1 @ e2
+                        det = ww * hh - wh * wh
+                        corners = [p0 + ((s_ * hh - t_ * wh) / det) * e1 + ((t_ * ww - s_ * wh) / det) * e2
+                                   for s_, t_ in ((0, 0), (ww, 0), (ww, hh), (0, hh))]
+                    for p in corners:
+                        assert np.linalg.norm(p - centre) <= radius, (kind, b, g)
+        planar = [g for g in range(sc.num_leaves) if int(sc.leaf(g)[0]) in (0, 1)]
+        assert sorted(seen) == planar
+        sc.close()
+    assert finite > 1000
