@@ -100,7 +100,7 @@ struct RenderParams {
     uint32_t *qsparse;              // k_setup's output: per light, RT_SETUP_THREADS slots per block, the block's jobs first
     unsigned *tcount;               // jobs of every (light, k_setup block); k_queue_offsets turns them into offsets in place
     int setup_blocks;               // k_setup blocks of this chunk
-    uint32_t *lit;                  // per chunk pixel: bit l set = point light l reaches it
+    uint32_t *lit;                  // per chunk pixel and group of 32 point lights: bit l set = light 32 g + l reaches it
     // RT_NORMAL_CALLBACK leaves (an arbitrary fnorm, Main.hs:956-965): k_cb_gather lists the hit points on them, the host
     // evaluates the caller's function, k_setup reads the normals back
     uint32_t *cb_slot;              // per slot of the chunk / level: index into the list
@@ -137,7 +137,9 @@ struct RenderParams {
     int talk;                       // 1: the rules of src/Talk.hs (rt_scene_set_dialect)
     uint32_t seed_lo, seed_hi;
     int tiles_x, tiles_y;
-    uint8_t point_light[32];        // index in `lights` of the k-th point light
+    uint16_t point_light[32];       // index in `lights` of the k-th point light of the current group of 32
+    uint32_t *lit_w;                // the current group's word of `lit` (= lit + group * lit_stride)
+    long long lit_stride;           // slots per group of 32 point lights in `lit`
 };
 
 struct HitRec { double px, py, pz, nx, ny, nz; };
@@ -697,13 +699,12 @@ __global__ void __launch_bounds__(RT_SETUP_THREADS) k_setup(const RenderParams P
         H.px = ix; H.py = iy; H.pz = iz; H.nx = nx; H.ny = ny; H.nz = nz;
         P.hitrec[pix] = H;
     }
-    if (act) P.lit[pix] = 0u;
+    if (act) P.lit_w[pix] = 0u;
     const int lane = (int)(threadIdx.x & 63), wv = (int)(threadIdx.x >> 6);
     uint32_t needmask = 0;
     int pl = 0;
-    for (int li = 0; li < P.nlights; ++li) {
-        const LightD &Lt = P.lights[li];
-        if (Lt.kind != 0) continue;
+    for (; pl < P.npoint; ++pl) {                     // the (up to 32) point lights of this group
+        const LightD &Lt = P.lights[P.point_light[pl]];
         bool need = false;
         if (id >= 0) {
             double tx, ty, tz;
@@ -725,7 +726,6 @@ __global__ void __launch_bounds__(RT_SETUP_THREADS) k_setup(const RenderParams P
         if (need) needmask |= 1u << pl;
         const unsigned long long m = __ballot(need);
         if (lane == 0) s_cnt[pl][wv] = (unsigned)__popcll(m);
-        ++pl;
     }
     __syncthreads();
     if ((int)threadIdx.x < P.npoint) {
@@ -935,7 +935,7 @@ __global__ void RT_HOT(RT_WAVES_EU_SHADOW) k_shadow(const RenderParams P) {
     if (P.nsph > 0) shadow_sphere_loop(P, as_const(P.sph_rec + ro * (size_t)P.nsph), D, pix, Lt, need, nexact);
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-        if (need[r]) atomicOr(&P.lit[pix[r]], 1u << pl);
+        if (need[r]) atomicOr(&P.lit_w[pix[r]], 1u << pl);
     for (int o = 32; o > 0; o >>= 1) nexact += __shfl_down(nexact, o);
     if (lane == 0 && nexact) stat_add(P, 2, (unsigned long long)nexact);
 }
@@ -1554,7 +1554,7 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_shadow_mfma(const RenderParams P) {
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-        if (nd[r]) atomicOr(&P.lit[pix[r]], 1u << pl);
+        if (nd[r]) atomicOr(&P.lit_w[pix[r]], 1u << pl);
     for (int o = 32; o > 0; o >>= 1) nexact += __shfl_down(nexact, o);
     if (lane == 0 && nexact) stat_add(P, 2, (unsigned long long)nexact);
     if (lane == 0) stat_add(P, 7, (unsigned long long)nblocks);
@@ -1747,7 +1747,7 @@ __global__ void __launch_bounds__(256) k_final(const RenderParams P) {
     if (id >= 0) {
         const MaterialD M = P.mats[P.leaves[id].mat];
         const HitRec H = P.hitrec[pix];
-        const uint32_t lit = P.lit[pix];
+        uint32_t lit = 0u;
         const RayD ray = slot_ray(P, pix);
         int pl = 0;
         for (int li = 0; li < P.nlights; ++li) {
@@ -1758,7 +1758,8 @@ __global__ void __launch_bounds__(256) k_final(const RenderParams P) {
                 cb = min(255, cb + round8(Lt.f * (double)M.diffuse[2]));
                 continue;
             }
-            if ((lit >> pl) & 1u) {                                                    // lit: Main.hs:476-487 / Talk.hs:244-248
+            if ((pl & 31) == 0) lit = P.lit[(long long)(pl >> 5) * P.lit_stride + pix];   // the next group of 32 point lights
+            if ((lit >> (pl & 31)) & 1u) {                                             // lit: Main.hs:476-487 / Talk.hs:244-248
                 int r, g, b;
                 light_terms(P, Lt, M, H, ray, r, g, b);
                 cr = min(255, cr + r); cg = min(255, cg + g); cb = min(255, cb + b);
@@ -2297,14 +2298,15 @@ size_t setup_blocks_bound(int w, size_t crow, bool levels) {   // k_setup blocks
 }
 WsNeeds ws_needs(int w, int nrows, size_t crow, int npoint, int levels, int spp, bool own_hit, bool shade, bool callbacks) {
     WsNeeds n;
-    const size_t npix = (size_t)w * (size_t)nrows, np = (size_t)(npoint > 0 ? npoint : 1);
+    const size_t npix = (size_t)w * (size_t)nrows, np = (size_t)(npoint > 0 ? std::min(npoint, 32) : 1);
+    const size_t groups = (size_t)std::max(1, (npoint + 31) / 32);
     const size_t cpix = levels > 1 ? level_capacity(w, crow) : crow * (size_t)w;      // slots of a chunk (bounce levels: padded)
     n.levels = levels;
     if (own_hit || spp > 1) n.hit_id = npix;
     if (!shade) return n;
     if (spp > 1) n.accum = 3 * npix;
     n.hitrec = cpix * sizeof(HitRec);
-    n.lit = cpix;
+    n.lit = cpix * groups;
     n.queue = cpix * np;
     const size_t ub = setup_blocks_bound(w, crow, levels > 1);
     n.qsparse = ub * RT_SETUP_THREADS * np;
@@ -2420,11 +2422,14 @@ int render_rows(rt_scene *s, DeviceScene &D, const Workspace &W, size_t crow, in
     P.mf_groups = s->mf_groups;
     P.mf_cone = (const float *)D.mf_cone.p; P.cull = s->opt_cull ? 1 : 0;
     P.nguard_cached = (s->opt_cull && !s->talk) ? s->guard_cached : 0;
-    for (size_t li = 0, k = 0; li < s->lights.size() && k < 32; ++li) if (s->lights[li].kind == 0) P.point_light[k++] = (uint8_t)li;
+    // point lights are worked off 32 at a time (one bit each in a word of `lit`); the reference's Light monoid has no limit
+    std::vector<uint16_t> point_lights;
+    for (size_t li = 0; li < s->lights.size(); ++li) if (s->lights[li].kind == 0) point_lights.push_back((uint16_t)li);
+    const int ngroups = std::max(1, (int)((point_lights.size() + 31) / 32));
     P.cam = fixed_camera(w, h);
     P.eps = ray_eps();
     P.ntri = (int)s->tri_gid.size(); P.nrect = (int)s->rect_gid.size();
-    P.nlights = (int)s->lights.size(); P.nleaves = (int)s->leaves.size(); P.npoint = s->npoint;
+    P.nlights = (int)s->lights.size(); P.nleaves = (int)s->leaves.size(); P.npoint = std::min(32, s->npoint);
     P.w = w; P.h = h;
     P.talk = s->talk ? 1 : 0;
     P.spp = spp; P.seed_lo = (uint32_t)seed; P.seed_hi = (uint32_t)(seed >> 32);
@@ -2493,19 +2498,27 @@ int render_rows(rt_scene *s, DeviceScene &D, const Workspace &W, size_t crow, in
                 const unsigned ublocks = lvl == 0 ? (unsigned)P.tiles_x * (unsigned)((rows + RT_SETUP_THREADS / 32 - 1) / (RT_SETUP_THREADS / 32))
                                                   : (unsigned)((slots_max + RT_SETUP_THREADS - 1) / RT_SETUP_THREADS);
                 P.setup_blocks = (int)ublocks;
-                hipLaunchKernelGGL(k_setup, dim3(ublocks), dim3(RT_SETUP_THREADS), 0, st, P);
-                if (s->npoint > 0) {
-                    hipLaunchKernelGGL(k_queue_offsets, dim3((unsigned)s->npoint), dim3(1024), 0, st, P);
-                    hipLaunchKernelGGL(k_queue_compact, dim3(ublocks, (unsigned)s->npoint), dim3(RT_SETUP_THREADS), 0, st, P);
-                }
-                if (timed && (rc = next_event(D, st, 2))) return rc;
-                if (s->npoint > 0) {
-                    if (use_mfma) hipLaunchKernelGGL(k_shadow_mfma, dim3(sblocks, (unsigned)s->npoint), dim3(RT_WAVES_PER_BLOCK * 64), 0, st, P);
+                P.lit_stride = (long long)slots_max;
+                for (int grp = 0; grp < ngroups; ++grp) {
+                    const int first = 32 * grp, np = std::max(0, std::min(32, (int)point_lights.size() - first));
+                    P.npoint = np;
+                    for (int k = 0; k < np; ++k) P.point_light[k] = point_lights[(size_t)first + k];
+                    P.lit_w = W.lit + (size_t)grp * slots_max;
+                    if (grp > 0) HIP_TRY(hipMemsetAsync(W.qcount, 0, 32 * sizeof(unsigned), st));
+                    hipLaunchKernelGGL(k_setup, dim3(ublocks), dim3(RT_SETUP_THREADS), 0, st, P);
+                    if (np > 0) {
+                        hipLaunchKernelGGL(k_queue_offsets, dim3((unsigned)np), dim3(1024), 0, st, P);
+                        hipLaunchKernelGGL(k_queue_compact, dim3(ublocks, (unsigned)np), dim3(RT_SETUP_THREADS), 0, st, P);
+                    }
+                    if (timed && (rc = next_event(D, st, 2))) return rc;
+                    if (np > 0) {
+                        if (use_mfma) hipLaunchKernelGGL(k_shadow_mfma, dim3(sblocks, (unsigned)np), dim3(RT_WAVES_PER_BLOCK * 64), 0, st, P);
 #ifdef RT_VALU_FILTER
-                    else hipLaunchKernelGGL(k_shadow, dim3(sblocks, (unsigned)s->npoint), dim3(RT_WAVES_PER_BLOCK * 64), 0, st, P);
+                        else hipLaunchKernelGGL(k_shadow, dim3(sblocks, (unsigned)np), dim3(RT_WAVES_PER_BLOCK * 64), 0, st, P);
 #endif
+                    }
+                    if (timed && (rc = next_event(D, st, 3))) return rc;
                 }
-                if (timed && (rc = next_event(D, st, 3))) return rc;
                 hipLaunchKernelGGL(k_final, dim3(lvl == 0 ? (unsigned)P.tiles_x * (unsigned)((rows + 7) / 8) : lblocks), dim3(256), 0, st, P);
                 if (timed && (rc = next_event(D, st, 4))) return rc;
             }
@@ -2537,7 +2550,7 @@ int check_render_args(const rt_scene *s, int w, int h, int depth, int spp, int r
         set_error("rt_render: bad image size or row band"); return RT_ERR_ARG;
     }
     if (depth < 0) { set_error("rt_render: depth must be >= 0"); return RT_ERR_ARG; }
-    if (s->npoint > 32) { set_error("rt_render: more than 32 point lights are not supported yet"); return RT_ERR_UNSUPPORTED; }
+    if (s->lights.size() > 65535) { set_error("rt_render: more than 65535 lights are not supported"); return RT_ERR_UNSUPPORTED; }
     return RT_OK;
 }
 // chunk rows of the growing-workspace renders: a multiple of the tile height

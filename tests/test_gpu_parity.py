@@ -380,13 +380,47 @@ def test_16k_image_row_bands_against_oracle(gpu_lib):
         assert (a_rgba[r0 - 8000, :, :3] == ref["rgb"][0]).all(), f"row {r0}"
 
 
-def test_32_point_lights(gpu_lib):
-    """The most point lights one render takes (one bit each in the per-pixel lit mask)."""
+def test_many_point_lights(gpu_lib):
+    """Monoid Light (Main.hs:436-441) has no limit: 32 lights fill one word of the per-pixel lit mask, 33 and 70 need
+    two and three groups."""
     world, _ = scenes.stacked_cubes()
     rng = np.random.default_rng(5)
-    lights = api.mconcat_lights([api.pointLight(0.06, 0.05, tuple(map(float, rng.uniform((-8, 2, -12), (8, 9, 2))))) for _ in range(32)]
-                                + [api.ambient(0.05)])
-    compare(world, lights, 160, 120, label="32-lights")
+    for n in (32, 33, 70):
+        lights = api.mconcat_lights([api.pointLight(2.0 / n, 1.6 / n, tuple(map(float, rng.uniform((-8, 2, -12), (8, 9, 2))))) for _ in range(n)]
+                                    + [api.ambient(0.05)])
+        compare(world, lights, 160, 120, label=f"{n}-lights")
+    # ambient lights in between, a mirror scene (the bounce levels take the groups too), supersampling
+    world, _ = scenes.mirror_room()
+    lights = []
+    for k in range(40):
+        lights += api.pointLight(0.04, 0.03, tuple(map(float, rng.uniform((-6, -3, -14), (6, 4, -2)))))
+        if k % 13 == 0:
+            lights += api.ambient(0.02)
+    compare(world, lights, 120, 90, depth=3, label="40-lights-mirror")
+
+
+def test_deep_reflection(gpu_lib):
+    """trace n for n beyond the 8 levels the first version kept: a mirror in front of the camera and one behind it,
+    depth 12, 20 and 30 (Main.hs:541-557)."""
+    mirror = api.black.replace(reflectivity=0.9, specular=(255, 255, 255), specularity=100)
+    world = api.mconcat([
+        api.rectangle(mirror, (0, 0, -10), (10, 0, 0), (0, 10, 0)),           # normal +z: faces the camera
+        api.rectangle(mirror, (0, 0, 2), (0, 10, 0), (10, 0, 0)),             # normal -z: behind the camera
+        api.rectangle(api.orange, (0, -3, -4), (0, 0, 14), (12, 0, 0)),
+        api.colorcube([api.red, api.green, api.blue], (1.5, -2, -6), 1.2)])
+    lights = api.mconcat_lights([api.pointLight(0.7, 0.4, (0, 2.5, -6)), api.ambient(0.15)])
+    osc = ob.OracleScene(world, lights)
+    sc = api.Scene(world, lights)
+    prev = None
+    for depth in (8, 12, 20, 30):
+        ref = osc.render(160, 100, depth=depth)
+        rgba, hit = sc.render(160, 100, depth=depth)
+        assert (hit == ref["hit_id"]).all() and (rgba[:, :, :3] == ref["rgb"]).all(), f"depth {depth}"
+        if depth in (12, 20, 30):
+            assert (rgba != prev).any()              # the deeper levels are visible between the mirrors
+        prev = rgba
+    assert sc.stats()["bounce_rays"] > 0
+    sc.close()
 
 
 def test_fuzzed_scenes_against_oracle(gpu_lib):

@@ -188,14 +188,9 @@ def test_cpp_host_mirror_builds_and_fails_loudly_without_gpu(tmp_path):
 
 
 def test_limits_and_dialect_errors():
-    """More than 32 point lights and misuse of the Talk.hs dialect are reported as errors before any device work."""
+    """Misuse of the Talk.hs dialect is reported as an error before any device work.  (Point lights and trace depth have
+    no limit worth the name any more: lights are worked off 32 at a time, bounce levels up to 64.)"""
     L = _lib.lib()
-    world, _ = scenes.planes()
-    lights = api.mconcat_lights([api.pointLight(0.1, 0.1, (float(k), 5.0, -3.0)) for k in range(33)])
-    sc = api.Scene(world, lights)
-    with pytest.raises(RuntimeError, match="32 point lights"):
-        sc.render(16, 16)
-    sc.close()
     h = C.c_void_p()
     assert L.rt_scene_create(C.byref(h)) == 0
     assert L.rt_scene_set_dialect(h, 7) == -1
