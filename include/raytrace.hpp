@@ -51,7 +51,8 @@ inline const Material black = colour(0, 0, 0), white = colour(255, 255, 255), re
 struct ShapeNode;
 using Shape = std::shared_ptr<const ShapeNode>;
 struct ShapeNode {
-    enum Kind { Empty, Rect, Tri, Sph, Cuboid, Cyl, Append, Concat, GaussNormals } kind = Empty;
+    enum Kind { Empty, Rect, Tri, Sph, Cuboid, Cyl, Append, Concat, GaussNormals, FnNormals } kind = Empty;
+    std::function<Vector3D(double, double)> fnorm;   // FnNormals: the closure of Main.hs:956-965
     std::vector<Material> mats;
     Vector3D a{}, b{}, c{};          // points / vectors of the constructor
     double p[4] = {0, 0, 0, 0};      // scalars of the constructor
@@ -95,11 +96,21 @@ inline Light mconcat(const std::vector<Light> &ls) { Light out; for (const Light
 
 // ---- linearInterpolation, Main.hs:937-988 -----------------------------------------------------------
 inline double gaussian(double x, double y) { return std::exp(-(x * x + y * y) * 4); }         // Main.hs:580
-enum class FNorm { Nothing, Gaussian };                                                        // Main.hs:581-584 runs on the GPU
+enum class FNorm { Nothing, Gaussian, Closure };                                               // Main.hs:581-584 runs on the GPU
+using FNormFn = std::function<Vector3D(double, double)>;                                       // Maybe (Double -> Double -> Vector3D)
 
+// `Just fnorm` with an arbitrary closure (the sinc and sine-cosine surfaces, Main.hs:586-605)
 inline std::pair<Shape, Light> linearInterpolation(const std::function<double(double, double)> &f, FNorm fnorm,
                                                    std::pair<double, double> p1, std::pair<double, double> p2,
+                                                   double step, Vector3D origin, double scale, FNormFn closure);
+inline std::pair<Shape, Light> linearInterpolation(const std::function<double(double, double)> &f, FNormFn closure,
+                                                   std::pair<double, double> p1, std::pair<double, double> p2,
                                                    double step, Vector3D origin, double scale) {
+    return linearInterpolation(f, FNorm::Closure, p1, p2, step, origin, scale, std::move(closure));
+}
+inline std::pair<Shape, Light> linearInterpolation(const std::function<double(double, double)> &f, FNorm fnorm,
+                                                   std::pair<double, double> p1, std::pair<double, double> p2,
+                                                   double step, Vector3D origin, double scale, FNormFn closure) {
     const double x1 = p1.first, y1 = p1.second, x2 = p2.first, y2 = p2.second;
     const double x = (x2 + x1) / 2, y = (y2 + y1) / 2, w = x2 - x1, h = y2 - y1, scaleInv = 1.0 / scale;
     const Vector3D offset = origin - scalar(scale, {x, 0, y});
@@ -114,12 +125,22 @@ inline std::pair<Shape, Light> linearInterpolation(const std::function<double(do
             if (fnorm == FNorm::Gaussian) {
                 ShapeNode n; n.kind = ShapeNode::GaussNormals; n.kids = {two}; n.a = offset; n.p[0] = scaleInv;
                 two = node(n);
+            } else if (fnorm == FNorm::Closure) {                  // `Just fnorm` for any fnorm: evaluated on the host
+                if (!closure) throw std::invalid_argument("linearInterpolation: FNorm::Closure needs a function");
+                ShapeNode n; n.kind = ShapeNode::FnNormals; n.kids = {two}; n.a = offset; n.p[0] = scaleInv; n.fnorm = closure;
+                two = node(n);
             }
             cells.push_back(two);
         }
     Shape shape = mconcat(std::vector<Shape>{mconcat(cells), rectangle(aquamarine, origin, {1.5 * scale * w, 0, 0}, {0, 0, -(1.5 * scale * h)})});
     Light light = mconcat(std::vector<Light>{pointLight(0.3, 0.6, origin + Vector3D{scale * w / 4, scale * 10, scale * w / 4}), ambient(0.3)});
     return {shape, light};
+}
+
+inline std::pair<Shape, Light> linearInterpolation(const std::function<double(double, double)> &f, FNorm fnorm,
+                                                   std::pair<double, double> p1, std::pair<double, double> p2,
+                                                   double step, Vector3D origin, double scale) {
+    return linearInterpolation(f, fnorm, p1, p2, step, origin, scale, nullptr);
 }
 
 // ---- rendering ----------------------------------------------------------------------------------
@@ -139,6 +160,14 @@ inline rt_material cmat(const Material &m) {
     c.specular[0] = m.mat_specular.r; c.specular[1] = m.mat_specular.g; c.specular[2] = m.mat_specular.b;
     c.specularity = m.mat_specularity; c.reflectivity = m.mat_reflectivity;
     return c;
+}
+// rt_normal_fn trampoline: `user` is the std::function of a FnNormals node (alive as long as the Shape is)
+inline void fnorm_trampoline(int n, const double *xy, double *normals, void *user) {
+    const FNormFn &fn = *static_cast<const FNormFn *>(user);
+    for (int i = 0; i < n; ++i) {
+        const Vector3D v = fn(xy[2 * i], xy[2 * i + 1]);
+        normals[3 * i] = v.x; normals[3 * i + 1] = v.y; normals[3 * i + 2] = v.z;
+    }
 }
 inline void emit(rt_scene *s, const Shape &sh) {
     const ShapeNode &n = *sh;
@@ -160,6 +189,12 @@ inline void emit(rt_scene *s, const Shape &sh) {
         emit(s, n.kids[0]);
         const double params[4] = {n.p[0], n.a.x, n.a.y, n.a.z};
         check(rt_set_normal_mode(s, first, rt_scene_num_leaves(s) - first, RT_NORMAL_GAUSSIAN, params, 4), "normals"); break; }
+    case ShapeNode::FnNormals: {
+        const int first = rt_scene_num_leaves(s);
+        emit(s, n.kids[0]);
+        const double params[4] = {n.p[0], n.a.x, n.a.y, n.a.z};
+        check(rt_set_normal_callback(s, first, rt_scene_num_leaves(s) - first, params, fnorm_trampoline,
+                                     const_cast<FNormFn *>(&n.fnorm)), "normals"); break; }
     }
 }
 } // namespace detail
@@ -178,6 +213,25 @@ inline Image parallelTrace(int w, int h, Camera camera, const Tracer &tr, bool w
     Image img; img.w = w; img.h = h; img.rgba.resize((size_t)w * h * 4);
     if (want_hit_ids) img.hit_id.resize((size_t)w * h);
     detail::check(rt_render(s, w, h, tr.depth, 1, 0, 0, h, img.rgba.data(), want_hit_ids ? img.hit_id.data() : nullptr), "rt_render");
+    return img;
+}
+
+// The same frame on several GPUs of this process at once (rt_render_multi): bands of equal measured cost, gathered on
+// devices[0] over xGMI, copied to host memory from there.
+inline Image parallelTraceMulti(const std::vector<int> &devices, int w, int h, Camera camera, const Tracer &tr, bool want_hit_ids = false) {
+    if (camera.width != w || camera.height != h) throw std::invalid_argument("parallelTrace: camera and image size differ");
+    rt_scene *s = nullptr;
+    detail::check(rt_scene_create(&s), "rt_scene_create");
+    std::unique_ptr<rt_scene, void (*)(rt_scene *)> guard(s, rt_scene_destroy);
+    detail::emit(s, tr.world);
+    for (const LightSrc &l : tr.lights) {
+        const double p[3] = {l.pos.x, l.pos.y, l.pos.z};
+        detail::check(l.point ? rt_add_point_light(s, l.diffuse, l.specular, p) : rt_add_ambient(s, l.f), "light");
+    }
+    Image img; img.w = w; img.h = h; img.rgba.resize((size_t)w * h * 4);
+    if (want_hit_ids) img.hit_id.resize((size_t)w * h);
+    detail::check(rt_render_multi(s, w, h, tr.depth, 1, 0, (int)devices.size(), devices.data(), img.rgba.data(),
+                                  want_hit_ids ? img.hit_id.data() : nullptr), "rt_render_multi");
     return img;
 }
 
