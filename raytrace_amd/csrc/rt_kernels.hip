@@ -1095,7 +1095,7 @@ __device__ __forceinline__ unsigned step_bits(const f32x16 acc) {
 // are taken off 64 at a time, so that every lane of the wave works on one: stage1 (the FP32 record test) sends its
 // survivors to a second queue, whose entries go through the exact FP64 evaluation, again 64 at a time.  Without the
 // queues those two stages ran on the few lanes that happened to hold a candidate (5 % of the lanes on average).
-//   q1 entry = (position in the MFMA leaf stream << 8) | ray of the wave (0..255); q1 only ever holds entries of the
+//   q1 entry = (row of the leaf in its block << 8) | ray of the wave (0..255), 16 bits; q1 only ever holds entries of the
 //   block whose records are staged in `rec` (it is emptied before the next block with candidates is looked at);
 //   q2 entry = (leaf index << 9) | (leaf kind << 8) | ray: everything the exact stage needs, so it survives the block.
 // The counts are wave-uniform.
@@ -1104,9 +1104,9 @@ __device__ __forceinline__ unsigned step_bits(const f32x16 acc) {
 // a gather of 64 different lines costs the CU's address path about 64 cycles per instruction, and with four of them
 // per batch of 64 candidates that path, shared by all waves of the CU, was what the kernels were waiting for.  Read
 // back, lanes with different rows hit different LDS banks and lanes with the same row share a broadcast.
-constexpr int RT_Q1_CAP = 128, RT_Q2_CAP = 128;
+constexpr int RT_Q1_CAP = 16 * 64 + 64, RT_Q2_CAP = 128;      // q1: one ray block can add 16 x 64 entries to the 63 that may wait
 struct WaveQueues {
-    uint32_t *q1, *q2;
+    uint16_t *q1; uint32_t *q2;
     unsigned n1, n2;
     unsigned nrec;                  // FP32 record tests so far (statistics)
     float *rec;                     // 16 x 32 floats
@@ -1135,7 +1135,7 @@ __device__ __forceinline__ void q_drain(WaveQueues &Q, unsigned keep, bool flush
         Q.n1 -= take;
         Q.nrec += take;
         const bool have = lane < take;
-        const uint32_t entry = have ? Q.q1[Q.n1 + lane] : 0u;
+        const uint32_t entry = have ? (uint32_t)Q.q1[Q.n1 + lane] : 0u;
         uint32_t entry2 = 0u;
         RT_TICK(ts)
         const bool pass = have && stage1(entry, entry2);
@@ -1190,19 +1190,14 @@ __device__ __forceinline__ void mfma_scan(const i32x4 *base, const FilterRec *re
         if (mx == 0x7fffffff)
 #endif
         if (__builtin_amdgcn_ballot_w64(mx > 0)) {       // wave-uniform: every lane takes part in the MFMAs below
-            // the records of this block's 32 leaves: 2 KiB, 32 bytes per lane (lane l: half l & 1 of record l >> 1); the
-            // load is in flight while the pass bits are worked out
+            // the records of this block's 32 leaves: 2 KiB, 32 bytes per lane (lane l: half l & 1 of record l >> 1)
             const int ln = (int)(threadIdx.x & 63u);
             const float4 *rsrc = reinterpret_cast<const float4 *>(recs + (size_t)g * MF_LEAVES) + 2 * ln;
             const float4 r0 = rsrc[0], r1 = rsrc[1];
             RT_TICK(tb)
-            unsigned long long lo = 0, hi = 0;      // bit 16 b + q: ray block b passes the leaf of accumulator register q
+            unsigned mb = 0;                        // ray blocks with a candidate
 #pragma unroll
-            for (int b = 0; b < 8; ++b)
-                if (__builtin_amdgcn_ballot_w64(m[b] > 0)) {
-                    const unsigned long long sb = (unsigned long long)step_bits(mfma0(a_use, B[b])) << (16 * (b & 3));
-                    if (b < 4) lo |= sb; else hi |= sb;
-                }
+            for (int b = 0; b < 8; ++b) mb |= (__builtin_amdgcn_ballot_w64(m[b] > 0) != 0ull ? 1u : 0u) << b;
             {
                 float *dst = Q.rec + (ln & 1) * 8 * 32 + (ln >> 1);
                 dst[0 * 32] = r0.x; dst[1 * 32] = r0.y; dst[2 * 32] = r0.z; dst[3 * 32] = r0.w;
@@ -1211,15 +1206,31 @@ __device__ __forceinline__ void mfma_scan(const i32x4 *base, const FilterRec *re
             }
             RT_TOCK(Q.t_bits, tb)
             RT_TICK(tl)
-            // one entry per lane and round; register q of lane half h is row (q & 3) + 8 (q >> 2) + 4 h of the block
-            const uint32_t k0 = (uint32_t)(g * MF_LEAVES + 4 * h);
-            while (__builtin_amdgcn_ballot_w64((lo | hi) != 0ull)) {
-                const bool any = (lo | hi) != 0ull, first = lo != 0ull;
-                const unsigned long long wd = first ? lo : hi;
-                const int k = __ffsll((long long)wd) - 1;
-                const int b = (k >> 4) + (first ? 0 : 4), q = k & 15;
-                q_push(Q.q1, Q.n1, any, ((k0 + (uint32_t)((q & 3) + 8 * (q >> 2))) << 8) | (uint32_t)(b * 32 + c));
-                if (first) lo &= lo - 1ull; else hi &= hi - 1ull;
+            // The MFMA of a ray block with candidates is issued again (bit-identical) and each of its 16 accumulator
+            // registers is compared on its own: the compare IS the ballot (a lane mask in scalar registers), so the lanes
+            // that pass append their entries with one prefix count, no per-lane bit vectors and no loop over their bits.
+            // Register q of lane half h is row (q & 3) + 8 (q >> 2) + 4 h of the block; entry = (row << 8) | ray.
+            const uint32_t lane_part = ((uint32_t)(4 * h) << 8) | (uint32_t)c;
+#pragma unroll 1
+            for (int b = 0; b < 8; ++b) {           // (not unrolled: one copy of the candidate stages)
+                if (!((mb >> b) & 1u)) continue;
+                f16x8 Bb;
+                switch (b) {                        // wave-uniform
+                case 0: Bb = B[0]; break; case 1: Bb = B[1]; break; case 2: Bb = B[2]; break; case 3: Bb = B[3]; break;
+                case 4: Bb = B[4]; break; case 5: Bb = B[5]; break; case 6: Bb = B[6]; break; default: Bb = B[7]; break;
+                }
+                const f32x16 pa = mfma0(a_use, Bb);
+                const uint32_t eb = lane_part + (uint32_t)(b * 32);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const bool p = __float_as_int(pa[q]) > 0;
+                    const unsigned long long pm = __builtin_amdgcn_ballot_w64(p);
+                    if (pm) {                       // wave-uniform
+                        if (p) Q.q1[Q.n1 + __builtin_amdgcn_mbcnt_hi((unsigned)(pm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)pm, 0u))] =
+                            (uint16_t)(eb + (uint32_t)(((q & 3) + 8 * (q >> 2)) << 8));
+                        Q.n1 += (unsigned)__popcll(pm);
+                    }
+                }
                 q_drain(Q, 63u, false, stage1, exact);
             }
             q_drain(Q, 0u, false, stage1, exact);       // q1 is empty before `rec` is overwritten
@@ -1371,7 +1382,8 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_shadow_mfma(const RenderParams P) {
     __shared__ uint32_t s_pix[RT_WAVES_PER_BLOCK][256];
     __shared__ int s_own[RT_WAVES_PER_BLOCK][256];
     __shared__ uint32_t s_occ[RT_WAVES_PER_BLOCK][256];
-    __shared__ uint32_t s_q1[RT_WAVES_PER_BLOCK][RT_Q1_CAP], s_q2[RT_WAVES_PER_BLOCK][RT_Q2_CAP];
+    __shared__ uint16_t s_q1[RT_WAVES_PER_BLOCK][RT_Q1_CAP];
+    __shared__ uint32_t s_q2[RT_WAVES_PER_BLOCK][RT_Q2_CAP];
     __shared__ uint16_t s_list[RT_WAVES_PER_BLOCK][RT_LIST_CAP + 8];
     __shared__ float s_bun[RT_WAVES_PER_BLOCK][RT_BUNDLE_FLOATS];
     __shared__ float s_rec[RT_WAVES_PER_BLOCK][16 * 32];
@@ -1572,7 +1584,8 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_primary_mfma(const RenderParams P) {
     RT_WAVE_T0
     __shared__ unsigned long long s_bt[RT_WAVES_PER_BLOCK][256];
     __shared__ int s_bid[RT_WAVES_PER_BLOCK][256];
-    __shared__ uint32_t s_q1[RT_WAVES_PER_BLOCK][RT_Q1_CAP], s_q2[RT_WAVES_PER_BLOCK][RT_Q2_CAP];
+    __shared__ uint16_t s_q1[RT_WAVES_PER_BLOCK][RT_Q1_CAP];
+    __shared__ uint32_t s_q2[RT_WAVES_PER_BLOCK][RT_Q2_CAP];
     __shared__ uint16_t s_list[RT_WAVES_PER_BLOCK][RT_LIST_CAP + 8];
     __shared__ float s_bun[RT_WAVES_PER_BLOCK][RT_BUNDLE_FLOATS];
     __shared__ float s_rec[RT_WAVES_PER_BLOCK][16 * 32];
@@ -1581,19 +1594,25 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_primary_mfma(const RenderParams P) {
     const int lane = (int)(threadIdx.x & 63), c = lane & 31, h = lane >> 5;
     const int tx = wave % P.tiles_x, ty = wave / P.tiles_x;
     if (ty >= P.tiles_y) return;
-    const int x0 = tx * RT_TILE_W, x = x0 + c;
+    const int x0 = tx * RT_TILE_W;
     const int ly0 = ty * RT_TILE_H;
+    // Ray e = 32 b + c of the wave is the pixel (ex(e), ey(e)) of the tile: ray block b is an 8 x 4 patch (four patches side
+    // by side, two rows of them), not a 32 x 1 strip — a leaf covers a blob of pixels, a blob touches fewer patches than
+    // strips, and only ray blocks with a candidate get their MFMA re-issued and their 16 registers compared.
+    auto ex = [](int e) { return ((e >> 5) & 3) * 8 + (e & 7); };
+    auto ey = [](int e) { return (e >> 7) * 4 + ((e >> 3) & 3); };
     unsigned long long *bt = s_bt[wv];
     int *bid = s_bid[wv];
     f16x8 B[8];
     const float dzf = (float)P.cam.d;
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
-        const bool ok = x < P.w && ly0 + b < P.nrows;
+        const int x = x0 + ex(b * 32 + c), ly = ly0 + ey(b * 32 + c);
+        const bool ok = x < P.w && ly < P.nrows;
         double ox, oy;
-        sample_offset(P, x, P.row0 + ly0 + b, ox, oy);
+        sample_offset(P, x, P.row0 + ly, ox, oy);
         const float dx = (float)(P.cam.scaleX * ((double)x + ox) + P.cam.dX);
-        const float dy = (float)(P.cam.scaleY * ((double)(P.row0 + ly0 + b) + oy) + P.cam.dY);
+        const float dy = (float)(P.cam.scaleY * ((double)(P.row0 + ly) + oy) + P.cam.dY);
         B[b] = ray_fragment(dx, dy, dzf, ok, h);
         if (h == 0) { bt[b * 32 + c] = ~0ull; bid[b * 32 + c] = -1; }
     }
@@ -1629,7 +1648,7 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_primary_mfma(const RenderParams P) {
         [&](uint32_t entry, uint32_t &entry2) -> bool {           // FP32 record test of one (pixel, leaf) pair
             const int e = (int)(entry & 255u), row = (int)((entry >> 8) & 31u);
             const float *R = Q.rec + row;                                          // apex 0 = the eye
-            const int xe = x0 + (e & 31), ye = P.row0 + ly0 + (e >> 5);
+            const int xe = x0 + ex(e), ye = P.row0 + ly0 + ey(e);
             const int kind = __float_as_int(R[14 * 32]), gid = __float_as_int(R[15 * 32]);
             double ox, oy;
             sample_offset(P, xe, ye, ox, oy);
@@ -1643,7 +1662,7 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_primary_mfma(const RenderParams P) {
             const int e = (int)(entry & 255u);
             const int kind = (int)((entry >> 8) & 1u), gid = (int)(entry >> 9);
             const LeafD &L = P.leaves[gid];
-            const RayD ray = camera_ray(P, x0 + (e & 31), P.row0 + ly0 + (e >> 5));
+            const RayD ray = camera_ray(P, x0 + ex(e), P.row0 + ly0 + ey(e));
             double ix, iy, iz, tt;
             ++nexact;
             const bool hit = (kind == LEAF_TRI ? leaf_isect<LEAF_TRI>(L, ray, ix, iy, iz, tt, RT_TALK(P)) : leaf_isect<LEAF_RECT>(L, ray, ix, iy, iz, tt, RT_TALK(P)))
@@ -1667,14 +1686,15 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_primary_mfma(const RenderParams P) {
         });
     __builtin_amdgcn_wave_barrier();
     RT_WAVE_PHASE(2)
-    // pixels (4h + r, c): the table, then spheres
-    double mt[4]; int mid[4]; bool act[4];
+    // the lane finishes rays (4h + r) * 32 + c: the table, then spheres
+    double mt[4]; int mid[4]; bool act[4]; int px[4], py[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int e = (4 * h + r) * 32 + c;
         mid[r] = bid[e];
         mt[r] = mid[r] >= 0 ? __longlong_as_double((long long)bt[e]) : (double)INFINITY;
-        act[r] = x < P.w && ly0 + 4 * h + r < P.nrows;
+        px[r] = x0 + ex(e); py[r] = ly0 + ey(e);
+        act[r] = px[r] < P.w && py[r] < P.nrows;
     }
     if (P.nsph > 0) {
         Dir4 D; f2 dd[2];
@@ -1682,9 +1702,9 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_primary_mfma(const RenderParams P) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             double ox, oy;
-            sample_offset(P, x, P.row0 + ly0 + 4 * h + r, ox, oy);
-            dx[r] = (float)(P.cam.scaleX * ((double)x + ox) + P.cam.dX);
-            dy[r] = (float)(P.cam.scaleY * ((double)(P.row0 + ly0 + 4 * h + r) + oy) + P.cam.dY);
+            sample_offset(P, px[r], P.row0 + py[r], ox, oy);
+            dx[r] = (float)(P.cam.scaleX * ((double)px[r] + ox) + P.cam.dX);
+            dy[r] = (float)(P.cam.scaleY * ((double)(P.row0 + py[r]) + oy) + P.cam.dY);
         }
 #pragma unroll
         for (int p = 0; p < 2; ++p) { D.x[p] = f2{dx[2 * p], dx[2 * p + 1]}; D.y[p] = f2{dy[2 * p], dy[2 * p + 1]}; D.z[p] = f2{dzf, dzf}; }
@@ -1700,9 +1720,9 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_primary_mfma(const RenderParams P) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     if ((z[r] >= cur.c[9]) & act[r]) {
-                        int yr = P.row0 + ly0 + 4 * h + r;
+                        int yr = P.row0 + py[r];
                         asm volatile("" : "+v"(yr));
-                        const RayD ray = camera_ray(P, x, yr);
+                        const RayD ray = camera_ray(P, px[r], yr);
                         double ix, iy, iz, tt;
                         ++nexact;
                         if (leaf_isect<LEAF_SPHERE>(L, ray, ix, iy, iz, tt, RT_TALK(P)) && guards_ok(P.guards, L.guard, ray)) {
@@ -1715,7 +1735,7 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_primary_mfma(const RenderParams P) {
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-        if (act[r]) P.hit_id[P.out_off + (long long)(ly0 + 4 * h + r) * P.w + x] = mid[r];
+        if (act[r]) P.hit_id[P.out_off + (long long)py[r] * P.w + px[r]] = mid[r];
     for (int o = 32; o > 0; o >>= 1) nexact += __shfl_down(nexact, o);
     if (lane == 0 && nexact) stat_add(P, 1, (unsigned long long)nexact);
     if (lane == 0) stat_add(P, 6, (unsigned long long)nblocks);
