@@ -1361,13 +1361,19 @@ __device__ __forceinline__ bool record_test_staged(const float *rec, int row, in
     return zz >= R[9 * 32];
 }
 
-#ifndef RT_WAVES_EU_MFMA
-#define RT_WAVES_EU_MFMA 3
+// Waves per SIMD the two matrix-core kernels are compiled for.  Measured (profiles/README.md, round 2): the shadow
+// kernel at 4 (128 VGPRs) spills its scan and loses 60 %; the primary kernel at 4 spills 120 B per lane in the exact
+// stage only and gains 7 %.
+#ifndef RT_WAVES_EU_MF_SHADOW
+#define RT_WAVES_EU_MF_SHADOW 3
+#endif
+#ifndef RT_WAVES_EU_MF_PRIMARY
+#define RT_WAVES_EU_MF_PRIMARY 4
 #endif
 
 // Kernel 3 on the matrix cores.  Lane (c = lane & 31, h = lane >> 5): ray column c of each of the wave's 8 ray
 // blocks, half of the leaves of each leaf block.
-__global__ void RT_HOT(RT_WAVES_EU_MFMA) k_shadow_mfma(const RenderParams P) {
+__global__ void RT_HOT(RT_WAVES_EU_MF_SHADOW) k_shadow_mfma(const RenderParams P) {
     RT_WAVE_T0
     const int pl = (int)blockIdx.y;
     const unsigned count = P.qcount[pl];
@@ -1580,7 +1586,7 @@ __global__ void RT_HOT(RT_WAVES_EU_MFMA) k_shadow_mfma(const RenderParams P) {
 // Kernel 1 on the matrix cores.  One wave = 32 x 8 pixel tile; ray block b = tile row b, column c = lane & 31.
 // The nearest hit of every pixel of the tile lives in LDS: t as the bit pattern of the double (t >= 0, so the
 // patterns order like the values) and the leaf index.
-__global__ void RT_HOT(RT_WAVES_EU_MFMA) k_primary_mfma(const RenderParams P) {
+__global__ void RT_HOT(RT_WAVES_EU_MF_PRIMARY) k_primary_mfma(const RenderParams P) {
     RT_WAVE_T0
     __shared__ unsigned long long s_bt[RT_WAVES_PER_BLOCK][256];
     __shared__ int s_bid[RT_WAVES_PER_BLOCK][256];
