@@ -632,8 +632,42 @@ static GenRec make_gen_rec(const LeafD &L, const double omax[3]) {
 // Reflected rays have no common apex, so their leaf records are ordered in space instead: along a Morton curve through
 // the leaves' centroids, cut into blocks of 32 with a bounding sphere each (k_general skips the blocks no ray of a
 // 64-ray run can reach).  Any order gives the same image: the nearest hit is the minimum over (t, leaf index).
-static void spatial_order(const rt_scene &s, const std::vector<int32_t> &gids, const double lo[3], const double hi[3],
-                          std::vector<int32_t> &order, std::vector<float> &spheres) {
+//
+// Stage 0 of the bounce levels, on the matrix cores (k_general): the line of a ray (o, unit d) meets the bounding sphere
+// (c, r) of a leaf iff |c - q|^2 - (c.d)^2 <= r^2, where q = o - (o.d) d is the point of the line nearest the origin of
+// the coordinates.  Taken relative to the centre C of the leaf's block and in units of the block radius R (c~ = (c - C)/R,
+// r~ = r/R, q~ likewise: all of size <= 1 for a ray that meets the leaf), the test is ONE linear form between a vector of
+// the leaf and a vector of the ray,
+//   F = (r~^2 - |c~|^2 + M) * 1 + 2 c~ . q~ - |q~|^2 + sum_ij c~_i c~_j d_i d_j  > 0,
+// 11 products, in plain FP16 with FP32 accumulation: v_mfma_f32_32x32x16_f16 decides 32 leaves x 32 rays per issue.
+// K-half 0 of a row = {r~^2 - |c~|^2 + M, 2 c~x, 2 c~y, 2 c~z, -1, 0, 0, 0} against {1, q~x, q~y, q~z, |q~|^2, 0, 0, 0};
+// K-half 1 = {c~x^2, c~y^2, c~z^2, 2 c~x c~y, 2 c~x c~z, 2 c~y c~z, 0, 0} against {dx^2, dy^2, dz^2, dx dy, dx dz, dy dz, 0, 0}.
+// Margin M: every operand is rounded to half precision (2^-12 relative each); for a ray that meets the leaf |q~| <= 1, so
+// the absolute values of the 11 products sum to <= 5 and their rounding errors to <= 5 * 2^-11 = 0.0025; the ray's q is
+// computed in FP32 from coordinates of size <= dall, an error of <= 2^-20 dall / R in q~, which moves F by <= 4 times that.
+// A far ray (|q~| large) has F ~ -|q~|^2, far more negative than any rounding error; q~ is clamped to +-64 in the kernel.
+constexpr double GEN_ROW_MARGIN = 0.004;
+static void sphere_row(const double c[3], double r, const float S[4], double dall, bool real, uint16_t lo8[8], uint16_t hi8[8]) {
+    for (int k = 0; k < 8; ++k) lo8[k] = hi8[k] = 0;
+    const double always[2] = {-1.0, 1.0};
+    const double R = (double)S[3];
+    bool ok = real && std::isfinite(R) && R > 0 && std::isfinite(r) && std::isfinite(c[0]) && std::isfinite(c[1]) && std::isfinite(c[2]);
+    double ct[3] = {0, 0, 0}, rt = 0, M = 0;
+    if (ok) {
+        for (int i = 0; i < 3; ++i) ct[i] = (c[i] - (double)S[i]) / R;
+        rt = (r * (1.0 + 1e-6) + 1e-7 * dall) / R;
+        M = GEN_ROW_MARGIN + 4.0 * std::ldexp(dall, -20) / R;
+        ok = M < 0.25 && std::fabs(ct[0]) <= 2 && std::fabs(ct[1]) <= 2 && std::fabs(ct[2]) <= 2 && rt <= 2;
+    }
+    if (!ok) { lo8[0] = f16_rne((float)always[real ? 1 : 0]); return; }     // a constant form: every ray (a real leaf) or none (padding)
+    const double v0[5] = {rt * rt - (ct[0] * ct[0] + ct[1] * ct[1] + ct[2] * ct[2]) + M, 2 * ct[0], 2 * ct[1], 2 * ct[2], -1.0};
+    const double v1[6] = {ct[0] * ct[0], ct[1] * ct[1], ct[2] * ct[2], 2 * ct[0] * ct[1], 2 * ct[0] * ct[2], 2 * ct[1] * ct[2]};
+    for (int k = 0; k < 5; ++k) lo8[k] = f16_rne((float)v0[k]);
+    for (int k = 0; k < 6; ++k) hi8[k] = f16_rne((float)v1[k]);
+}
+
+static void spatial_order(const rt_scene &s, const std::vector<int32_t> &gids, const double lo[3], const double hi[3], double dall,
+                          std::vector<int32_t> &order, std::vector<float> &spheres, std::vector<uint16_t> &rows) {
     const size_t n = gids.size();
     std::vector<std::pair<uint32_t, int32_t>> keyed(n);
     std::vector<int> nv(n);
@@ -662,13 +696,14 @@ static void spatial_order(const rt_scene &s, const std::vector<int32_t> &gids, c
     }
     // leaves much larger than the typical one (walls, floors) would blow up the sphere of whatever block they fall into
     // and drag its 31 neighbours into every scan: they come first, in blocks of their own (but for the last of them)
+    std::vector<double> rad(n, 0.0), cen(n * 3, 0.0);          // bounding sphere of every leaf: centroid of its vertices, farthest vertex
     {
-        std::vector<double> rad(n, 0.0);
         for (size_t k = 0; k < n; ++k) {
             double c[3] = {0, 0, 0}, r2 = 0;
             for (int j = 0; j < nv[k]; ++j) for (int i = 0; i < 3; ++i) c[i] += verts[k * 12 + j * 3 + i] / nv[k];
             for (int j = 0; j < nv[k]; ++j) { double d2 = 0; for (int i = 0; i < 3; ++i) { const double d = verts[k * 12 + j * 3 + i] - c[i]; d2 += d * d; } r2 = std::fmax(r2, d2); }
             rad[k] = std::sqrt(r2);
+            for (int i = 0; i < 3; ++i) cen[k * 3 + i] = c[i];
         }
         std::vector<double> sorted(rad);
         std::sort(sorted.begin(), sorted.end());
@@ -708,6 +743,18 @@ static void spatial_order(const rt_scene &s, const std::vector<int32_t> &gids, c
         S[3] = std::nextafterf((float)r, INFINITY);
         if (!std::isfinite(S[0]) || !std::isfinite(S[1]) || !std::isfinite(S[2]) || !std::isfinite(S[3])) { S[0] = S[1] = S[2] = 0.f; S[3] = INFINITY; }
     }
+    spheres[nblk * 4 + 3] = INFINITY;                           // (the padding block: never looked at)
+    // the matrix-core rows of every block: lane (m, h) of a wave reads 16 bytes at rows[((b * 2 + h) * 32 + m) * 8]
+    rows.assign((nblk + 1) * 64 * 8, 0);
+    for (size_t b = 0; b <= nblk; ++b)
+        for (size_t m = 0; m < 32; ++m) {
+            const size_t k = b * 32 + m;
+            const bool real = b < nblk && k < n;
+            const size_t src = real ? (size_t)keyed[k].second : 0;
+            const double zero[3] = {0, 0, 0};
+            sphere_row(real && nv[src] > 0 ? &cen[src * 3] : zero, real && nv[src] > 0 ? rad[src] : INFINITY, &spheres[b * 4], dall, real,
+                       &rows[((b * 2 + 0) * 32 + m) * 8], &rows[((b * 2 + 1) * 32 + m) * 8]);
+        }
 }
 
 void build_filter_records(rt_scene &s, int w, int h, bool eye_only) {
@@ -845,10 +892,15 @@ void build_filter_records(rt_scene &s, int w, int h, bool eye_only) {
             for (int i = 0; i < 3; ++i) omax[i] = (s.leaves.empty() ? 1.0 : std::fmax(std::fabs(lo[i]), std::fabs(hi[i]))) * 1.001 + 1e-3;
             GenRec never{}; never.c[12] = 1.0f;
             s.gen_tri.assign(ntri + 1, never); s.gen_rect.assign(nrect + 1, never);
-            spatial_order(s, s.tri_gid, lo, hi, s.gen_tri_gid, s.gen_tri_sph);
-            spatial_order(s, s.rect_gid, lo, hi, s.gen_rect_gid, s.gen_rect_sph);
-            for (size_t k = 0; k < ntri; ++k) s.gen_tri[k] = make_gen_rec(s.leaves[s.gen_tri_gid[k]], omax);
-            for (size_t k = 0; k < nrect; ++k) s.gen_rect[k] = make_gen_rec(s.leaves[s.gen_rect_gid[k]], omax);
+            const double dall = 2.0 * std::sqrt(omax[0] * omax[0] + omax[1] * omax[1] + omax[2] * omax[2]);   // |o - C| <= dall for points of the scene
+            // records padded to whole blocks (+ one never block): k_general stages the 32 records of a block with one load
+            const size_t tpad = ((ntri + 31) / 32 + 1) * 32, rpad = ((nrect + 31) / 32 + 1) * 32;
+            s.gen_tri.assign(tpad, never); s.gen_rect.assign(rpad, never);
+            spatial_order(s, s.tri_gid, lo, hi, dall, s.gen_tri_gid, s.gen_tri_sph, s.gen_tri_rows);
+            spatial_order(s, s.rect_gid, lo, hi, dall, s.gen_rect_gid, s.gen_rect_sph, s.gen_rect_rows);
+            auto with_gid = [](GenRec r, int32_t gid) { std::memcpy(&r.c[15], &gid, 4); return r; };       // the spare float carries the leaf index
+            for (size_t k = 0; k < ntri; ++k) s.gen_tri[k] = with_gid(make_gen_rec(s.leaves[s.gen_tri_gid[k]], omax), s.gen_tri_gid[k]);
+            for (size_t k = 0; k < nrect; ++k) s.gen_rect[k] = with_gid(make_gen_rec(s.leaves[s.gen_rect_gid[k]], omax), s.gen_rect_gid[k]);
             s.gen_sph.assign(nsph + 1, never);
             for (size_t k = 0; k < nsph; ++k) s.gen_sph[k] = make_sphere_gen_rec(s.leaves[s.sph_gid[k]], omax);
         }
