@@ -122,6 +122,8 @@ struct RenderParams {
     const int32_t *gen_rect_gid;
     const float *gen_tri_sph;       // bounding sphere of every block of 32 consecutive records: centre xyz, radius (inf: always scan)
     const float *gen_rect_sph;
+    const uint16_t *gen_tri_rows;   // the blocks' matrix-core rows: 64 x 16 bytes per block (lane (m, h): K-half h of leaf m), + one padding block
+    const uint16_t *gen_rect_rows;
     CameraD cam;
     double eps;
     int ntri, nrect, nsph, nlights, nleaves, npoint;
@@ -1837,27 +1839,8 @@ __global__ void __launch_bounds__(256) k_final(const RenderParams P) {
 typedef const rt::GenRec RT_CONST *CGenPtr;
 __device__ __forceinline__ CGenPtr as_const(const GenRec *p) { return (CGenPtr)(const void *)p; }
 
-// One ray (the lane's) against one leaf record (wave-uniform: scalar loads).  z >= negm  <=>  the ray may hit the leaf:
-// q_k*a = e_k*a - b*f_k and t*a = -b must all carry the sign of a (rt_scene.cpp: make_gen_rec).
-template <int KIND>
-__device__ __forceinline__ float filter_gen(CGenPtr R, float ox, float oy, float oz, float dx, float dy, float dz) {
-    const float a = __builtin_fmaf(R->c[0], dx, __builtin_fmaf(R->c[1], dy, R->c[2] * dz));
-    const float b = __builtin_fmaf(R->c[0], ox, __builtin_fmaf(R->c[1], oy, __builtin_fmaf(R->c[2], oz, R->c[3])));
-    const float e1 = __builtin_fmaf(R->c[4], ox, __builtin_fmaf(R->c[5], oy, __builtin_fmaf(R->c[6], oz, R->c[7])));
-    const float f1 = __builtin_fmaf(R->c[4], dx, __builtin_fmaf(R->c[5], dy, R->c[6] * dz));
-    const float e2 = __builtin_fmaf(R->c[8], ox, __builtin_fmaf(R->c[9], oy, __builtin_fmaf(R->c[10], oz, R->c[11])));
-    const float f2_ = __builtin_fmaf(R->c[8], dx, __builtin_fmaf(R->c[9], dy, R->c[10] * dz));
-    const float u = __builtin_fmaf(e1, a, -(b * f1));
-    const float v = __builtin_fmaf(e2, a, -(b * f2_));
-    if (KIND == LEAF_TRI) {
-        const float w = a - u - v, t = -b;
-        const float lo = __builtin_fminf(__builtin_fminf(__builtin_fminf(u, v), w), t);
-        const float hi = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(u, v), w), t);
-        return __builtin_fmaxf(lo, -hi);
-    }
-    const float q = __builtin_fabsf(a) - __builtin_fmaxf(__builtin_fabsf(u), __builtin_fabsf(v));
-    return __builtin_fminf(q, -(b * a));
-}
+// Record test of the bounce levels: z >= negm  <=>  the ray may hit the leaf: q_k*a = e_k*a - b*f_k and t*a = -b must all
+// carry the sign of a (rt_scene.cpp: make_gen_rec); filter_gen_staged below evaluates it on a record staged in LDS.
 
 // Bound of one run of 64 reflected rays (one per lane): the origins lie within ro of c, the directions within the cone
 // (a, cos rho) — the same in every lane.  Reflected rays of neighbouring pixels off the same mirror leave from
@@ -1918,65 +1901,170 @@ __device__ __forceinline__ bool run_meets(const RunBound &b, float Cx, float Cy,
     return __builtin_fmaf(vx, b.ax, __builtin_fmaf(vy, b.ay, vz * b.az)) >= dist * c;
 }
 
-// Kernel of the bounce levels.  One wave = one run of 64 reflected rays (what one wave of k_final left: one patch of one
-// surface), one ray per lane.
-//   1. the run's bound against the bounding sphere of every block of 32 leaves (a lane per block);
-//   2. for the blocks that are left, every leaf's record (scalar loads) against the 64 rays: FP32, conservative;
-//   3. pairs that pass go to a queue in LDS and through the exact FP64 evaluation 64 at a time, on all lanes, like the
-//      candidates of the matrix-core kernels; the nearest hit of every ray lives in LDS as (bits of t, leaf).
-struct GenWave {
-    unsigned long long *bt; int *bid; uint32_t *q; double *ray;      // LDS: nearest hit per ray, candidate queue, the 64 rays (9 x 64 doubles)
-    unsigned n, nexact;
-};
-template <class EX>
-__device__ __forceinline__ void gen_push(GenWave &Wv, bool cand, uint32_t entry, EX &&exact) {
-    const unsigned long long m = __builtin_amdgcn_ballot_w64(cand);
-    if (!m) return;                                               // wave-uniform
-    if (cand) Wv.q[Wv.n + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = entry;
-    Wv.n += (unsigned)__popcll(m);
-    if (Wv.n >= 64u) {
-        Wv.n -= 64u;
-        exact(Wv.q[Wv.n + (threadIdx.x & 63u)], true);
+// The same test on a record staged in LDS (WaveQueues::rec: c[k] of row r at rec[32 k + r]); R = rec + row.
+template <int KIND>
+__device__ __forceinline__ float filter_gen_staged(const float *R, float ox, float oy, float oz, float dx, float dy, float dz) {
+    const float n0 = R[0 * 32], n1 = R[1 * 32], n2 = R[2 * 32];
+    const float g0 = R[4 * 32], g1 = R[5 * 32], g2 = R[6 * 32];
+    const float k0 = R[8 * 32], k1 = R[9 * 32], k2 = R[10 * 32];
+    const float a = __builtin_fmaf(n0, dx, __builtin_fmaf(n1, dy, n2 * dz));
+    const float b = __builtin_fmaf(n0, ox, __builtin_fmaf(n1, oy, __builtin_fmaf(n2, oz, R[3 * 32])));
+    const float e1 = __builtin_fmaf(g0, ox, __builtin_fmaf(g1, oy, __builtin_fmaf(g2, oz, R[7 * 32])));
+    const float f1 = __builtin_fmaf(g0, dx, __builtin_fmaf(g1, dy, g2 * dz));
+    const float e2 = __builtin_fmaf(k0, ox, __builtin_fmaf(k1, oy, __builtin_fmaf(k2, oz, R[11 * 32])));
+    const float f2_ = __builtin_fmaf(k0, dx, __builtin_fmaf(k1, dy, k2 * dz));
+    const float u = __builtin_fmaf(e1, a, -(b * f1));
+    const float v = __builtin_fmaf(e2, a, -(b * f2_));
+    if (KIND == LEAF_TRI) {
+        const float w = a - u - v, t = -b;
+        const float lo = __builtin_fminf(__builtin_fminf(__builtin_fminf(u, v), w), t);
+        const float hi = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(u, v), w), t);
+        return __builtin_fmaxf(lo, -hi);
     }
+    const float q = __builtin_fabsf(a) - __builtin_fmaxf(__builtin_fabsf(u), __builtin_fabsf(v));
+    return __builtin_fminf(q, -(b * a));
 }
 
+// Kernel of the bounce levels.  One wave = one run of 64 reflected rays (what one wave of k_final left: one patch of one
+// surface).  Lane (c = lane & 31, h = lane >> 5) looks after ray column c of the run's two ray blocks (rays c and 32 + c).
+//   1. the run's bound against the bounding sphere of every block of 32 leaves (a lane per block);
+//   2. for the blocks that are left, stage 0 on the matrix cores: the line of every ray against the bounding sphere of
+//      every leaf of the block, one linear form per pair (rt_scene.cpp: sphere_row), 32 leaves x 32 rays per MFMA; the
+//      ray's vector depends on the block (the point of the line nearest the block's centre), so the B operand is rebuilt
+//      per block: ~25 vector instructions per ray block, against the 20 per LEAF of the scalar-record loop this replaces;
+//   3. pairs that pass go through the wave's LDS queues like the candidates of the other two matrix-core kernels: the
+//      FP32 record test of the exact shape on the block's records staged in LDS, then the exact FP64 evaluation, both 64
+//      pairs at a time on all lanes; the nearest hit of every ray lives in LDS as (bits of t, leaf).
+// Ray flags (LDS): 0 = no ray (padding of k_final, end of the list), 1 = a ray, 2 = a ray whose direction or origin is
+// not a usable number (NaN, inf, zero): it skips stage 0 and meets every record, as it did before there was a stage 0.
+template <class EX>
+__device__ __forceinline__ void q2_push(WaveQueues &Q, bool cand, uint32_t entry, EX &&exact) {
+    if (!__builtin_amdgcn_ballot_w64(cand)) return;                // wave-uniform
+    q_push(Q.q2, Q.n2, cand, entry);
+    if (Q.n2 >= 64u) { Q.n2 -= 64u; exact(Q.q2[Q.n2 + (threadIdx.x & 63u)]); }
+}
+
+struct GenRays {                 // the two rays of a lane's column, FP32: origin, unit direction; flag as above
+    float o[2][3], u[2][3];
+    int flag[2];
+    f16x8 Bc[2];                 // K-half 1 of the ray's vector: {dx^2, dy^2, dz^2, dx dy, dx dz, dy dz, 0, 0} (the same for every block)
+};
+
 template <int KIND, class EX>
-__device__ __forceinline__ void general_blocks(const RenderParams &P, const GenRec *recs, const int32_t *gids, const float *spheres, int n,
-                                               const RunBound &rb, bool act, float ox, float oy, float oz, float dx, float dy, float dz,
-                                               GenWave &Wv, unsigned &nblocks, EX &&exact) {
-    const int lane = (int)(threadIdx.x & 63), nblk = (n + 31) / 32;
+__device__ __forceinline__ void general_blocks(const RenderParams &P, const GenRec *recs, const uint16_t *rows, const float *spheres, int n,
+                                               const RunBound &rb, const GenRays &G, const double *s_ray, const int *s_flag, bool anybad,
+                                               WaveQueues &Q, unsigned &nblocks, EX &&exact) {
+    const int lane = (int)(threadIdx.x & 63), c = lane & 31, h = lane >> 5, nblk = (n + 31) / 32;
+    const i32x4 *rows4 = reinterpret_cast<const i32x4 *>(rows);
+    const float4 *sph4 = reinterpret_cast<const float4 *>(spheres);
+    auto stage1 = [&](uint32_t entry, uint32_t &entry2) -> bool {
+        const int e = (int)(entry & 63u), row = (int)((entry >> 8) & 31u);
+        const float *R = Q.rec + row;
+        const float ox = (float)s_ray[0 * 64 + e], oy = (float)s_ray[1 * 64 + e], oz = (float)s_ray[2 * 64 + e];
+        const float dx = (float)s_ray[3 * 64 + e], dy = (float)s_ray[4 * 64 + e], dz = (float)s_ray[5 * 64 + e];
+        const float z = filter_gen_staged<KIND>(R, ox, oy, oz, dx, dy, dz);
+        entry2 = ((uint32_t)__float_as_int(R[15 * 32]) << 8) | ((uint32_t)KIND << 6) | (uint32_t)e;
+        return z >= R[12 * 32];
+    };
     for (int g0 = 0; g0 < nblk; g0 += 64) {
-        const int g = g0 + lane;
-        bool pass = g < nblk;
+        const int gl = g0 + lane;
+        bool pass = gl < nblk;
         if (pass) {
-            const float4 S = reinterpret_cast<const float4 *>(spheres)[g];
+            const float4 S = sph4[gl];
             pass = run_meets(rb, S.x, S.y, S.z, S.w);
         }
         unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
         nblocks += (unsigned)__popcll(m);
-        while (m) {                                               // wave-uniform
-            const int i0 = (g0 + __ffsll((long long)m) - 1) * 32;
+        if (!m) continue;
+        // the loads of a block (its sphere, its rows) are issued one block ahead; the padding block nblk ends the chain
+        int g = g0 + __ffsll((long long)m) - 1;
+        m &= m - 1ull;
+        float4 Sn = sph4[g];
+        i32x4 An = rows4[(size_t)g * 64 + lane];
+        for (;;) {                                                  // wave-uniform
+            const float4 S = Sn;
+            const i32x4 A = An;
+            const int gc = g;
+            const bool more = m != 0ull;
+            g = more ? g0 + __ffsll((long long)m) - 1 : nblk;
             m &= m - 1ull;
-            CGenPtr R = as_const(recs + i0);
-            CIntPtr G = as_const(gids + i0);
-            const int cnt = min(32, n - i0);
-            for (int i = 0; i < cnt; ++i) {
-                const float z = filter_gen<KIND>(R + i, ox, oy, oz, dx, dy, dz);
-                gen_push(Wv, act && z >= R[i].c[12], ((uint32_t)G[i] << 8) | ((uint32_t)KIND << 6) | (uint32_t)lane, exact);
+            Sn = sph4[g];
+            An = rows4[(size_t)g * 64 + lane];
+            const float Cx = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(S.x)));
+            const float Cy = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(S.y)));
+            const float Cz = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(S.z)));
+            const float Rb = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(S.w)));
+            const float inv = Rb < 3.0e38f ? __builtin_amdgcn_rcpf(Rb) : 0.f;      // a block without a sphere: its rows are constants
+            f16x8 B[2];
+            int mx[2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const float px = G.o[b][0] - Cx, py = G.o[b][1] - Cy, pz = G.o[b][2] - Cz;
+                const float sd = __builtin_fmaf(px, G.u[b][0], __builtin_fmaf(py, G.u[b][1], pz * G.u[b][2]));
+                // q = the point of the ray's line nearest the block centre, in block radii; far away is far enough at 64
+                const float qx = __builtin_amdgcn_fmed3f(__builtin_fmaf(-sd, G.u[b][0], px) * inv, -64.f, 64.f);
+                const float qy = __builtin_amdgcn_fmed3f(__builtin_fmaf(-sd, G.u[b][1], py) * inv, -64.f, 64.f);
+                const float qz = __builtin_amdgcn_fmed3f(__builtin_fmaf(-sd, G.u[b][2], pz) * inv, -64.f, 64.f);
+                const float qq = __builtin_fmaf(qx, qx, __builtin_fmaf(qy, qy, qz * qz));
+                const bool on = G.flag[b] == 1;
+                const _Float16 z0 = (_Float16)0.f;
+                const f16x8 Bq = {on ? (_Float16)1.f : z0, on ? (_Float16)qx : z0, on ? (_Float16)qy : z0, on ? (_Float16)qz : z0,
+                                  on ? (_Float16)qq : z0, z0, z0, z0};
+                B[b] = h ? G.Bc[b] : Bq;
+                mx[b] = step_max(mfma0(A, B[b]));
+                if (G.flag[b] == 2) mx[b] = 1;
             }
+            unsigned mb = (__builtin_amdgcn_ballot_w64(mx[0] > 0) != 0ull ? 1u : 0u) | (__builtin_amdgcn_ballot_w64(mx[1] > 0) != 0ull ? 2u : 0u);
+            if (mb) {                                               // wave-uniform
+                // the records of this block's 32 leaves: 2 KiB, 32 bytes per lane (lane l: half l & 1 of record l >> 1)
+                const float4 *rsrc = reinterpret_cast<const float4 *>(recs + (size_t)gc * 32) + 2 * lane;
+                const float4 r0 = rsrc[0], r1 = rsrc[1];
+                float *dst = Q.rec + (lane & 1) * 8 * 32 + (lane >> 1);
+                dst[0 * 32] = r0.x; dst[1 * 32] = r0.y; dst[2 * 32] = r0.z; dst[3 * 32] = r0.w;
+                dst[4 * 32] = r1.x; dst[5 * 32] = r1.y; dst[6 * 32] = r1.z; dst[7 * 32] = r1.w;
+                __builtin_amdgcn_wave_barrier();
+                const uint32_t lane_part = ((uint32_t)(4 * h) << 8) | (uint32_t)c;
+#pragma unroll 1
+                for (int b = 0; b < 2; ++b) {
+                    if (!((mb >> b) & 1u)) continue;
+                    const f32x16 pa = mfma0(A, b ? B[1] : B[0]);      // issued again (bit-identical): the 16 results were not kept
+                    const bool force = anybad && (b ? G.flag[1] : G.flag[0]) == 2;
+                    const uint32_t eb = lane_part + (uint32_t)(b * 32);
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const bool p = __float_as_int(pa[q]) > 0 || force;
+                        const unsigned long long pm = __builtin_amdgcn_ballot_w64(p);
+                        if (pm) {                                   // wave-uniform
+                            if (p) Q.q1[Q.n1 + __builtin_amdgcn_mbcnt_hi((unsigned)(pm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)pm, 0u))] =
+                                (uint16_t)(eb + (uint32_t)(((q & 3) + 8 * (q >> 2)) << 8));
+                            Q.n1 += (unsigned)__popcll(pm);
+                        }
+                    }
+                    q_drain(Q, 63u, false, stage1, exact);
+                }
+                q_drain(Q, 0u, false, stage1, exact);               // q1 is empty before `rec` is overwritten
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (!more) break;
         }
     }
 }
 
-__global__ void __attribute__((amdgpu_waves_per_eu(4, 8))) __launch_bounds__(64) k_general(const RenderParams P) {
+#ifndef RT_WAVES_EU_GEN
+#define RT_WAVES_EU_GEN 4
+#endif
+__global__ void __attribute__((amdgpu_waves_per_eu(RT_WAVES_EU_GEN, 8))) __launch_bounds__(64) k_general(const RenderParams P) {
     __shared__ unsigned long long s_bt[64];
     __shared__ int s_bid[64];
-    __shared__ uint32_t s_q[128];
+    __shared__ int s_flag[64];
+    __shared__ uint16_t s_q1[RT_Q1_CAP];
+    __shared__ uint32_t s_q2[RT_Q2_CAP];
     __shared__ double s_ray[9 * 64];
+    __shared__ float s_rec[16 * 32];
     const unsigned count = num_slots(P);
     const unsigned wave = blockIdx.x;
     if (wave * 64u >= count) return;
-    const int lane = (int)(threadIdx.x & 63);
+    const int lane = (int)(threadIdx.x & 63), c = lane & 31;
     const unsigned slot = wave * 64u + (unsigned)lane;
     const bool inlist = slot < count;
     const bool act = inlist && P.rays[slot].parent != 0xffffffffu;       // (not a padding entry of k_final)
@@ -1990,38 +2078,55 @@ __global__ void __attribute__((amdgpu_waves_per_eu(4, 8))) __launch_bounds__(64)
     const float ox = (float)ray.px, oy = (float)ray.py, oz = (float)ray.pz;
     const float dx = (float)ray.dx, dy = (float)ray.dy, dz = (float)ray.dz;
     const RunBound rb = run_bound(act, ox, oy, oz, dx, dy, dz, P.cull != 0);
+    bool anybad;
+    {
+        const float dd = __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, dz * dz));
+        const bool bad = act && !(dd > 1e-30f && dd < 1e30f && __builtin_fabsf(ox) < 1e18f && __builtin_fabsf(oy) < 1e18f && __builtin_fabsf(oz) < 1e18f);
+        s_flag[lane] = act ? (bad ? 2 : 1) : 0;
+        anybad = __builtin_amdgcn_ballot_w64(bad) != 0ull;
+    }
     __builtin_amdgcn_wave_barrier();
-    GenWave Wv = {s_bt, s_bid, s_q, s_ray, 0u, 0u};
-    unsigned nblocks = 0;
-    // exact: intersect leaf reflected-ray (Main.hs:543 inside trace (n-1)), for the entry's ray; `all`: every lane holds one
-    auto exact = [&](uint32_t entry, bool have) {
+    GenRays G;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int e = 32 * b + c;
+        G.flag[b] = s_flag[e];
+        const float ex = (float)s_ray[3 * 64 + e], ey = (float)s_ray[4 * 64 + e], ez = (float)s_ray[5 * 64 + e];
+        const float rn = G.flag[b] == 1 ? __builtin_amdgcn_rsqf(__builtin_fmaf(ex, ex, __builtin_fmaf(ey, ey, ez * ez))) : 0.f;
+        G.u[b][0] = ex * rn; G.u[b][1] = ey * rn; G.u[b][2] = ez * rn;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) G.o[b][k] = G.flag[b] == 1 ? (float)s_ray[k * 64 + e] : 0.f;
+        const _Float16 z0 = (_Float16)0.f;
+        G.Bc[b] = f16x8{(_Float16)(G.u[b][0] * G.u[b][0]), (_Float16)(G.u[b][1] * G.u[b][1]), (_Float16)(G.u[b][2] * G.u[b][2]),
+                        (_Float16)(G.u[b][0] * G.u[b][1]), (_Float16)(G.u[b][0] * G.u[b][2]), (_Float16)(G.u[b][1] * G.u[b][2]), z0, z0};
+    }
+    WaveQueues Q = {s_q1, s_q2, 0u, 0u, 0u, s_rec};
+    unsigned nblocks = 0, nexact = 0;
+    // exact: intersect leaf reflected-ray (Main.hs:543 inside trace (n-1)), for the entry's ray
+    auto exact = [&](uint32_t entry) {
         const int e = (int)(entry & 63u), kind = (int)((entry >> 6) & 3u), gid = (int)(entry >> 8);
-        bool hit = false;
-        double tt = 0;
-        if (have) {
-            const LeafD &L = P.leaves[gid];
-            RayD r;
-            r.px = Wv.ray[0 * 64 + e]; r.py = Wv.ray[1 * 64 + e]; r.pz = Wv.ray[2 * 64 + e];
-            r.dx = Wv.ray[3 * 64 + e]; r.dy = Wv.ray[4 * 64 + e]; r.dz = Wv.ray[5 * 64 + e];
-            r.rx = Wv.ray[6 * 64 + e]; r.ry = Wv.ray[7 * 64 + e]; r.rz = Wv.ray[8 * 64 + e];
-            double ix, iy, iz;
-            ++Wv.nexact;
-            hit = (kind == LEAF_TRI ? leaf_isect<LEAF_TRI>(L, r, ix, iy, iz, tt, RT_TALK(P))
-                   : (kind == LEAF_RECT ? leaf_isect<LEAF_RECT>(L, r, ix, iy, iz, tt, RT_TALK(P)) : leaf_isect<LEAF_SPHERE>(L, r, ix, iy, iz, tt, RT_TALK(P))))
-                  && guards_ok(P.guards, L.guard, r);
-        }
+        const LeafD &L = P.leaves[gid];
+        RayD r;
+        r.px = s_ray[0 * 64 + e]; r.py = s_ray[1 * 64 + e]; r.pz = s_ray[2 * 64 + e];
+        r.dx = s_ray[3 * 64 + e]; r.dy = s_ray[4 * 64 + e]; r.dz = s_ray[5 * 64 + e];
+        r.rx = s_ray[6 * 64 + e]; r.ry = s_ray[7 * 64 + e]; r.rz = s_ray[8 * 64 + e];
+        double ix, iy, iz, tt = 0;
+        ++nexact;
+        const bool hit = (kind == LEAF_TRI ? leaf_isect<LEAF_TRI>(L, r, ix, iy, iz, tt, RT_TALK(P))
+                          : (kind == LEAF_RECT ? leaf_isect<LEAF_RECT>(L, r, ix, iy, iz, tt, RT_TALK(P)) : leaf_isect<LEAF_SPHERE>(L, r, ix, iy, iz, tt, RT_TALK(P))))
+                         && guards_ok(P.guards, L.guard, r);
         // nearest wins; equal t -> the left-most leaf of the tree (Main.hs:213-214); the same four steps as in k_primary_mfma
         const unsigned long long tb = (unsigned long long)__double_as_longlong(tt + 0.0);
         unsigned long long old = 0;
-        if (hit) { old = Wv.bt[e]; atomicMin(&Wv.bt[e], tb); }
+        if (hit) { old = s_bt[e]; atomicMin(&s_bt[e], tb); }
         __builtin_amdgcn_wave_barrier();
-        const bool win = hit && Wv.bt[e] == tb;
-        if (win && tb < old) Wv.bid[e] = 0x7fffffff;
+        const bool win = hit && s_bt[e] == tb;
+        if (win && tb < old) s_bid[e] = 0x7fffffff;
         __builtin_amdgcn_wave_barrier();
-        if (win) atomicMin(&Wv.bid[e], gid);
+        if (win) atomicMin(&s_bid[e], gid);
     };
-    general_blocks<LEAF_TRI>(P, P.gen_tri, P.gen_tri_gid, P.gen_tri_sph, P.ntri, rb, act, ox, oy, oz, dx, dy, dz, Wv, nblocks, exact);
-    general_blocks<LEAF_RECT>(P, P.gen_rect, P.gen_rect_gid, P.gen_rect_sph, P.nrect, rb, act, ox, oy, oz, dx, dy, dz, Wv, nblocks, exact);
+    general_blocks<LEAF_TRI>(P, P.gen_tri, P.gen_tri_rows, P.gen_tri_sph, P.ntri, rb, G, s_ray, s_flag, anybad, Q, nblocks, exact);
+    general_blocks<LEAF_RECT>(P, P.gen_rect, P.gen_rect_rows, P.gen_rect_sph, P.nrect, rb, G, s_ray, s_flag, anybad, Q, nblocks, exact);
     if (P.nsph > 0) {           // spheres (few per scene): delta/4 = (d.o)^2 - (o.o - r^2) with o = origin - centre, Main.hs:396-400
         CGenPtr recs = as_const(P.gen_sph);
         CIntPtr gids = as_const(P.sph_gid);
@@ -2029,25 +2134,20 @@ __global__ void __attribute__((amdgpu_waves_per_eu(4, 8))) __launch_bounds__(64)
             CGenPtr R = recs + i;
             const float sx = ox - R->c[0], sy = oy - R->c[1], sz = oz - R->c[2];
             const float b = __builtin_fmaf(dx, sx, __builtin_fmaf(dy, sy, dz * sz));
-            const float c = __builtin_fmaf(sx, sx, __builtin_fmaf(sy, sy, __builtin_fmaf(sz, sz, -R->c[3])));
-            const float z = __builtin_fmaf(b, b, -c);
-            gen_push(Wv, act && z >= R->c[12], ((uint32_t)gids[i] << 8) | ((uint32_t)LEAF_SPHERE << 6) | (uint32_t)lane, exact);
+            const float cc = __builtin_fmaf(sx, sx, __builtin_fmaf(sy, sy, __builtin_fmaf(sz, sz, -R->c[3])));
+            const float z = __builtin_fmaf(b, b, -cc);
+            q2_push(Q, act && z >= R->c[12], ((uint32_t)gids[i] << 8) | ((uint32_t)LEAF_SPHERE << 6) | (uint32_t)lane, exact);
         }
     }
-    if (Wv.n > 0u) {                                              // the last, partial batch
-        const bool have = (unsigned)lane < Wv.n;
-        const uint32_t entry = have ? Wv.q[lane] : 0u;
-        Wv.n = 0u;
-        exact(entry, have);
-    }
+    q_drain(Q, 0u, true, [](uint32_t, uint32_t &) { return false; }, exact);       // the last, partial batch
     __builtin_amdgcn_wave_barrier();
-    if (inlist) P.hit_id[P.out_off + slot] = Wv.bid[lane];       // padding entries: -1 (a miss)
-    unsigned nexact = Wv.nexact;
+    if (inlist) P.hit_id[P.out_off + slot] = s_bid[lane];        // padding entries: -1 (a miss)
     for (int o2 = 32; o2 > 0; o2 >>= 1) nexact += __shfl_down(nexact, o2);
     if (lane == 0 && nexact) stat_add(P, 1, (unsigned long long)nexact);
     const unsigned nrays = (unsigned)__popcll(__builtin_amdgcn_ballot_w64(act));
     if (lane == 0) stat_add(P, 5, (unsigned long long)nrays);     // reflected rays traced
     if (lane == 0) stat_add(P, 8, (unsigned long long)nblocks);   // (run of 64 rays, block of 32 leaves) pairs looked at
+    if (lane == 0 && Q.nrec) stat_add(P, 4, (unsigned long long)Q.nrec);
 }
 
 // colour of a level folded into the level below: addPixelRGB8 direct (scalePixelRGB8 reflectivity sub), Main.hs:545, 554
@@ -2262,6 +2362,8 @@ int device_prepare(rt_scene &s, DeviceScene &D, int device, int w, int h) {
             if ((rc = upload(D.gen_rect_gid, s.gen_rect_gid))) return rc;
             if ((rc = upload(D.gen_tri_sph, s.gen_tri_sph))) return rc;
             if ((rc = upload(D.gen_rect_sph, s.gen_rect_sph))) return rc;
+            if ((rc = upload(D.gen_tri_rows, s.gen_tri_rows))) return rc;
+            if ((rc = upload(D.gen_rect_rows, s.gen_rect_rows))) return rc;
         }
         if ((rc = upload(D.tri_gid, s.tri_gid))) return rc;
         if ((rc = upload(D.rect_gid, s.rect_gid))) return rc;
@@ -2442,6 +2544,7 @@ int render_rows(rt_scene *s, DeviceScene &D, const Workspace &W, size_t crow, in
     P.gen_tri = (const GenRec *)D.gen_tri.p; P.gen_rect = (const GenRec *)D.gen_rect.p;
     P.gen_tri_gid = (const int32_t *)D.gen_tri_gid.p; P.gen_rect_gid = (const int32_t *)D.gen_rect_gid.p;
     P.gen_tri_sph = (const float *)D.gen_tri_sph.p; P.gen_rect_sph = (const float *)D.gen_rect_sph.p;
+    P.gen_tri_rows = (const uint16_t *)D.gen_tri_rows.p; P.gen_rect_rows = (const uint16_t *)D.gen_rect_rows.p;
     P.sph_rec = (const FilterRec *)D.sph_rec.p; P.gen_sph = (const GenRec *)D.gen_sph.p; P.sph_gid = (const int32_t *)D.sph_gid.p;
     P.nsph = (int)s->sph_gid.size();
     P.mf_rows = (const uint16_t *)D.mf_rows.p; P.mf_gid = (const int32_t *)D.mf_gid.p; P.mf_rec = (const FilterRec *)D.mf_rec.p;
@@ -2627,7 +2730,7 @@ void rt_scene_destroy(rt_scene *s) {
         if (d.copy_stream) (void)hipStreamSynchronize((hipStream_t)d.copy_stream);
         DevBuf *bufs[] = {&d.leaves, &d.aux, &d.guards, &d.mats, &d.lights, &d.tri_rec, &d.rect_rec, &d.tri_gid, &d.rect_gid,
                           &d.sph_rec, &d.gen_sph, &d.sph_gid, &d.mf_rows, &d.mf_gid, &d.mf_cone, &d.mf_rec, &d.gen_tri, &d.gen_rect,
-                          &d.gen_tri_gid, &d.gen_rect_gid, &d.gen_tri_sph, &d.gen_rect_sph};
+                          &d.gen_tri_gid, &d.gen_rect_gid, &d.gen_tri_sph, &d.gen_rect_sph, &d.gen_tri_rows, &d.gen_rect_rows};
         for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
         Workspace &W = d.ws;
         void *ptrs[] = {W.counters, W.qcount, W.hit_id, W.accum, W.hitrec, W.queue, W.qsparse, W.tcount, W.lit,

@@ -891,7 +891,6 @@ void build_filter_records(rt_scene &s, int w, int h, bool eye_only) {
             double omax[3];
             for (int i = 0; i < 3; ++i) omax[i] = (s.leaves.empty() ? 1.0 : std::fmax(std::fabs(lo[i]), std::fabs(hi[i]))) * 1.001 + 1e-3;
             GenRec never{}; never.c[12] = 1.0f;
-            s.gen_tri.assign(ntri + 1, never); s.gen_rect.assign(nrect + 1, never);
             const double dall = 2.0 * std::sqrt(omax[0] * omax[0] + omax[1] * omax[1] + omax[2] * omax[2]);   // |o - C| <= dall for points of the scene
             // records padded to whole blocks (+ one never block): k_general stages the 32 records of a block with one load
             const size_t tpad = ((ntri + 31) / 32 + 1) * 32, rpad = ((nrect + 31) / 32 + 1) * 32;
@@ -1236,6 +1235,21 @@ int rt_scene_get_general_block(const rt_scene *s, int kind, int block, float sph
     if (block < 0 || block >= nblk) { set_error("rt_scene_get_general_block: block out of range"); return RT_ERR_ARG; }
     for (int k = 0; k < 4; ++k) sphere[k] = sph[(size_t)block * 4 + k];
     for (int k = 0; k < 32; ++k) { const size_t i = (size_t)block * 32 + k; leaves[k] = i < gid.size() ? gid[i] : -1; }
+    return nblk;
+}
+
+int rt_scene_get_general_rows(const rt_scene *s, int kind, int block, uint16_t out[512]) {
+    if (!s || !out || (kind != LEAF_RECT && kind != LEAF_TRI) || s->rec_w < 0) {
+        set_error("rt_scene_get_general_rows: bad argument (call rt_scene_prepare_host first)"); return RT_ERR_ARG;
+    }
+    const std::vector<int32_t> &gid = kind == LEAF_TRI ? s->gen_tri_gid : s->gen_rect_gid;
+    const std::vector<uint16_t> &rows = kind == LEAF_TRI ? s->gen_tri_rows : s->gen_rect_rows;
+    const int nblk = (int)((gid.size() + 31) / 32);
+    if (!s->reflective) return 0;
+    if (block < 0 || block >= nblk) { set_error("rt_scene_get_general_rows: block out of range"); return RT_ERR_ARG; }
+    for (int m = 0; m < 32; ++m)
+        for (int h = 0; h < 2; ++h)
+            for (int k = 0; k < 8; ++k) out[m * 16 + h * 8 + k] = rows[(((size_t)block * 2 + h) * 32 + m) * 8 + k];
     return nblk;
 }
 

@@ -14,6 +14,7 @@ if len(sys.argv) > 3 and sys.argv[3] == "nocull":
 rgba = torch.empty((h, w, 4), dtype=torch.uint8, device="cuda")
 hit = torch.empty((h, w), dtype=torch.int32, device="cuda")
 prev = None
+first = None
 for depth in (1, 2, 3, 4):
     for _ in range(2):
         sc.render_device(w, h, rgba.data_ptr(), hit.data_ptr(), depth=depth)
@@ -23,7 +24,10 @@ for depth in (1, 2, 3, 4):
         dr = st["bounce_rays"] - prev["bounce_rays"]
         dms = st["ms_primary"] - prev["ms_primary"]
         nblk = -(-4000 // 32) + -(-(sc.num_leaves - 4000 - 1) // 32)
-        line += f"\n   this level: {dr} rays in {dms:.3f} ms = {dr / dms / 1e3:.0f} Mrays/s; blocks looked at per wave {(st['bounce_blocks'] - prev['bounce_blocks']) / (dr / 256):.1f} of ~{nblk}; exact per ray {(st['exact_evals'] - prev['exact_evals']) / dr:.2f} (incl. the level's shadow rays)"
+        line += f"\n   this level: {dr} rays in {dms:.3f} ms = {dr / dms / 1e3:.0f} Mrays/s; blocks looked at per wave {(st['bounce_blocks'] - prev['bounce_blocks']) / (dr / 64):.1f} of ~{nblk}; exact per ray {(st['exact_evals'] - prev['exact_evals']) / dr:.2f} (incl. the level's shadow rays)"
+    if first is None:
+        first = st
+        line += f"\n   primary level: {w * h} rays in {st['ms_primary']:.3f} ms = {w * h / st['ms_primary'] / 1e3:.0f} Mrays/s"
     print(line)
     prev = st
-print(f"primary level: {w * h / prev['ms_primary'] / 1e3 if False else 0}")
+print(f"records = FP32 record tests so far (all kernels)")
