@@ -181,10 +181,11 @@ int  rt_scene_get_block_cone(const rt_scene *, int apex, int block, float out[8]
  * {centre xyz, radius} (radius inf: always looked at), leaves = its leaf indices (-1: none).  Returns the number of blocks
  * (0 for a scene without reflective materials: nothing is built). */
 int  rt_scene_get_general_block(const rt_scene *, int kind, int block, float sphere[4], int32_t leaves[32]);
-/* The matrix-core rows of the same block (stage 0 of the bounce levels): 32 rows x 16 halfs (IEEE binary16 bit patterns),
-   row m = the bounding sphere of leaf m of the block as a linear form in the ray's vector (rt_scene.cpp: sphere_row;
-   DESIGN.md section 3).  Introspection for the CPU tests of the filter; returns the number of blocks. */
-int  rt_scene_get_general_rows(const rt_scene *, int kind, int block, uint16_t out[512]);
+/* The matrix-core rows of the same block (stage 0 of the bounce levels): 32 rows x 32 halfs (IEEE binary16 bit patterns,
+   K index = 16 step + 8 half + slot), row m = the bounding sphere of leaf m of the block as a linear form in the ray's
+   vector, written in the frame {centre xyz, radius} of the block's super-block (rt_scene.cpp: sphere_row; DESIGN.md
+   section 3).  Introspection for the CPU tests of the filter; returns the number of blocks. */
+int  rt_scene_get_general_rows(const rt_scene *, int kind, int block, float frame[4], uint16_t out[1024]);
 /* Guard chain of `leaf`: writes up to cap boxes {x0,y0,z0,x1,y1,z1}, innermost first; returns the count. */
 int  rt_scene_get_guards(const rt_scene *, int leaf, double *out, int cap);
 /* fixedCamera w h: out = {scaleX, scaleY, dX, dY, d}                      Main.hs:506-527 */

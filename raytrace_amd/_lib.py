@@ -68,7 +68,7 @@ SYMBOLS = {
     "rt_scene_get_mfma_row": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_uint16)]),
     "rt_scene_get_block_cone": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "rt_scene_get_general_block": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
-    "rt_scene_get_general_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_uint16)]),
+    "rt_scene_get_general_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_uint16)]),
     "rt_scene_get_guards": (C.c_int, [C.c_void_p, C.c_int, _D3, C.c_int]),
     "rt_camera_params": (C.c_int, [C.c_int, C.c_int, _D3]),
     "rt_render": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int,

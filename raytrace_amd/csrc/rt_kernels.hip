@@ -122,8 +122,10 @@ struct RenderParams {
     const int32_t *gen_rect_gid;
     const float *gen_tri_sph;       // bounding sphere of every block of 32 consecutive records: centre xyz, radius (inf: always scan)
     const float *gen_rect_sph;
-    const uint16_t *gen_tri_rows;   // the blocks' matrix-core rows: 64 x 16 bytes per block (lane (m, h): K-half h of leaf m), + one padding block
+    const uint16_t *gen_tri_rows;   // the blocks' matrix-core rows: 2 K steps x 64 x 16 bytes per block (lane (m, h): K-half h of leaf m), + one padding block
     const uint16_t *gen_rect_rows;
+    const float *gen_tri_ssph;      // super-blocks of 32 blocks: bounding sphere = the frame their leaves' rows are written in
+    const float *gen_rect_ssph;
     CameraD cam;
     double eps;
     int ntri, nrect, nsph, nlights, nleaves, npoint;
@@ -235,9 +237,34 @@ __device__ __forceinline__ unsigned num_slots(const RenderParams &P) {
     return c < (unsigned)P.lcap ? c : (unsigned)P.lcap;
 }
 // the ray of a slot: `cast camera x y` at level 0, `mkray (ipos + 1e-5 rdir) rdir` (Main.hs:552) above
+// A level's ray list in memory: runs of 64 slots, structure-of-arrays inside a run (8 fields x 64 x 8 bytes = 4 KiB per
+// run: origin, direction, reflectivity, parent slot), so that a wave reading or writing the rays of a run touches 512
+// contiguous bytes per field.  (As an array of 72-byte structures every field access of a wave scattered over 36 cache
+// lines: k_final spent 0.4 of its 0.47 ms per chunk writing the reflected rays.)  RayRec is the value in registers.
+__device__ __forceinline__ size_t ray_index(unsigned slot, int field) { return ((size_t)(slot >> 6) * 8 + (size_t)field) * 64 + (slot & 63u); }
+__device__ __forceinline__ uint32_t ray_parent(const RayRec *rays, unsigned slot) {
+    return (uint32_t)reinterpret_cast<const unsigned long long *>(rays)[ray_index(slot, 7)];
+}
+__device__ __forceinline__ RayRec load_ray(const RayRec *rays, unsigned slot) {
+    const double *p = reinterpret_cast<const double *>(rays);
+    RayRec R;
+    R.ox = p[ray_index(slot, 0)]; R.oy = p[ray_index(slot, 1)]; R.oz = p[ray_index(slot, 2)];
+    R.dx = p[ray_index(slot, 3)]; R.dy = p[ray_index(slot, 4)]; R.dz = p[ray_index(slot, 5)];
+    R.rho = p[ray_index(slot, 6)];
+    R.parent = ray_parent(rays, slot); R._pad = 0u;
+    return R;
+}
+__device__ __forceinline__ void store_ray(RayRec *rays, unsigned slot, const RayRec &R) {
+    double *p = reinterpret_cast<double *>(rays);
+    p[ray_index(slot, 0)] = R.ox; p[ray_index(slot, 1)] = R.oy; p[ray_index(slot, 2)] = R.oz;
+    p[ray_index(slot, 3)] = R.dx; p[ray_index(slot, 4)] = R.dy; p[ray_index(slot, 5)] = R.dz;
+    p[ray_index(slot, 6)] = R.rho;
+    reinterpret_cast<unsigned long long *>(rays)[ray_index(slot, 7)] = (unsigned long long)R.parent;
+}
+
 __device__ __forceinline__ RayD slot_ray(const RenderParams &P, int slot) {
     if (P.rays) {
-        const RayRec R = P.rays[slot];
+        const RayRec R = load_ray(P.rays, (unsigned)slot);
         return mkray(R.ox, R.oy, R.oz, R.dx, R.dy, R.dz, P.eps);
     }
     const int ly = slot / P.w;
@@ -1758,13 +1785,14 @@ __global__ void RT_HOT(RT_WAVES_EU_MF_PRIMARY) k_primary_mfma(const RenderParams
 // Kernel 4: `light lights hit ray` (Main.hs:545, 436-441) = pointLight (467-487) + ambient (490-492),
 //   saturating 8-bit sums, coalesced RGBA8 store.
 
-__global__ void __launch_bounds__(256) k_final(const RenderParams P) {
-    // level 0: a block takes a 32 x 8 pixel tile, a wave 8 x 8 pixels of it; bounce levels: slots in order
-    int pix = (int)(blockIdx.x * 256 + threadIdx.x);
+// Launched with 256 threads, or with 1024 when reflected rays are handed to a next level (one atomic per BLOCK then).
+__global__ void __launch_bounds__(1024) k_final(const RenderParams P) {
+    // level 0: a block takes a 32 x 8 (32 x 32) pixel tile, a wave 8 x 8 pixels of it; bounce levels: slots in order
+    int pix = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     bool act = (unsigned)pix < num_slots(P);
     if (!P.rays) {
-        const int tx = (int)blockIdx.x % P.tiles_x, ty = (int)blockIdx.x / P.tiles_x;
-        const int x = tx * 32 + (int)(threadIdx.x >> 6) * 8 + (int)(threadIdx.x & 7), y = ty * 8 + (int)((threadIdx.x & 63) >> 3);
+        const int tx = (int)blockIdx.x % P.tiles_x, ty = (int)blockIdx.x / P.tiles_x, wq = (int)(threadIdx.x >> 6);
+        const int x = tx * 32 + (wq & 3) * 8 + (int)(threadIdx.x & 7), y = ty * (int)(blockDim.x >> 5) + (wq >> 2) * 8 + (int)((threadIdx.x & 63) >> 3);
         act = x < P.w && y < P.nrows;
         pix = act ? y * P.w + x : 0;
     }
@@ -1810,14 +1838,23 @@ __global__ void __launch_bounds__(256) k_final(const RenderParams P) {
         // The reflected rays of a wave (8 x 8 pixels at level 0) take a run of 64 slots of the next level, lane for lane
         // (one atomic per wave); lanes that reflect nothing leave a padding entry (parent = ~0).  Kept together like
         // this, the 64 rays k_general bounds at a time leave one patch of one surface: a narrow bundle.
-        const int lane = (int)(threadIdx.x & 63);
+        // The runs of a block are claimed with ONE atomic (a wave each cost 0.4 ms per chunk: 50 000 atomics on one address
+        // are serialised in the L2) and stay together in the list.
+        __shared__ unsigned s_run[17];
+        const int lane = (int)(threadIdx.x & 63), wq = (int)(threadIdx.x >> 6), nw = (int)(blockDim.x >> 6);
         const unsigned long long m = __ballot(spawn);
+        if (lane == 0) s_run[wq] = m ? 1u : 0u;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned total = 0;
+            for (int k = 0; k < nw; ++k) { const unsigned c = s_run[k]; s_run[k] = total; total += c; }
+            s_run[16] = total ? atomicAdd(P.next_count, 64u * total) : 0u;
+        }
+        __syncthreads();
         if (m) {
-            unsigned base = 0;
-            if (lane == 0) base = atomicAdd(P.next_count, 64u);
-            base = __shfl(base, 0);
+            const unsigned base = s_run[16] + 64u * s_run[wq];
             if (!spawn) { child.dz = 1.0; child.parent = 0xffffffffu; }
-            P.next_rays[base + (unsigned)lane] = child;
+            store_ray(P.next_rays, base + (unsigned)lane, child);
         }
     }
     if (!act) return;
@@ -1947,16 +1984,41 @@ __device__ __forceinline__ void q2_push(WaveQueues &Q, bool cand, uint32_t entry
 struct GenRays {                 // the two rays of a lane's column, FP32: origin, unit direction; flag as above
     float o[2][3], u[2][3];
     int flag[2];
-    f16x8 Bc[2];                 // K-half 1 of the ray's vector: {dx^2, dy^2, dz^2, dx dy, dx dz, dy dz, 0, 0} (the same for every block)
+    f16x8 B1[2];                 // step 1 of the ray's vector for this lane's K-half: hi / mid parts of d_i d_j x 2^10 (the same for every frame)
+    _Float16 d5h[2], d5m[2];     // hi / mid of dy dz x 2^10 (they sit in step 0)
 };
 
+// Step 0 of the vector of ray block b's rays in the frame (centre C, radius 1024 / invs), for this lane's K-half: the parts
+// that depend on the frame (rt_scene.cpp: sphere_row has the slot layout).  Everything is scaled by 2^10.
+__device__ __forceinline__ f16x8 gen_ray_fragment(const GenRays &G, int b, int h, float Cx, float Cy, float Cz, float invs) {
+    const float px = G.o[b][0] - Cx, py = G.o[b][1] - Cy, pz = G.o[b][2] - Cz;
+    const float sd = __builtin_fmaf(px, G.u[b][0], __builtin_fmaf(py, G.u[b][1], pz * G.u[b][2]));
+    // q = the point of the ray's line nearest the centre, in radii; far away is far enough at 4
+    const float qx = __builtin_amdgcn_fmed3f(__builtin_fmaf(-sd, G.u[b][0], px) * invs, -4096.f, 4096.f);
+    const float qy = __builtin_amdgcn_fmed3f(__builtin_fmaf(-sd, G.u[b][1], py) * invs, -4096.f, 4096.f);
+    const float qz = __builtin_amdgcn_fmed3f(__builtin_fmaf(-sd, G.u[b][2], pz) * invs, -4096.f, 4096.f);
+    const float qq = __builtin_fmaf(qx, qx, __builtin_fmaf(qy, qy, qz * qz)) * (1.f / 1024.f);
+    const float v1 = h ? qy : qq, v2 = h ? qz : qx;
+    const _Float16 v1h = (_Float16)v1, v2h = (_Float16)v2;
+    const _Float16 v1m = (_Float16)(v1 - (float)v1h), v2m = (_Float16)(v2 - (float)v2h);
+    const _Float16 one = (_Float16)1024.f, z0 = (_Float16)0.f;
+    // K-half 0: {1, 1, qq_h, qq_m, qx_h, qx_m, qx_h, D5_m}   K-half 1: {qy_h, qy_m, qy_h, qz_h, qz_m, qz_h, D5_h, 0}
+    f16x8 B = {h ? v1h : one, h ? v1m : one, v1h, h ? v2h : v1m, h ? v2m : v2h, h ? v2h : v2m, h ? G.d5h[b] : v2h, h ? z0 : G.d5m[b]};
+    if (G.flag[b] != 1) B = f16x8{z0, z0, z0, z0, z0, z0, z0, z0};
+    return B;
+}
+__device__ __forceinline__ float rfl(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+__device__ __forceinline__ f32x16 mfma2(const i32x4 a0, const f16x8 b0, const i32x4 a1, const f16x8 b1) {       // K = 32: two steps
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a1), b1, mfma0(a0, b0), 0, 0, 0);
+}
+
 template <int KIND, class EX>
-__device__ __forceinline__ void general_blocks(const RenderParams &P, const GenRec *recs, const uint16_t *rows, const float *spheres, int n,
-                                               const RunBound &rb, const GenRays &G, const double *s_ray, const int *s_flag, bool anybad,
-                                               WaveQueues &Q, unsigned &nblocks, EX &&exact) {
+__device__ __forceinline__ void general_blocks(const RenderParams &P, const GenRec *recs, const uint16_t *rows, const float *spheres,
+                                               const float *sspheres, int n, const RunBound &rb, const GenRays &G, const double *s_ray, bool anybad,
+                                               uint16_t *list, WaveQueues &Q, unsigned &nblocks, EX &&exact) {
     const int lane = (int)(threadIdx.x & 63), c = lane & 31, h = lane >> 5, nblk = (n + 31) / 32;
     const i32x4 *rows4 = reinterpret_cast<const i32x4 *>(rows);
-    const float4 *sph4 = reinterpret_cast<const float4 *>(spheres);
+    const float4 *sph4 = reinterpret_cast<const float4 *>(spheres), *ssph4 = reinterpret_cast<const float4 *>(sspheres);
     auto stage1 = [&](uint32_t entry, uint32_t &entry2) -> bool {
         const int e = (int)(entry & 63u), row = (int)((entry >> 8) & 31u);
         const float *R = Q.rec + row;
@@ -1966,56 +2028,40 @@ __device__ __forceinline__ void general_blocks(const RenderParams &P, const GenR
         entry2 = ((uint32_t)__float_as_int(R[15 * 32]) << 8) | ((uint32_t)KIND << 6) | (uint32_t)e;
         return z >= R[12 * 32];
     };
-    for (int g0 = 0; g0 < nblk; g0 += 64) {
-        const int gl = g0 + lane;
-        bool pass = gl < nblk;
-        if (pass) {
-            const float4 S = sph4[gl];
-            pass = run_meets(rb, S.x, S.y, S.z, S.w);
-        }
-        unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
-        nblocks += (unsigned)__popcll(m);
-        if (!m) continue;
-        // the loads of a block (its sphere, its rows) are issued one block ahead; the padding block nblk ends the chain
-        int g = g0 + __ffsll((long long)m) - 1;
-        m &= m - 1ull;
-        float4 Sn = sph4[g];
-        i32x4 An = rows4[(size_t)g * 64 + lane];
-        for (;;) {                                                  // wave-uniform
-            const float4 S = Sn;
-            const i32x4 A = An;
+    // Works off the blocks list[0..cnt-1]; list[cnt] names the padding block (the loads run one block ahead).
+    auto scan_list = [&](int cnt) {
+        int g = __builtin_amdgcn_readfirstlane((int)list[0]);
+        i32x4 An0 = rows4[(size_t)g * 128 + lane], An1 = rows4[(size_t)g * 128 + 64 + lane];
+        float4 SSn = ssph4[g >> 5];
+        int frame = -1;
+        f16x8 B0[2] = {};
+        for (int k = 0; k < cnt; ++k) {                             // wave-uniform
+            const i32x4 A0 = An0, A1 = An1;
+            const float4 SS = SSn;
             const int gc = g;
-            const bool more = m != 0ull;
-            g = more ? g0 + __ffsll((long long)m) - 1 : nblk;
-            m &= m - 1ull;
-            Sn = sph4[g];
-            An = rows4[(size_t)g * 64 + lane];
-            const float Cx = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(S.x)));
-            const float Cy = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(S.y)));
-            const float Cz = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(S.z)));
-            const float Rb = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(S.w)));
-            const float inv = Rb < 3.0e38f ? __builtin_amdgcn_rcpf(Rb) : 0.f;      // a block without a sphere: its rows are constants
-            f16x8 B[2];
-            int mx[2];
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                const float px = G.o[b][0] - Cx, py = G.o[b][1] - Cy, pz = G.o[b][2] - Cz;
-                const float sd = __builtin_fmaf(px, G.u[b][0], __builtin_fmaf(py, G.u[b][1], pz * G.u[b][2]));
-                // q = the point of the ray's line nearest the block centre, in block radii; far away is far enough at 64
-                const float qx = __builtin_amdgcn_fmed3f(__builtin_fmaf(-sd, G.u[b][0], px) * inv, -64.f, 64.f);
-                const float qy = __builtin_amdgcn_fmed3f(__builtin_fmaf(-sd, G.u[b][1], py) * inv, -64.f, 64.f);
-                const float qz = __builtin_amdgcn_fmed3f(__builtin_fmaf(-sd, G.u[b][2], pz) * inv, -64.f, 64.f);
-                const float qq = __builtin_fmaf(qx, qx, __builtin_fmaf(qy, qy, qz * qz));
-                const bool on = G.flag[b] == 1;
-                const _Float16 z0 = (_Float16)0.f;
-                const f16x8 Bq = {on ? (_Float16)1.f : z0, on ? (_Float16)qx : z0, on ? (_Float16)qy : z0, on ? (_Float16)qz : z0,
-                                  on ? (_Float16)qq : z0, z0, z0, z0};
-                B[b] = h ? G.Bc[b] : Bq;
-                mx[b] = step_max(mfma0(A, B[b]));
-                if (G.flag[b] == 2) mx[b] = 1;
+            g = __builtin_amdgcn_readfirstlane((int)list[k + 1]);
+            An0 = rows4[(size_t)g * 128 + lane]; An1 = rows4[(size_t)g * 128 + 64 + lane];
+            SSn = ssph4[g >> 5];
+            if ((gc >> 5) != frame) {                               // a new super-block: the rays' vectors in its frame
+                frame = gc >> 5;
+                RT_TICK(tb)
+                const float Rs = rfl(SS.w);
+                const float invs = Rs < 3.0e38f ? 1024.f * __builtin_amdgcn_rcpf(Rs) : 0.f;    // no sphere: its rows are constants
+                const float Cx = rfl(SS.x), Cy = rfl(SS.y), Cz = rfl(SS.z);
+                B0[0] = gen_ray_fragment(G, 0, h, Cx, Cy, Cz, invs);
+                B0[1] = gen_ray_fragment(G, 1, h, Cx, Cy, Cz, invs);
+                RT_TOCK(Q.t_bits, tb)
             }
-            unsigned mb = (__builtin_amdgcn_ballot_w64(mx[0] > 0) != 0ull ? 1u : 0u) | (__builtin_amdgcn_ballot_w64(mx[1] > 0) != 0ull ? 2u : 0u);
+            int mx0 = step_max(mfma2(A0, B0[0], A1, G.B1[0]));
+            int mx1 = step_max(mfma2(A0, B0[1], A1, G.B1[1]));
+            if (G.flag[0] == 2) mx0 = 1;
+            if (G.flag[1] == 2) mx1 = 1;
+            const unsigned mb = (__builtin_amdgcn_ballot_w64(mx0 > 0) != 0ull ? 1u : 0u) | (__builtin_amdgcn_ballot_w64(mx1 > 0) != 0ull ? 2u : 0u);
             if (mb) {                                               // wave-uniform
+#ifdef RT_GEN_DEBUG
+                nblocks += 0x10000u;                                // (measurement build: blocks with a candidate, in the high half)
+#endif
+                RT_TICK(tl)
                 // the records of this block's 32 leaves: 2 KiB, 32 bytes per lane (lane l: half l & 1 of record l >> 1)
                 const float4 *rsrc = reinterpret_cast<const float4 *>(recs + (size_t)gc * 32) + 2 * lane;
                 const float4 r0 = rsrc[0], r1 = rsrc[1];
@@ -2027,7 +2073,7 @@ __device__ __forceinline__ void general_blocks(const RenderParams &P, const GenR
 #pragma unroll 1
                 for (int b = 0; b < 2; ++b) {
                     if (!((mb >> b) & 1u)) continue;
-                    const f32x16 pa = mfma0(A, b ? B[1] : B[0]);      // issued again (bit-identical): the 16 results were not kept
+                    const f32x16 pa = mfma2(A0, b ? B0[1] : B0[0], A1, b ? G.B1[1] : G.B1[0]);   // issued again (bit-identical): the 16 results were not kept
                     const bool force = anybad && (b ? G.flag[1] : G.flag[0]) == 2;
                     const uint32_t eb = lane_part + (uint32_t)(b * 32);
 #pragma unroll
@@ -2044,8 +2090,42 @@ __device__ __forceinline__ void general_blocks(const RenderParams &P, const GenR
                 }
                 q_drain(Q, 0u, false, stage1, exact);               // q1 is empty before `rec` is overwritten
                 __builtin_amdgcn_wave_barrier();
+                RT_TOCK(Q.t_loop, tl)
             }
-            if (!more) break;
+        }
+    };
+    // The run's bound against the bounding sphere of every block, a lane per block, 256 blocks per trip to the L2; the
+    // blocks it reaches go to a list in LDS.
+    int cnt = 0;                                                    // wave-uniform
+    for (int g0 = 0; g0 < nblk; g0 += 256) {
+        float4 S[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int g = g0 + 64 * u + lane;
+            S[u] = sph4[g < nblk ? g : nblk];
+        }
+        unsigned long long mk[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int g = g0 + 64 * u + lane;
+            mk[u] = __builtin_amdgcn_ballot_w64(g < nblk && run_meets(rb, S[u].x, S[u].y, S[u].z, S[u].w));
+        }
+#pragma unroll 1
+        for (int u = 0; u < 4 && g0 + 64 * u < nblk; ++u) {         // (not unrolled: one copy of the scan)
+            const unsigned long long m = u == 0 ? mk[0] : (u == 1 ? mk[1] : (u == 2 ? mk[2] : mk[3]));
+            const int g = g0 + 64 * u + lane;
+            if ((m >> lane) & 1ull) list[cnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = (uint16_t)g;
+            cnt += (int)__popcll(m);
+            if (cnt > RT_LIST_CAP - 64 || g0 + 64 * u + 64 >= nblk) {
+                nblocks += (unsigned)cnt;
+                if (cnt > 0) {
+                    if (lane == 0) list[cnt] = (uint16_t)nblk;
+                    __builtin_amdgcn_wave_barrier();
+                    scan_list(cnt);
+                    __builtin_amdgcn_wave_barrier();
+                }
+                cnt = 0;
+            }
         }
     }
 }
@@ -2054,9 +2134,11 @@ __device__ __forceinline__ void general_blocks(const RenderParams &P, const GenR
 #define RT_WAVES_EU_GEN 4
 #endif
 __global__ void __attribute__((amdgpu_waves_per_eu(RT_WAVES_EU_GEN, 8))) __launch_bounds__(64) k_general(const RenderParams P) {
+    RT_WAVE_T0
     __shared__ unsigned long long s_bt[64];
     __shared__ int s_bid[64];
     __shared__ int s_flag[64];
+    __shared__ uint16_t s_list[RT_LIST_CAP + 8];
     __shared__ uint16_t s_q1[RT_Q1_CAP];
     __shared__ uint32_t s_q2[RT_Q2_CAP];
     __shared__ double s_ray[9 * 64];
@@ -2067,7 +2149,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(RT_WAVES_EU_GEN, 8))) __launc
     const int lane = (int)(threadIdx.x & 63), c = lane & 31;
     const unsigned slot = wave * 64u + (unsigned)lane;
     const bool inlist = slot < count;
-    const bool act = inlist && P.rays[slot].parent != 0xffffffffu;       // (not a padding entry of k_final)
+    const bool act = inlist && ray_parent(P.rays, slot) != 0xffffffffu;  // (not a padding entry of k_final)
     const RayD ray = slot_ray(P, inlist ? (int)slot : 0);
     {
         const double r9[9] = {ray.px, ray.py, ray.pz, ray.dx, ray.dy, ray.dz, ray.rx, ray.ry, ray.rz};
@@ -2096,10 +2178,20 @@ __global__ void __attribute__((amdgpu_waves_per_eu(RT_WAVES_EU_GEN, 8))) __launc
         G.u[b][0] = ex * rn; G.u[b][1] = ey * rn; G.u[b][2] = ez * rn;
 #pragma unroll
         for (int k = 0; k < 3; ++k) G.o[b][k] = G.flag[b] == 1 ? (float)s_ray[k * 64 + e] : 0.f;
-        const _Float16 z0 = (_Float16)0.f;
-        G.Bc[b] = f16x8{(_Float16)(G.u[b][0] * G.u[b][0]), (_Float16)(G.u[b][1] * G.u[b][1]), (_Float16)(G.u[b][2] * G.u[b][2]),
-                        (_Float16)(G.u[b][0] * G.u[b][1]), (_Float16)(G.u[b][0] * G.u[b][2]), (_Float16)(G.u[b][1] * G.u[b][2]), z0, z0};
+        // d_i d_j x 2^10, split: this lane's K-half of step 1, and dy dz for step 0
+        const float s10 = 1024.f;
+        const float D[6] = {G.u[b][0] * G.u[b][0] * s10, G.u[b][1] * G.u[b][1] * s10, G.u[b][2] * G.u[b][2] * s10,
+                            G.u[b][0] * G.u[b][1] * s10, G.u[b][0] * G.u[b][2] * s10, G.u[b][1] * G.u[b][2] * s10};
+        _Float16 Dh[6], Dm[6];
+#pragma unroll
+        for (int t = 0; t < 6; ++t) { Dh[t] = (_Float16)D[t]; Dm[t] = (_Float16)(D[t] - (float)Dh[t]); }
+        // K-half 0: {D0_h, D0_m, D0_h, D1_h, D1_m, D1_h, D2_h, D2_m}   K-half 1: {D2_h, D3_h, D3_m, D3_h, D4_h, D4_m, D4_h, D5_h}
+        G.B1[b] = (lane >> 5) ? f16x8{Dh[2], Dh[3], Dm[3], Dh[3], Dh[4], Dm[4], Dh[4], Dh[5]}
+                              : f16x8{Dh[0], Dm[0], Dh[0], Dh[1], Dm[1], Dh[1], Dh[2], Dm[2]};
+        G.d5h[b] = Dh[5]; G.d5m[b] = Dm[5];
     }
+    RT_WAVE_PHASE(0)
+    RT_WAVE_PHASE(1)
     WaveQueues Q = {s_q1, s_q2, 0u, 0u, 0u, s_rec};
     unsigned nblocks = 0, nexact = 0;
     // exact: intersect leaf reflected-ray (Main.hs:543 inside trace (n-1)), for the entry's ray
@@ -2125,8 +2217,8 @@ __global__ void __attribute__((amdgpu_waves_per_eu(RT_WAVES_EU_GEN, 8))) __launc
         __builtin_amdgcn_wave_barrier();
         if (win) atomicMin(&s_bid[e], gid);
     };
-    general_blocks<LEAF_TRI>(P, P.gen_tri, P.gen_tri_rows, P.gen_tri_sph, P.ntri, rb, G, s_ray, s_flag, anybad, Q, nblocks, exact);
-    general_blocks<LEAF_RECT>(P, P.gen_rect, P.gen_rect_rows, P.gen_rect_sph, P.nrect, rb, G, s_ray, s_flag, anybad, Q, nblocks, exact);
+    general_blocks<LEAF_TRI>(P, P.gen_tri, P.gen_tri_rows, P.gen_tri_sph, P.gen_tri_ssph, P.ntri, rb, G, s_ray, anybad, s_list, Q, nblocks, exact);
+    general_blocks<LEAF_RECT>(P, P.gen_rect, P.gen_rect_rows, P.gen_rect_sph, P.gen_rect_ssph, P.nrect, rb, G, s_ray, anybad, s_list, Q, nblocks, exact);
     if (P.nsph > 0) {           // spheres (few per scene): delta/4 = (d.o)^2 - (o.o - r^2) with o = origin - centre, Main.hs:396-400
         CGenPtr recs = as_const(P.gen_sph);
         CIntPtr gids = as_const(P.sph_gid);
@@ -2146,8 +2238,15 @@ __global__ void __attribute__((amdgpu_waves_per_eu(RT_WAVES_EU_GEN, 8))) __launc
     if (lane == 0 && nexact) stat_add(P, 1, (unsigned long long)nexact);
     const unsigned nrays = (unsigned)__popcll(__builtin_amdgcn_ballot_w64(act));
     if (lane == 0) stat_add(P, 5, (unsigned long long)nrays);     // reflected rays traced
+#ifdef RT_GEN_DEBUG
+    nblocks >>= 16;
+#endif
     if (lane == 0) stat_add(P, 8, (unsigned long long)nblocks);   // (run of 64 rays, block of 32 leaves) pairs looked at
     if (lane == 0 && Q.nrec) stat_add(P, 4, (unsigned long long)Q.nrec);
+#ifdef RT_WAVE_TIMES
+    wave_ph[2] = (Q.t_s1 & 0xffff) | ((Q.t_ex & 0xffff) << 16) | ((Q.t_bits & 0xffff) << 32) | ((Q.t_loop & 0xffff) << 48);
+    wave_record(P, 2u, wave, wave_t0, nblocks, Q.nrec, nexact, wave_ph);
+#endif
 }
 
 // colour of a level folded into the level below: addPixelRGB8 direct (scalePixelRGB8 reflectivity sub), Main.hs:545, 554
@@ -2156,8 +2255,10 @@ __global__ void __launch_bounds__(256) k_combine(const RayRec *__restrict__ rays
     const unsigned i = blockIdx.x * 256 + threadIdx.x;
     const unsigned n = *count < cap ? *count : cap;
     if (i >= n) return;
-    const RayRec R = rays[i];
+    RayRec R;
+    R.parent = ray_parent(rays, i);
     if (R.parent == 0xffffffffu) return;        // padding entry
+    R.rho = reinterpret_cast<const double *>(rays)[ray_index(i, 6)];
     const uint32_t c = col[i], pc = parent_col[R.parent];
     uint32_t out = 0;
 #pragma unroll
@@ -2364,6 +2465,8 @@ int device_prepare(rt_scene &s, DeviceScene &D, int device, int w, int h) {
             if ((rc = upload(D.gen_rect_sph, s.gen_rect_sph))) return rc;
             if ((rc = upload(D.gen_tri_rows, s.gen_tri_rows))) return rc;
             if ((rc = upload(D.gen_rect_rows, s.gen_rect_rows))) return rc;
+            if ((rc = upload(D.gen_tri_ssph, s.gen_tri_ssph))) return rc;
+            if ((rc = upload(D.gen_rect_ssph, s.gen_rect_ssph))) return rc;
         }
         if ((rc = upload(D.tri_gid, s.tri_gid))) return rc;
         if ((rc = upload(D.rect_gid, s.rect_gid))) return rc;
@@ -2545,6 +2648,7 @@ int render_rows(rt_scene *s, DeviceScene &D, const Workspace &W, size_t crow, in
     P.gen_tri_gid = (const int32_t *)D.gen_tri_gid.p; P.gen_rect_gid = (const int32_t *)D.gen_rect_gid.p;
     P.gen_tri_sph = (const float *)D.gen_tri_sph.p; P.gen_rect_sph = (const float *)D.gen_rect_sph.p;
     P.gen_tri_rows = (const uint16_t *)D.gen_tri_rows.p; P.gen_rect_rows = (const uint16_t *)D.gen_rect_rows.p;
+    P.gen_tri_ssph = (const float *)D.gen_tri_ssph.p; P.gen_rect_ssph = (const float *)D.gen_rect_ssph.p;
     P.sph_rec = (const FilterRec *)D.sph_rec.p; P.gen_sph = (const GenRec *)D.gen_sph.p; P.sph_gid = (const int32_t *)D.sph_gid.p;
     P.nsph = (int)s->sph_gid.size();
     P.mf_rows = (const uint16_t *)D.mf_rows.p; P.mf_gid = (const int32_t *)D.mf_gid.p; P.mf_rec = (const FilterRec *)D.mf_rec.p;
@@ -2648,7 +2752,10 @@ int render_rows(rt_scene *s, DeviceScene &D, const Workspace &W, size_t crow, in
                     }
                     if (timed && (rc = next_event(D, st, 3))) return rc;
                 }
-                hipLaunchKernelGGL(k_final, dim3(lvl == 0 ? (unsigned)P.tiles_x * (unsigned)((rows + 7) / 8) : lblocks), dim3(256), 0, st, P);
+                if (P.next_rays)
+                    hipLaunchKernelGGL(k_final, dim3(lvl == 0 ? (unsigned)P.tiles_x * (unsigned)((rows + 31) / 32) : (lblocks + 3) / 4), dim3(1024), 0, st, P);
+                else
+                    hipLaunchKernelGGL(k_final, dim3(lvl == 0 ? (unsigned)P.tiles_x * (unsigned)((rows + 7) / 8) : lblocks), dim3(256), 0, st, P);
                 if (timed && (rc = next_event(D, st, 4))) return rc;
             }
             P.rays = nullptr; P.count_ptr = nullptr; P.next_rays = nullptr; P.hit_id = hit0; P.out_off = off0;
@@ -2730,7 +2837,8 @@ void rt_scene_destroy(rt_scene *s) {
         if (d.copy_stream) (void)hipStreamSynchronize((hipStream_t)d.copy_stream);
         DevBuf *bufs[] = {&d.leaves, &d.aux, &d.guards, &d.mats, &d.lights, &d.tri_rec, &d.rect_rec, &d.tri_gid, &d.rect_gid,
                           &d.sph_rec, &d.gen_sph, &d.sph_gid, &d.mf_rows, &d.mf_gid, &d.mf_cone, &d.mf_rec, &d.gen_tri, &d.gen_rect,
-                          &d.gen_tri_gid, &d.gen_rect_gid, &d.gen_tri_sph, &d.gen_rect_sph, &d.gen_tri_rows, &d.gen_rect_rows};
+                          &d.gen_tri_gid, &d.gen_rect_gid, &d.gen_tri_sph, &d.gen_rect_sph, &d.gen_tri_rows, &d.gen_rect_rows,
+                          &d.gen_tri_ssph, &d.gen_rect_ssph};
         for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
         Workspace &W = d.ws;
         void *ptrs[] = {W.counters, W.qcount, W.hit_id, W.accum, W.hitrec, W.queue, W.qsparse, W.tcount, W.lit,

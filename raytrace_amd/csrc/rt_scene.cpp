@@ -635,21 +635,29 @@ static GenRec make_gen_rec(const LeafD &L, const double omax[3]) {
 //
 // Stage 0 of the bounce levels, on the matrix cores (k_general): the line of a ray (o, unit d) meets the bounding sphere
 // (c, r) of a leaf iff |c - q|^2 - (c.d)^2 <= r^2, where q = o - (o.d) d is the point of the line nearest the origin of
-// the coordinates.  Taken relative to the centre C of the leaf's block and in units of the block radius R (c~ = (c - C)/R,
-// r~ = r/R, q~ likewise: all of size <= 1 for a ray that meets the leaf), the test is ONE linear form between a vector of
-// the leaf and a vector of the ray,
+// the coordinates.  Taken relative to the centre C and in units of the radius R of a FRAME that holds the leaf (the
+// bounding sphere of the leaf's super-block: 32 blocks = 1024 leaves; c~ = (c - C)/R, r~ = r/R, q~ likewise, all of size
+// <= 1 for a ray that meets the leaf), the test is ONE linear form between a vector of the leaf and a vector of the ray,
 //   F = (r~^2 - |c~|^2 + M) * 1 + 2 c~ . q~ - |q~|^2 + sum_ij c~_i c~_j d_i d_j  > 0,
-// 11 products, in plain FP16 with FP32 accumulation: v_mfma_f32_32x32x16_f16 decides 32 leaves x 32 rays per issue.
-// K-half 0 of a row = {r~^2 - |c~|^2 + M, 2 c~x, 2 c~y, 2 c~z, -1, 0, 0, 0} against {1, q~x, q~y, q~z, |q~|^2, 0, 0, 0};
-// K-half 1 = {c~x^2, c~y^2, c~z^2, 2 c~x c~y, 2 c~x c~z, 2 c~y c~z, 0, 0} against {dx^2, dy^2, dz^2, dx dy, dx dz, dy dz, 0, 0}.
-// Margin M: every operand is rounded to half precision (2^-12 relative each); for a ray that meets the leaf |q~| <= 1, so
-// the absolute values of the 11 products sum to <= 5 and their rounding errors to <= 5 * 2^-11 = 0.0025; the ray's q is
-// computed in FP32 from coordinates of size <= dall, an error of <= 2^-20 dall / R in q~, which moves F by <= 4 times that.
-// A far ray (|q~| large) has F ~ -|q~|^2, far more negative than any rounding error; q~ is clamped to +-64 in the kernel.
-constexpr double GEN_ROW_MARGIN = 0.004;
-static void sphere_row(const double c[3], double r, const float S[4], double dall, bool real, uint16_t lo8[8], uint16_t hi8[8]) {
-    for (int k = 0; k < 8; ++k) lo8[k] = hi8[k] = 0;
-    const double always[2] = {-1.0, 1.0};
+// 11 products.  Every operand is split into an FP16 hi and mid part (22 significant bits) and the products hi*hi,
+// hi*mid, mid*hi are kept: 31 FP16 products = two steps of v_mfma_f32_32x32x16_f16 (K = 32), which decide 32 leaves x
+// 32 rays.  The ray's vector depends only on the frame, so it is built once per super-block, not per block.
+// Slots (A = leaf value, B = ray value; X = 2 c~x .., Q = {c~x^2, c~y^2, c~z^2, 2 c~x c~y, 2 c~x c~z, 2 c~y c~z},
+// D = {dx^2, dy^2, dz^2, dx dy, dx dz, dy dz}, k = r~^2 - |c~|^2 + M; every value times 2^10 so that no mid part is an FP16
+// denormal the matrix core might flush):
+//   step 0, K-half 0: A {k_h, k_m, -1, -1, X_h, X_h, X_m, Q5_h}   B {1, 1, qq_h, qq_m, qx_h, qx_m, qx_h, D5_m}
+//   step 0, K-half 1: A {Y_h, Y_h, Y_m, Z_h, Z_h, Z_m, Q5_m, 0}   B {qy_h, qy_m, qy_h, qz_h, qz_m, qz_h, D5_h, 0}
+//   step 1, K-half 0: A {Q0_h, Q0_h, Q0_m, Q1_h, Q1_h, Q1_m, Q2_h, Q2_h}   B {D0_h, D0_m, D0_h, D1_h, D1_m, D1_h, D2_h, D2_m}
+//   step 1, K-half 1: A {Q2_m, Q3_h, Q3_h, Q3_m, Q4_h, Q4_h, Q4_m, Q5_h}   B {D2_h, D3_h, D3_m, D3_h, D4_h, D4_m, D4_h, D5_h}
+// Margin M: for a ray that meets the leaf |q~| <= 1, so the absolute values of the 11 terms sum to <= 5; a split operand
+// is off by <= 2^-22 of its value and the dropped mid*mid products by 2^-22: <= 5 * 3 * 2^-22 = 3.6e-6; FP32 accumulation
+// of 32 products of a sum <= 5: <= 32 * 2^-24 * 5 = 9.6e-6; the ray's q is computed in FP32 from coordinates of size
+// <= dall, an error of <= 2^-20 dall / R in q~, which moves F by <= 4 times that.  M = 2.5e-5 + 4 * 2^-20 dall / R.
+// A far ray (|q~| large) has F ~ -|q~|^2, far more negative than any rounding error; q~ is clamped to +-4 in the kernel
+// (a ray that meets the leaf has |q~| <= |c~| + r~ <= 2: leaves that do not fit that get the constant row "always").
+constexpr double GEN_ROW_MARGIN = 2.5e-5, GEN_SCALE = 1024.0;
+static void sphere_row(const double c[3], double r, const float S[4], double dall, bool real, uint16_t out[32]) {
+    for (int k = 0; k < 32; ++k) out[k] = 0;
     const double R = (double)S[3];
     bool ok = real && std::isfinite(R) && R > 0 && std::isfinite(r) && std::isfinite(c[0]) && std::isfinite(c[1]) && std::isfinite(c[2]);
     double ct[3] = {0, 0, 0}, rt = 0, M = 0;
@@ -657,17 +665,25 @@ static void sphere_row(const double c[3], double r, const float S[4], double dal
         for (int i = 0; i < 3; ++i) ct[i] = (c[i] - (double)S[i]) / R;
         rt = (r * (1.0 + 1e-6) + 1e-7 * dall) / R;
         M = GEN_ROW_MARGIN + 4.0 * std::ldexp(dall, -20) / R;
-        ok = M < 0.25 && std::fabs(ct[0]) <= 2 && std::fabs(ct[1]) <= 2 && std::fabs(ct[2]) <= 2 && rt <= 2;
+        ok = M < 0.25 && std::sqrt(ct[0] * ct[0] + ct[1] * ct[1] + ct[2] * ct[2]) + rt <= 2.0;
     }
-    if (!ok) { lo8[0] = f16_rne((float)always[real ? 1 : 0]); return; }     // a constant form: every ray (a real leaf) or none (padding)
-    const double v0[5] = {rt * rt - (ct[0] * ct[0] + ct[1] * ct[1] + ct[2] * ct[2]) + M, 2 * ct[0], 2 * ct[1], 2 * ct[2], -1.0};
-    const double v1[6] = {ct[0] * ct[0], ct[1] * ct[1], ct[2] * ct[2], 2 * ct[0] * ct[1], 2 * ct[0] * ct[2], 2 * ct[1] * ct[2]};
-    for (int k = 0; k < 5; ++k) lo8[k] = f16_rne((float)v0[k]);
-    for (int k = 0; k < 6; ++k) hi8[k] = f16_rne((float)v1[k]);
+    if (!ok) { out[0] = f16_rne((float)(real ? GEN_SCALE : -GEN_SCALE)); return; }     // a constant form: every ray (a real leaf) or none (padding)
+    uint16_t kh, km, Xh[3], Xm[3], Qh[6], Qm[6];
+    split_f16(GEN_SCALE * (rt * rt - (ct[0] * ct[0] + ct[1] * ct[1] + ct[2] * ct[2]) + M), kh, km);
+    for (int i = 0; i < 3; ++i) split_f16(GEN_SCALE * 2 * ct[i], Xh[i], Xm[i]);
+    const double Q[6] = {ct[0] * ct[0], ct[1] * ct[1], ct[2] * ct[2], 2 * ct[0] * ct[1], 2 * ct[0] * ct[2], 2 * ct[1] * ct[2]};
+    for (int t = 0; t < 6; ++t) split_f16(GEN_SCALE * Q[t], Qh[t], Qm[t]);
+    const uint16_t neg1 = f16_rne((float)-GEN_SCALE);
+    const uint16_t s0h0[8] = {kh, km, neg1, neg1, Xh[0], Xh[0], Xm[0], Qh[5]};
+    const uint16_t s0h1[8] = {Xh[1], Xh[1], Xm[1], Xh[2], Xh[2], Xm[2], Qm[5], 0};
+    const uint16_t s1h0[8] = {Qh[0], Qh[0], Qm[0], Qh[1], Qh[1], Qm[1], Qh[2], Qh[2]};
+    const uint16_t s1h1[8] = {Qm[2], Qh[3], Qh[3], Qm[3], Qh[4], Qh[4], Qm[4], Qh[5]};
+    for (int k = 0; k < 8; ++k) { out[k] = s0h0[k]; out[8 + k] = s0h1[k]; out[16 + k] = s1h0[k]; out[24 + k] = s1h1[k]; }
 }
 
 static void spatial_order(const rt_scene &s, const std::vector<int32_t> &gids, const double lo[3], const double hi[3], double dall,
-                          std::vector<int32_t> &order, std::vector<float> &spheres, std::vector<uint16_t> &rows) {
+                          std::vector<int32_t> &order, std::vector<float> &spheres, std::vector<uint16_t> &rows,
+                          std::vector<float> &sup_spheres) {
     const size_t n = gids.size();
     std::vector<std::pair<uint32_t, int32_t>> keyed(n);
     std::vector<int> nv(n);
@@ -744,16 +760,43 @@ static void spatial_order(const rt_scene &s, const std::vector<int32_t> &gids, c
         if (!std::isfinite(S[0]) || !std::isfinite(S[1]) || !std::isfinite(S[2]) || !std::isfinite(S[3])) { S[0] = S[1] = S[2] = 0.f; S[3] = INFINITY; }
     }
     spheres[nblk * 4 + 3] = INFINITY;                           // (the padding block: never looked at)
-    // the matrix-core rows of every block: lane (m, h) of a wave reads 16 bytes at rows[((b * 2 + h) * 32 + m) * 8]
-    rows.assign((nblk + 1) * 64 * 8, 0);
+    // 32 consecutive blocks make a super-block; its bounding sphere is the frame its leaves' rows are written in
+    const size_t nsup = (nblk + 31) / 32;
+    sup_spheres.assign((nsup + 1) * 4, 0.f);
+    for (size_t sb = 0; sb <= nsup; ++sb) {
+        float *S = &sup_spheres[sb * 4];
+        S[3] = INFINITY;
+        double c[3] = {0, 0, 0};
+        size_t cnt = 0;
+        for (size_t b = sb * 32; b < std::min(nblk, sb * 32 + 32); ++b)
+            if (std::isfinite(spheres[b * 4 + 3])) { for (int i = 0; i < 3; ++i) c[i] += (double)spheres[b * 4 + i]; ++cnt; }
+        if (!cnt) continue;
+        for (int i = 0; i < 3; ++i) c[i] /= (double)cnt;
+        double r = 0;
+        for (size_t b = sb * 32; b < std::min(nblk, sb * 32 + 32); ++b) {
+            if (!std::isfinite(spheres[b * 4 + 3])) continue;
+            double d2 = 0;
+            for (int i = 0; i < 3; ++i) { const double d = (double)spheres[b * 4 + i] - c[i]; d2 += d * d; }
+            r = std::fmax(r, std::sqrt(d2) + (double)spheres[b * 4 + 3]);
+        }
+        r = r * (1.0 + 1e-6) + 1e-6 * (std::fabs(c[0]) + std::fabs(c[1]) + std::fabs(c[2]) + 1.0);
+        S[0] = (float)c[0]; S[1] = (float)c[1]; S[2] = (float)c[2]; S[3] = std::nextafterf((float)r, INFINITY);
+        if (!std::isfinite(S[0]) || !std::isfinite(S[1]) || !std::isfinite(S[2]) || !std::isfinite(S[3])) { S[0] = S[1] = S[2] = 0.f; S[3] = INFINITY; }
+    }
+    // the matrix-core rows of every block, in the frame of its super-block: lane (m, h) of a wave reads 16 bytes at
+    // rows[(((b * 2 + step) * 2 + h) * 32 + m) * 8] for each of the two K steps
+    rows.assign((nblk + 1) * 128 * 8, 0);
     for (size_t b = 0; b <= nblk; ++b)
         for (size_t m = 0; m < 32; ++m) {
             const size_t k = b * 32 + m;
             const bool real = b < nblk && k < n;
             const size_t src = real ? (size_t)keyed[k].second : 0;
             const double zero[3] = {0, 0, 0};
-            sphere_row(real && nv[src] > 0 ? &cen[src * 3] : zero, real && nv[src] > 0 ? rad[src] : INFINITY, &spheres[b * 4], dall, real,
-                       &rows[((b * 2 + 0) * 32 + m) * 8], &rows[((b * 2 + 1) * 32 + m) * 8]);
+            uint16_t row[32];
+            sphere_row(real && nv[src] > 0 ? &cen[src * 3] : zero, real && nv[src] > 0 ? rad[src] : INFINITY, &sup_spheres[(b / 32) * 4], dall, real, row);
+            for (int st = 0; st < 2; ++st)
+                for (int h = 0; h < 2; ++h)
+                    for (int q = 0; q < 8; ++q) rows[(((b * 2 + st) * 2 + h) * 32 + m) * 8 + q] = row[st * 16 + h * 8 + q];
         }
 }
 
@@ -895,8 +938,8 @@ void build_filter_records(rt_scene &s, int w, int h, bool eye_only) {
             // records padded to whole blocks (+ one never block): k_general stages the 32 records of a block with one load
             const size_t tpad = ((ntri + 31) / 32 + 1) * 32, rpad = ((nrect + 31) / 32 + 1) * 32;
             s.gen_tri.assign(tpad, never); s.gen_rect.assign(rpad, never);
-            spatial_order(s, s.tri_gid, lo, hi, dall, s.gen_tri_gid, s.gen_tri_sph, s.gen_tri_rows);
-            spatial_order(s, s.rect_gid, lo, hi, dall, s.gen_rect_gid, s.gen_rect_sph, s.gen_rect_rows);
+            spatial_order(s, s.tri_gid, lo, hi, dall, s.gen_tri_gid, s.gen_tri_sph, s.gen_tri_rows, s.gen_tri_ssph);
+            spatial_order(s, s.rect_gid, lo, hi, dall, s.gen_rect_gid, s.gen_rect_sph, s.gen_rect_rows, s.gen_rect_ssph);
             auto with_gid = [](GenRec r, int32_t gid) { std::memcpy(&r.c[15], &gid, 4); return r; };       // the spare float carries the leaf index
             for (size_t k = 0; k < ntri; ++k) s.gen_tri[k] = with_gid(make_gen_rec(s.leaves[s.gen_tri_gid[k]], omax), s.gen_tri_gid[k]);
             for (size_t k = 0; k < nrect; ++k) s.gen_rect[k] = with_gid(make_gen_rec(s.leaves[s.gen_rect_gid[k]], omax), s.gen_rect_gid[k]);
@@ -1238,18 +1281,21 @@ int rt_scene_get_general_block(const rt_scene *s, int kind, int block, float sph
     return nblk;
 }
 
-int rt_scene_get_general_rows(const rt_scene *s, int kind, int block, uint16_t out[512]) {
-    if (!s || !out || (kind != LEAF_RECT && kind != LEAF_TRI) || s->rec_w < 0) {
+int rt_scene_get_general_rows(const rt_scene *s, int kind, int block, float frame[4], uint16_t out[1024]) {
+    if (!s || !out || !frame || (kind != LEAF_RECT && kind != LEAF_TRI) || s->rec_w < 0) {
         set_error("rt_scene_get_general_rows: bad argument (call rt_scene_prepare_host first)"); return RT_ERR_ARG;
     }
     const std::vector<int32_t> &gid = kind == LEAF_TRI ? s->gen_tri_gid : s->gen_rect_gid;
     const std::vector<uint16_t> &rows = kind == LEAF_TRI ? s->gen_tri_rows : s->gen_rect_rows;
+    const std::vector<float> &ssph = kind == LEAF_TRI ? s->gen_tri_ssph : s->gen_rect_ssph;
     const int nblk = (int)((gid.size() + 31) / 32);
     if (!s->reflective) return 0;
     if (block < 0 || block >= nblk) { set_error("rt_scene_get_general_rows: block out of range"); return RT_ERR_ARG; }
+    for (int k = 0; k < 4; ++k) frame[k] = ssph[(size_t)(block / 32) * 4 + k];
     for (int m = 0; m < 32; ++m)
-        for (int h = 0; h < 2; ++h)
-            for (int k = 0; k < 8; ++k) out[m * 16 + h * 8 + k] = rows[(((size_t)block * 2 + h) * 32 + m) * 8 + k];
+        for (int st = 0; st < 2; ++st)
+            for (int h = 0; h < 2; ++h)
+                for (int k = 0; k < 8; ++k) out[m * 32 + st * 16 + h * 8 + k] = rows[((((size_t)block * 2 + st) * 2 + h) * 32 + m) * 8 + k];
     return nblk;
 }
 

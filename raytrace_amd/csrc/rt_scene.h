@@ -54,6 +54,7 @@ struct DeviceScene {          // the scene on ONE device (HBM), owned by the rt_
     DevBuf gen_tri, gen_rect;        // general-ray records (reflective scenes only), in a space-filling order
     DevBuf gen_tri_gid, gen_rect_gid, gen_tri_sph, gen_rect_sph;   // that order's leaf indices; bounding spheres of its blocks of 32
     DevBuf gen_tri_rows, gen_rect_rows;                            // the blocks' matrix-core rows (leaf bounding spheres as linear forms)
+    DevBuf gen_tri_ssph, gen_rect_ssph;                            // super-blocks of 32 blocks: bounding sphere = the frame of their rows
     void *stream = nullptr;          // hipStream_t: renders of this scene on this device (when the caller passes none)
     void *copy_stream = nullptr;     // hipStream_t: rt_render's copies to host memory, band by band; rt_render_multi's peer copies
     void *copy_stream2 = nullptr;    // hipStream_t: rt_render_multi's copies from the home device to host memory
@@ -104,7 +105,8 @@ struct rt_scene {
     std::vector<rt::GenRec> gen_tri, gen_rect, gen_sph;   // only filled when a material reflects; gen_tri / gen_rect in spatial order
     std::vector<int32_t> gen_tri_gid, gen_rect_gid;       // position in that order -> leaf index
     std::vector<float> gen_tri_sph, gen_rect_sph;         // per block of 32 records: bounding sphere {centre xyz, radius}
-    std::vector<uint16_t> gen_tri_rows, gen_rect_rows;    // per block: 2 x 32 x 8 halfs (rt_scene.cpp: sphere_row), + one padding block
+    std::vector<uint16_t> gen_tri_rows, gen_rect_rows;    // per block: 2 steps x 2 halves x 32 x 8 halfs (rt_scene.cpp: sphere_row), + one padding block
+    std::vector<float> gen_tri_ssph, gen_rect_ssph;       // per super-block of 32 blocks: bounding sphere
     std::vector<uint16_t> mf_rows;        // MFMA rows: (1 + npoint) x (mf_groups + 2) blocks of 32 rows x 8 halves
     std::vector<int32_t> mf_gid;          // per apex: MFMA stream position -> leaf index (-1: padding)
     std::vector<float> mf_cone;           // per apex and block: bounding cone of the block's leaves, 8 floats (rt_scene.cpp: block_cone)

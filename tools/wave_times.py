@@ -10,24 +10,25 @@ from raytrace_amd import api, scenes, _lib
 path = "/tmp/wave_times.bin"
 os.environ["RT_WAVE_TIMES_FILE"] = path
 _lib.check(_lib.lib().rt_init(0))
-w, h = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (3840, 2160)
-world, lights = scenes.synthetic()
+mirror = len(sys.argv) > 1 and sys.argv[1] == "mirror"        # the reflective workload at trace depth 2: k_general (level 1)
+w, h = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 and not mirror else (3840, 2160)
+world, lights = scenes.mirror_bench() if mirror else scenes.synthetic()
 sc = api.Scene(world, lights)
 sc.set_option(_lib.RT_OPT_HOST_BANDS, 1)           # one band: the records describe the whole frame
 for _ in range(3):
-    sc.render(w, h)
+    sc.render(w, h, depth=2 if mirror else 4)
     st = sc.stats()
 raw = np.fromfile(path, dtype=np.uint64)
 n = int(raw[0]); rec = raw[8:8 + 8 * n].reshape(n, 8)
 print(f"{n} wave records; kernel ms: primary {st['ms_primary']:.3f} shadow {st['ms_shadow']:.3f}")
-for name, sel in (("k_primary_mfma", (rec[:, 0] & 0xff) == 0), ("k_shadow_mfma", (rec[:, 0] & 0xff) == 1)):
+for name, sel in (("k_primary_mfma", (rec[:, 0] & 0xff) == 0), ("k_shadow_mfma", (rec[:, 0] & 0xff) == 1), ("k_general", (rec[:, 0] & 0xff) == 2)):
     r = rec[sel]
     if len(r) == 0:
         continue
     t0, t1 = r[:, 2].astype(np.float64) / 100.0, r[:, 3].astype(np.float64) / 100.0      # us (100 MHz)
     dur = t1 - t0
     span = t1.max() - t0.min()
-    slots = 1024 * 3
+    slots = 1024 * (3 if name == "k_shadow_mfma" else 4)
     print(f"{name}: {len(r)} waves, span {span:.1f} us, wave duration us: mean {dur.mean():.1f} p50 {np.percentile(dur, 50):.1f} p90 {np.percentile(dur, 90):.1f} "
           f"p99 {np.percentile(dur, 99):.1f} max {dur.max():.1f}; slot occupancy {dur.sum() / (span * slots):.2f}")
     # when do waves finish: how long is the tail after 90 % of the waves have ended
