@@ -1,10 +1,17 @@
 #!/bin/bash
-# Builds a kernel variant into raytrace_amd/lib/ab/<name>.so for tools/ab_bench.sh.  usage: tools/build_variant.sh name [-DFLAG=..]...
+# Builds a kernel variant into raytrace_amd/lib/ab/<name>.so for tools/ab_bench.sh.
+# usage: [SCENE_FLAGS="-DX=.."] tools/build_variant.sh name [-DFLAG=..]...   (flags go to rt_kernels.hip; SCENE_FLAGS to rt_scene.cpp)
 set -e
 name=$1; shift
 cd "$(dirname "$0")/../raytrace_amd/csrc"
 mkdir -p ../lib/ab /tmp/abbuild
 /opt/rocm/bin/hipcc "$@" -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -Wall -Wno-unused-function -c -o /tmp/abbuild/$name.o rt_kernels.hip
-[ -f rt_scene.o ] || make rt_scene.o
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../lib/ab/$name.so rt_scene.o /tmp/abbuild/$name.o
+scene=rt_scene.o
+if [ -n "$SCENE_FLAGS" ]; then
+  g++ $SCENE_FLAGS -O2 -std=c++17 -fPIC -ffp-contract=off -Wall -c -o /tmp/abbuild/${name}_scene.o rt_scene.cpp
+  scene=/tmp/abbuild/${name}_scene.o
+else
+  [ -f rt_scene.o ] || make rt_scene.o
+fi
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../lib/ab/$name.so $scene /tmp/abbuild/$name.o
 echo built $name

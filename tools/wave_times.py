@@ -20,6 +20,8 @@ for _ in range(3):
     st = sc.stats()
 raw = np.fromfile(path, dtype=np.uint64)
 n = int(raw[0]); rec = raw[8:8 + 8 * n].reshape(n, 8)
+if os.environ.get("RT_WAVE_TIMES_KEEP"):                      # keep the raw records (for scheduling experiments off the box)
+    np.save(os.environ["RT_WAVE_TIMES_KEEP"], rec)
 print(f"{n} wave records; kernel ms: primary {st['ms_primary']:.3f} shadow {st['ms_shadow']:.3f}")
 for name, sel in (("k_primary_mfma", (rec[:, 0] & 0xff) == 0), ("k_shadow_mfma", (rec[:, 0] & 0xff) == 1), ("k_general", (rec[:, 0] & 0xff) == 2)):
     r = rec[sel]
