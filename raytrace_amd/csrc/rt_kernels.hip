@@ -205,7 +205,11 @@ __device__ __forceinline__ RayD camera_ray(const RenderParams &P, int x, int y) 
 constexpr int RT_STAT_SLOTS = 256;
 // Workspace::qcount: [0, 32) shadow jobs per point light; [32, 32 + RT_MAX_LEVELS] rays per bounce level; then the
 // number of hit points waiting for a normal callback
-constexpr int RT_QCOUNT_CB = 32 + RT_MAX_LEVELS + 1, RT_QCOUNT_WORDS = RT_QCOUNT_CB + 1;
+constexpr int RT_QCOUNT_CB = 32 + RT_MAX_LEVELS + 1, RT_QCOUNT_CLEAR = RT_QCOUNT_CB + 1;
+// ... then, NOT cleared between renders: [RT_QCOUNT_HIST, + 64) per point light of a group {wall-clock ticks, waves} of a
+// sample of its k_shadow_mfma waves, halved at every launch (a moving average); [RT_QCOUNT_ORDER, + 32) the order the
+// lights' waves are dispatched in, costliest light first (k_queue_offsets).
+constexpr int RT_QCOUNT_HIST = RT_QCOUNT_CLEAR, RT_QCOUNT_ORDER = RT_QCOUNT_HIST + 64, RT_QCOUNT_WORDS = RT_QCOUNT_ORDER + 32;
 __device__ __forceinline__ void stat_add(const RenderParams &P, int k, unsigned long long v) {
     const unsigned wave = (blockIdx.x + blockIdx.y * gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
     atomicAdd(&P.counters[(size_t)(wave % RT_STAT_SLOTS) * 16 + k], v);
@@ -795,6 +799,22 @@ __global__ void __launch_bounds__(1024) k_queue_offsets(const RenderParams P) {
     if (t == 1023) {
         P.qcount[pl] = s_part[1023];
         if (s_part[1023]) stat_add(P, 0, (unsigned long long)s_part[1023]);
+    }
+    // The order k_shadow_mfma takes the lights in: the light whose waves took longest on average (a sample of the waves
+    // of the renders before this one) first.  The kernel ends when its last wave ends, and with 3 waves per SIMD that
+    // tail is a fifth of its time; started last, the cheap lights' waves make a shorter one.  The order decides when a
+    // wave runs, never what it computes; without a history (first render, rt_render_device_noalloc) it is 0, 1, 2, ...
+    if (pl == 0 && t < 32) {
+        unsigned *hist = P.qcount + RT_QCOUNT_HIST, *order = P.qcount + RT_QCOUNT_ORDER;
+        const unsigned ticks = hist[2 * t], waves = hist[2 * t + 1];
+        const float cost = (t < P.npoint && waves > 0u) ? (float)ticks / (float)waves : 0.f;
+        unsigned rank = 0;
+        for (int j = 0; j < P.npoint; ++j) {
+            const float cj = __shfl(cost, j);
+            rank += (cj > cost || (cj == cost && j < t)) ? 1u : 0u;
+        }
+        if (t < P.npoint) order[rank] = (unsigned)t;
+        hist[2 * t] = ticks >> 1; hist[2 * t + 1] = waves >> 1;
     }
 }
 
@@ -1404,10 +1424,11 @@ __device__ __forceinline__ bool record_test_staged(const float *rec, int row, in
 // blocks, half of the leaves of each leaf block.
 __global__ void RT_HOT(RT_WAVES_EU_MF_SHADOW) k_shadow_mfma(const RenderParams P) {
     RT_WAVE_T0
-    const int pl = (int)blockIdx.y;
+    const int pl = (int)P.qcount[RT_QCOUNT_ORDER + blockIdx.y];      // costliest light first (k_queue_offsets)
     const unsigned count = P.qcount[pl];
     const unsigned wave = blockIdx.x * RT_WAVES_PER_BLOCK + (threadIdx.x >> 6);
     if (wave * 256u >= count) return;
+    const unsigned long long t_start = wall_clock64();
     const int lane = (int)(threadIdx.x & 63), c = lane & 31, h = lane >> 5;
     const int li = P.point_light[pl];
     const LightD &Lt = P.lights[li];
@@ -1606,6 +1627,10 @@ __global__ void RT_HOT(RT_WAVES_EU_MF_SHADOW) k_shadow_mfma(const RenderParams P
     if (lane == 0 && nexact) stat_add(P, 2, (unsigned long long)nexact);
     if (lane == 0) stat_add(P, 7, (unsigned long long)nblocks);
     if (lane == 0 && Q.nrec) stat_add(P, 4, (unsigned long long)Q.nrec);
+    if (lane == 0 && (wave & 7u) == 3u) {       // every eighth wave reports how long it took (100 MHz ticks): the lights' order next time
+        atomicAdd(&P.qcount[RT_QCOUNT_HIST + 2 * pl], (unsigned)(wall_clock64() - t_start));
+        atomicAdd(&P.qcount[RT_QCOUNT_HIST + 2 * pl + 1], 1u);
+    }
 #ifdef RT_WAVE_TIMES
     wave_ph[2] = (Q.t_s1 & 0xffff) | ((Q.t_ex & 0xffff) << 16) | ((Q.t_bits & 0xffff) << 32) | ((Q.t_loop & 0xffff) << 48);
     wave_record(P, 1u | ((unsigned)pl << 8), wave, wave_t0, nblocks, Q.nrec, nexact, wave_ph);
@@ -2551,7 +2576,10 @@ int ws_grow(DeviceScene &D, const WsNeeds &n) {
     int rc;
     Workspace &W = D.ws;
     if (!W.counters) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&W.counters), RT_STAT_SLOTS * 16 * sizeof(unsigned long long)));
-    if (!W.qcount) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&W.qcount), RT_QCOUNT_WORDS * sizeof(unsigned)));
+    if (!W.qcount) {
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&W.qcount), RT_QCOUNT_WORDS * sizeof(unsigned)));
+        HIP_TRY(hipMemset(W.qcount, 0, RT_QCOUNT_WORDS * sizeof(unsigned)));
+    }
     if (n.hit_id && (rc = ensure(W.hit_id, D.hit_id_cap, n.hit_id))) return rc;
     if (n.accum && (rc = ensure(W.accum, D.accum_cap, n.accum))) return rc;
     if (n.hitrec && (rc = ensure(W.hitrec, D.hitrec_cap, n.hitrec))) return rc;
@@ -2715,7 +2743,7 @@ int render_rows(rt_scene *s, DeviceScene &D, const Workspace &W, size_t crow, in
             uint8_t *const rgba0 = P.rgba;
             uint32_t *const accum0 = P.accum;
             unsigned *const lvl_count = W.qcount + 32;
-            HIP_TRY(hipMemsetAsync(W.qcount, 0, RT_QCOUNT_WORDS * sizeof(unsigned), st));
+            HIP_TRY(hipMemsetAsync(W.qcount, 0, RT_QCOUNT_CLEAR * sizeof(unsigned), st));
             for (int lvl = 0; lvl < levels; ++lvl) {
                 if (lvl > 0) {      // trace (n-1) lights world reflected, Main.hs:554
                     HIP_TRY(hipMemsetAsync(W.qcount, 0, 32 * sizeof(unsigned), st));
@@ -3251,6 +3279,8 @@ extern "C" int rt_render_device_noalloc(rt_scene *s, int w, int h, int depth, in
         (void)fits(rows_fit);                              // W = the layout that is used
     }
     hipStream_t st = stream ? (hipStream_t)stream : (hipStream_t)D.stream;
+    // (the array keeps whatever the last call left: no history of the lights' costs here, they are taken in their own order)
+    if (nrows > 0) HIP_TRY(hipMemsetAsync(W.qcount + RT_QCOUNT_HIST, 0, (RT_QCOUNT_WORDS - RT_QCOUNT_HIST) * sizeof(unsigned), st));
     for (int r = 0; r < nrows; r += rows_fit) {
         const int rows = nrows - r < rows_fit ? nrows - r : rows_fit;
         const size_t off = (size_t)r * (size_t)w;
