@@ -2459,6 +2459,7 @@ int device_prepare(rt_scene &s, DeviceScene &D, int device, int w, int h) {
     if (!D.copy_stream) { hipStream_t st; HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); D.copy_stream = st; }
     if (!D.copy_stream2) { hipStream_t st; HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); D.copy_stream2 = st; }
     for (void *&e : D.band_done) if (!e) { hipEvent_t ev; HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); e = ev; }
+    for (void *&e : D.hits_done) if (!e) { hipEvent_t ev; HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); e = ev; }
     if (D.version == s.version && D.eye_version == s.eye_version) return RT_OK;
     const double t0 = now_ms();
     int rc;
@@ -2638,7 +2639,9 @@ int run_normal_callbacks(rt_scene &s, const RenderParams &P, hipStream_t st, uns
 // whole frame.  `W` holds buffers of at least ws_needs(...) elements for chunks of `crow` rows; `timed` records an
 // event per kernel boundary (creates events on first use).
 int render_rows(rt_scene *s, DeviceScene &D, const Workspace &W, size_t crow, int w, int h, int depth, int spp, uint64_t seed,
-                int row0, int nrows, void *d_rgba, void *d_hit_id, hipStream_t st, bool more, bool timed) {
+                int row0, int nrows, void *d_rgba, void *d_hit_id, hipStream_t st, bool more, bool timed, hipEvent_t hits_done = nullptr) {
+    // hits_done: recorded on `st` as soon as the caller's hit-ID buffer is complete (after the nearest-hit kernel of
+    // sample 0's last chunk: everything later only reads it), so that a copy of it can run beside the shading kernels
     int rc;
     const size_t npix = (size_t)w * (size_t)nrows;
     if (!more) { D.last_primary = 0; D.ev_used = 0; }
@@ -2733,6 +2736,7 @@ int render_rows(rt_scene *s, DeviceScene &D, const Workspace &W, size_t crow, in
 #endif
             }
             if (timed && (rc = next_event(D, st, 1))) return rc;
+            if (hits_done && sample == 0 && r + crow >= (size_t)nrows) HIP_TRY(hipEventRecord(hits_done, st));
             if (!d_rgba) continue;
             // grids: shadow waves of 256 jobs, one thread per slot; bounce levels have up to lcap slots
             const size_t slots_max = levels > 1 ? (size_t)P.lcap : (size_t)P.qcap;
@@ -2829,7 +2833,7 @@ size_t chunk_rows(int w, int nrows, int levels) {
 
 // rt_render_device on the growing workspace of the (scene, device) pair
 int render_band(rt_scene *s, int device, int w, int h, int depth, int spp, uint64_t seed, int row0, int nrows,
-                void *d_rgba, void *d_hit_id, hipStream_t st, bool more) {
+                void *d_rgba, void *d_hit_id, hipStream_t st, bool more, hipEvent_t hits_done = nullptr) {
     int rc;
     DeviceScene &D = s->dev[device];
     if ((rc = device_prepare(*s, D, device, w, h))) return rc;
@@ -2838,7 +2842,7 @@ int render_band(rt_scene *s, int device, int w, int h, int depth, int spp, uint6
     const size_t crow = chunk_rows(w, nrows, levels);
     const WsNeeds need = ws_needs(w, nrows, crow, s->npoint, levels, spp, d_hit_id == nullptr, d_rgba != nullptr, !s->normal_fn.empty());
     if ((rc = ws_grow(D, need))) return rc;
-    return render_rows(s, D, D.ws, crow, w, h, depth, spp, seed, row0, nrows, d_rgba, d_hit_id, st ? st : (hipStream_t)D.stream, more, true);
+    return render_rows(s, D, D.ws, crow, w, h, depth, spp, seed, row0, nrows, d_rgba, d_hit_id, st ? st : (hipStream_t)D.stream, more, true, hits_done);
 }
 
 } // namespace
@@ -2879,6 +2883,7 @@ void rt_scene_destroy(rt_scene *s) {
         }
         for (void *e : d.evpool) if (e) (void)hipEventDestroy((hipEvent_t)e);
         for (void *e : d.band_done) if (e) (void)hipEventDestroy((hipEvent_t)e);
+        for (void *e : d.hits_done) if (e) (void)hipEventDestroy((hipEvent_t)e);
         if (d.stream) (void)hipStreamDestroy((hipStream_t)d.stream);
         if (d.copy_stream) (void)hipStreamDestroy((hipStream_t)d.copy_stream);
         if (d.copy_stream2) (void)hipStreamDestroy((hipStream_t)d.copy_stream2);
@@ -2906,12 +2911,14 @@ int rt_render(rt_scene *s, int w, int h, int depth, int spp, uint64_t seed, int 
     if ((rc = device_prepare(*s, D, t_device, w, h))) return rc;
     if ((rc = ensure(D.rgba, D.rgba_cap, 4 * npix))) return rc;
     if ((rc = ensure(D.hit_out, D.hit_out_cap, npix))) return rc;
-    hipStream_t st = (hipStream_t)D.stream, cst = (hipStream_t)D.copy_stream;
-    // The frame is enqueued as up to RT_HOST_BANDS_MAX row bands of at least ~2 Mi pixels; band k's copy to the
-    // caller's memory runs on its own stream behind the render of band k+1, so only the last band's copy is exposed.
+    hipStream_t st = (hipStream_t)D.stream, cst = (hipStream_t)D.copy_stream, hst = (hipStream_t)D.copy_stream2;
+    // The frame is enqueued as row bands; band k's copies to the caller's memory run on their own streams beside the
+    // kernels that follow: the hit IDs as soon as the band's nearest-hit kernel has ended (the shading kernels only read
+    // them), the colours behind the band's last kernel, i.e. beside band k + 1.  Only the last band's colours are
+    // exposed.  Bands cost kernel time (every band has its own tails), so there are few: one per ~4 Mi pixels.
     // Into rt_host_alloc'ed (page-locked) memory the copies are DMA at PCIe rate; into pageable memory they stage
     // through the runtime's bounce buffers and block this thread, which is why every band is enqueued first.
-    int nb = s->opt_host_bands > 0 ? s->opt_host_bands : (int)(npix >> 21);
+    int nb = s->opt_host_bands > 0 ? s->opt_host_bands : (int)(npix >> 22);
     nb = nb < 1 ? 1 : (nb > RT_HOST_BANDS_MAX ? RT_HOST_BANDS_MAX : nb);
     int brows = (nrows + nb - 1) / nb;
     brows = (brows + RT_TILE_H - 1) / RT_TILE_H * RT_TILE_H;
@@ -2920,19 +2927,25 @@ int rt_render(rt_scene *s, int w, int h, int depth, int spp, uint64_t seed, int 
         const int rows = nrows - r < brows ? nrows - r : brows;
         const size_t off = (size_t)r * (size_t)w;
         rc = render_band(s, t_device, w, h, depth, spp, seed, row0 + r, rows, rgba_out ? D.rgba + 4 * off : nullptr,
-                         D.hit_out + off, st, r > 0);
+                         D.hit_out + off, st, r > 0, hit_id_out ? (hipEvent_t)D.hits_done[used] : nullptr);
         if (rc == RT_OK && !hip_ok(hipEventRecord((hipEvent_t)D.band_done[used], st), "hipEventRecord")) rc = RT_ERR_HIP;
     }
     int band = 0;
     for (int r = 0; r < nrows && rc == RT_OK; r += brows, ++band) {
         const int rows = nrows - r < brows ? nrows - r : brows;
         const size_t off = (size_t)r * (size_t)w, n = (size_t)rows * (size_t)w;
-        if (!hip_ok(hipStreamWaitEvent(cst, (hipEvent_t)D.band_done[band], 0), "hipStreamWaitEvent")) { rc = RT_ERR_HIP; break; }
-        if (rgba_out && !hip_ok(hipMemcpyAsync(rgba_out + 4 * off, D.rgba + 4 * off, 4 * n, hipMemcpyDeviceToHost, cst), "hipMemcpyAsync")) rc = RT_ERR_HIP;
-        if (rc == RT_OK && hit_id_out && !hip_ok(hipMemcpyAsync(hit_id_out + off, D.hit_out + off, n * sizeof(int32_t), hipMemcpyDeviceToHost, cst), "hipMemcpyAsync")) rc = RT_ERR_HIP;
+        if (hit_id_out) {
+            if (!hip_ok(hipStreamWaitEvent(hst, (hipEvent_t)D.hits_done[band], 0), "hipStreamWaitEvent")) { rc = RT_ERR_HIP; break; }
+            if (!hip_ok(hipMemcpyAsync(hit_id_out + off, D.hit_out + off, n * sizeof(int32_t), hipMemcpyDeviceToHost, hst), "hipMemcpyAsync")) { rc = RT_ERR_HIP; break; }
+        }
+        if (rgba_out) {
+            if (!hip_ok(hipStreamWaitEvent(cst, (hipEvent_t)D.band_done[band], 0), "hipStreamWaitEvent")) { rc = RT_ERR_HIP; break; }
+            if (!hip_ok(hipMemcpyAsync(rgba_out + 4 * off, D.rgba + 4 * off, 4 * n, hipMemcpyDeviceToHost, cst), "hipMemcpyAsync")) rc = RT_ERR_HIP;
+        }
     }
     // always drain both streams, also after an error: nothing may still be writing the caller's buffers on return
     if (!hip_ok(hipStreamSynchronize(cst), "hipStreamSynchronize") && rc == RT_OK) rc = RT_ERR_HIP;
+    if (!hip_ok(hipStreamSynchronize(hst), "hipStreamSynchronize") && rc == RT_OK) rc = RT_ERR_HIP;
     if (!hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize") && rc == RT_OK) rc = RT_ERR_HIP;
     return rc;
 }

@@ -59,6 +59,7 @@ struct DeviceScene {          // the scene on ONE device (HBM), owned by the rt_
     void *copy_stream = nullptr;     // hipStream_t: rt_render's copies to host memory, band by band; rt_render_multi's peer copies
     void *copy_stream2 = nullptr;    // hipStream_t: rt_render_multi's copies from the home device to host memory
     void *band_done[RT_HOST_BANDS_MAX] = {};   // hipEvent_t
+    void *hits_done[RT_HOST_BANDS_MAX] = {};   // hipEvent_t: the band's hit-ID buffer is complete (rt_render copies it early)
     // work buffers of rt_render / rt_render_device, grown on demand
     Workspace ws;
     size_t hit_id_cap = 0, accum_cap = 0, hitrec_cap = 0, queue_cap = 0, qsparse_cap = 0, tcount_cap = 0, lit_cap = 0;
