@@ -104,7 +104,8 @@ int  rt_scene_set_dialect(rt_scene *, int dialect);
  *                      256 rays; 0: every wave scans every block (the plain all-pairs scan).  Same pixels either way.
  *   RT_OPT_FILTER      0 (default): first stage on the matrix cores; 1: the FP32 vector-ALU kernels, which exist only
  *                      in the cross-check build libraytrace_gpu_valu.so (RT_ERR_UNSUPPORTED in the product library).
- *   RT_OPT_HOST_BANDS  copy bands of rt_render, 1..8 (0 = default: one per 2 Mi pixels).
+ *   RT_OPT_HOST_BANDS  copy bands of rt_render, 1..8 (0 = default: one per 4 Mi pixels; a band's hit IDs travel to the
+ *                      host as soon as its nearest-hit kernel has ended, its colours beside the next band's kernels).
  *   RT_OPT_MULTI_STAGE 1: rt_render_multi sends the bands of devices[0] through a staging buffer and a peer copy too,
  *                      like those of the other devices (default 0: they are rendered in place; tests use 1). */
 enum { RT_OPT_CULL = 0, RT_OPT_FILTER = 1, RT_OPT_HOST_BANDS = 2, RT_OPT_MULTI_STAGE = 3 };
