@@ -2467,7 +2467,10 @@ int device_prepare(rt_scene &s, DeviceScene &D, int device, int w, int h) {
     int rc;
     // a render of the stale copy may still be in flight on some stream: the arrays are overwritten in place
     if (D.version != 0) HIP_TRY(hipDeviceSynchronize());
-    const size_t ntri = s.tri_gid.size(), nrect = s.rect_gid.size(), nsph = s.sph_gid.size();
+    const size_t nsph = s.sph_gid.size();
+#ifdef RT_VALU_FILTER
+    const size_t ntri = s.tri_gid.size(), nrect = s.rect_gid.size();
+#endif
     const size_t gstride = (size_t)s.mf_groups + 2;
     if (D.version != s.version) {
         if ((rc = upload(D.leaves, s.leaves))) return rc;
@@ -2500,8 +2503,10 @@ int device_prepare(rt_scene &s, DeviceScene &D, int device, int w, int h) {
         if ((rc = upload(D.rect_gid, s.rect_gid))) return rc;
     } else {
         // only the camera bound grew: apex 0 (the eye) of every per-apex array
+#ifdef RT_VALU_FILTER
         if ((rc = upload_slice(D.tri_rec, s.tri_rec, 0, ntri))) return rc;
         if ((rc = upload_slice(D.rect_rec, s.rect_rec, 0, nrect))) return rc;
+#endif
         if ((rc = upload_slice(D.sph_rec, s.sph_rec, 0, nsph))) return rc;
         if ((rc = upload_slice(D.mf_rows, s.mf_rows, 0, gstride * 32 * 8))) return rc;
         if ((rc = upload_slice(D.mf_gid, s.mf_gid, 0, gstride * MF_LEAVES))) return rc;

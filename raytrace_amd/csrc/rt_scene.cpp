@@ -14,6 +14,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <thread>
 #include <limits>
 
 namespace rt {
@@ -840,8 +841,13 @@ void build_filter_records(rt_scene &s, int w, int h, bool eye_only) {
     if (!eye_only) {
         // four records of padding: the kernels prefetch up to record i + 2 while testing record i
         s.sph_rec.assign(nsph * (size_t)napex + 4, never_rec());
+#ifdef RT_VALU_FILTER   // the per-type record blocks feed the vector-ALU kernels of the cross-check build only
         s.tri_rec.assign(ntri * (size_t)napex + 4, never_rec());
         s.rect_rec.assign(nrect * (size_t)napex + 4, never_rec());
+#else
+        s.tri_rec.assign(4, never_rec());
+        s.rect_rec.assign(4, never_rec());
+#endif
         s.mf_gid.assign(gstride * (size_t)napex * MF_LEAVES, -1);
         s.mf_rows.assign(gstride * (size_t)napex * 32 * 8, 0);
         s.mf_rec.assign(gstride * (size_t)napex * MF_LEAVES, never_rec());
@@ -862,8 +868,10 @@ void build_filter_records(rt_scene &s, int w, int h, bool eye_only) {
         }
         for (size_t k = 0; k < gstride * 8; ++k) s.mf_cone[(size_t)apex * gstride * 8 + k] = 0.f;
     };
-    int apex = 0;
-    auto fill = [&](const double A[3], const double dmax[3], double eye_d) {
+    // the apexes are independent of one another (disjoint slices of every array): one host thread each
+    struct ApexJob { double A[3], dmax[3], eye_d; int apex; };
+    std::vector<ApexJob> jobs;
+    auto fill = [&](const double A[3], const double dmax[3], double eye_d, int apex) {
         reset_apex(apex);
         std::vector<LeafCone> cone(nplanar);
         std::vector<double> cu(nplanar), cv(nplanar);
@@ -904,29 +912,48 @@ void build_filter_records(rt_scene &s, int w, int h, bool eye_only) {
             std::memcpy(&r2.c[15], &gid, 4);
         }
         for (size_t g = 0; g < gstride; ++g) block_cone(&ordered[g * MF_LEAVES], MF_LEAVES, &s.mf_cone[((size_t)apex * gstride + g) * 8]);
+#ifdef RT_VALU_FILTER
         for (size_t k = 0; k < ntri; ++k) s.tri_rec[(size_t)apex * ntri + k] = make_rec(s.leaves[s.tri_gid[k]], A, dmax, eye_d);
         for (size_t k = 0; k < nrect; ++k) s.rect_rec[(size_t)apex * nrect + k] = make_rec(s.leaves[s.rect_gid[k]], A, dmax, eye_d);
+#endif
         for (size_t k = 0; k < nsph; ++k) s.sph_rec[(size_t)apex * nsph + k] = make_sphere_rec(s.leaves[s.sph_gid[k]], A, dmax);
-        ++apex;
+    };
+    auto add_job = [&](const double A[3], const double dmax[3], double eye_d) {
+        ApexJob j{};
+        for (int i = 0; i < 3; ++i) { j.A[i] = A[i]; j.dmax[i] = dmax[i]; }
+        j.eye_d = eye_d; j.apex = (int)jobs.size();
+        jobs.push_back(j);
+        return j.apex;
     };
     {   // the eye: every primary ray o = (posX, posY, 0), D = (posX, posY, d) passes through o - D.  The apex does not
         // depend on the image size (d = -tan(fov/2)/2); only the bound on |posX|, |posY| does, through the margins.
         const CameraD cam = fixed_camera(1, 1);
         const double A[3] = {0.0, 0.0, -cam.d};
-        fill(A, s.eye_dmax, cam.d);
+        add_job(A, s.eye_dmax, cam.d);
     }
     if (!eye_only) {
         for (LightD &Lt : s.lights) {
             if (Lt.kind != 0) continue;
-            Lt.rec_offset = apex;
             const double A[3] = {Lt.px, Lt.py, Lt.pz};
             double dmax[3];
             for (int i = 0; i < 3; ++i) {
                 const double a = std::fabs(lo[i] - A[i]), b = std::fabs(hi[i] - A[i]);
                 dmax[i] = (s.leaves.empty() ? 1.0 : std::fmax(a, b)) * 1.001 + 1e-3;
             }
-            fill(A, dmax, 0.0);
+            Lt.rec_offset = add_job(A, dmax, 0.0);
         }
+    }
+    {
+        const size_t width = std::max<size_t>(1, std::min<size_t>(8, std::thread::hardware_concurrency()));
+        for (size_t j0 = 0; j0 < jobs.size(); j0 += width) {
+            std::vector<std::thread> pool;
+            for (size_t j = j0 + 1; j < std::min(jobs.size(), j0 + width); ++j)
+                pool.emplace_back([&, j] { fill(jobs[j].A, jobs[j].dmax, jobs[j].eye_d, jobs[j].apex); });
+            fill(jobs[j0].A, jobs[j0].dmax, jobs[j0].eye_d, jobs[j0].apex);
+            for (std::thread &t : pool) t.join();
+        }
+    }
+    if (!eye_only) {
         s.reflective = false;
         for (const MaterialD &m : s.mats) if (m.reflectivity > 0) s.reflective = true;
         s.gen_tri.clear(); s.gen_rect.clear(); s.gen_sph.clear();
@@ -1239,10 +1266,20 @@ int rt_scene_get_filter_record(const rt_scene *s, int apex, int leaf, float out[
         set_error("rt_scene_get_filter_record: bad argument (call rt_scene_prepare_host first)"); return RT_ERR_ARG;
     }
     const LeafD &L = s->leaves[leaf];
-    const std::vector<FilterRec> &v = L.kind == LEAF_TRI ? s->tri_rec : (L.kind == LEAF_SPHERE ? s->sph_rec : s->rect_rec);
-    const size_t n = L.kind == LEAF_TRI ? s->tri_gid.size() : (L.kind == LEAF_SPHERE ? s->sph_gid.size() : s->rect_gid.size());
-    std::memcpy(out, v[(size_t)apex * n + (size_t)L.slot].c, sizeof(float) * 16);
-    return RT_OK;
+    if (L.kind == LEAF_SPHERE) {
+        std::memcpy(out, s->sph_rec[(size_t)apex * s->sph_gid.size() + (size_t)L.slot].c, sizeof(float) * 16);
+        return RT_OK;
+    }
+    // a planar leaf's record sits in the apex's stream, at the position of its matrix-core row
+    const size_t gstride = (size_t)s->mf_groups + 2, base = (size_t)apex * gstride * MF_LEAVES;
+    for (size_t k = 0; k < gstride * MF_LEAVES; ++k)
+        if (s->mf_gid[base + k] == leaf) {
+            std::memcpy(out, s->mf_rec[base + k].c, sizeof(float) * 16);
+            out[14] = out[15] = 0.f;                               // (the stream's copy carries kind and index there)
+            return RT_OK;
+        }
+    set_error("rt_scene_get_filter_record: the leaf has no record");
+    return RT_ERR_ARG;
 }
 
 int rt_scene_get_mfma_row(const rt_scene *s, int apex, int leaf, uint16_t out[8]) {

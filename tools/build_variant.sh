@@ -8,10 +8,10 @@ mkdir -p ../lib/ab /tmp/abbuild
 /opt/rocm/bin/hipcc "$@" -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -Wall -Wno-unused-function -c -o /tmp/abbuild/$name.o rt_kernels.hip
 scene=rt_scene.o
 if [ -n "$SCENE_FLAGS" ]; then
-  g++ $SCENE_FLAGS -O2 -std=c++17 -fPIC -ffp-contract=off -Wall -c -o /tmp/abbuild/${name}_scene.o rt_scene.cpp
+  g++ $SCENE_FLAGS -O2 -std=c++17 -fPIC -pthread -ffp-contract=off -Wall -c -o /tmp/abbuild/${name}_scene.o rt_scene.cpp
   scene=/tmp/abbuild/${name}_scene.o
 else
   [ -f rt_scene.o ] || make rt_scene.o
 fi
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../lib/ab/$name.so $scene /tmp/abbuild/$name.o
+/opt/rocm/bin/hipcc -shared -fPIC -pthread --offload-arch=gfx950 -o ../lib/ab/$name.so $scene /tmp/abbuild/$name.o
 echo built $name
