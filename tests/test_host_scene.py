@@ -290,3 +290,29 @@ def test_normal_callback_registration():
     sc.close()
     with pytest.raises(TypeError):
         api.linearInterpolation(lambda x, y: 0.0, "sinc", (-1.0, -1.0), (1.0, 1.0), 0.5, (0.0, -2.0, -10.0), 2.0)
+
+
+def test_host_index_is_the_same_every_time_it_is_built():
+    """The apexes' record streams are built on one host thread each (rt_scene.cpp: build_filter_records); they write
+    disjoint slices, so two builds of the same scene must agree byte for byte: rows, records, block cones, light order."""
+    import ctypes as C
+    L = _lib.lib()
+    world, lights = scenes.synthetic(ntri=600, ncuboid=60)
+    snaps = []
+    for _ in range(2):
+        sc = api.Scene(world, lights)
+        assert L.rt_scene_prepare_host(sc.handle, 640, 360) >= 0
+        row, rec, cone = (C.c_uint16 * 8)(), (C.c_float * 16)(), (C.c_float * 8)()
+        snap = []
+        for apex in range(5):
+            groups = L.rt_scene_get_block_cone(sc.handle, apex, 0, cone)
+            for g in range(groups + 2):
+                L.rt_scene_get_block_cone(sc.handle, apex, g, cone)
+                snap.append(bytes(cone))
+            for leaf in range(0, sc.num_leaves, 7):
+                pos = L.rt_scene_get_mfma_row(sc.handle, apex, leaf, row)
+                assert L.rt_scene_get_filter_record(sc.handle, apex, leaf, rec) == 0
+                snap.append((pos, bytes(row), bytes(rec)))
+        snaps.append(snap)
+        sc.close()
+    assert snaps[0] == snaps[1]
