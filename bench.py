@@ -113,11 +113,14 @@ def utilisation(kernel, ms, mfmas_live, pmc):
     return out
 
 
+PREWARM = 20
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--ntri", type=int, default=10000)
@@ -241,13 +244,19 @@ def main():
     else:
         pieces = 1
     subs = [sub_bands(b, pieces) for b in bands]
-    marks = {}
+    # (the three events of a step are made once and recorded again every step: the last step's are the ones read)
+    marks = {k: torch.cuda.Event(enable_timing=True) for k in ("start", "rendered", "end")}
+    frame_ptr, hit_ptr = mine.data_ptr(), hit.data_ptr()
 
     def step(seed=20260355):
+        if n == 1:      # one GPU: nothing but the render call in the timed loop (it goes to the stream it is given)
+            scene.render_device(w, h, frame_ptr, hit_ptr, depth=args.depth, spp=args.spp, seed=seed, row0=row0, nrows=nrows,
+                                stream=rs.cuda_stream)
+            return
         pending, host = [], []
         host_frame = torch.empty((h, w, 4), dtype=torch.uint8) if staged and rank == 0 else None
         with torch.cuda.stream(rs):
-            marks["start"] = rs.record_event(torch.cuda.Event(enable_timing=True))
+            rs.record_event(marks["start"])
             for k in range(pieces):
                 r0, nr = subs[rank][k]
                 piece = mine[r0 - row0:r0 - row0 + nr]
@@ -255,9 +264,7 @@ def main():
                     scene.render_device(w, h, piece.data_ptr(), hit[r0 - row0:].data_ptr(), depth=args.depth, spp=args.spp,
                                         seed=seed, row0=r0, nrows=nr, stream=rs.cuda_stream)
                 if k == pieces - 1:
-                    marks["rendered"] = rs.record_event(torch.cuda.Event(enable_timing=True))
-                if n == 1:
-                    continue
+                    rs.record_event(marks["rendered"])
                 group = [s[k] for s in subs]
                 if not staged:     # ncclSend/ncclRecv in one group: every peer has a direct xGMI link to GPU 0
                     pending += gather_bands(dist, frame, piece, group, rank, wait=False)
@@ -272,7 +279,7 @@ def main():
                 for r0, nr, host_piece in host:
                     host_frame[r0:r0 + nr] = host_piece
                 frame.copy_(host_frame)
-            marks["end"] = rs.record_event(torch.cuda.Event(enable_timing=True))
+            rs.record_event(marks["end"])
 
     def sync():
         torch.cuda.synchronize()
@@ -280,6 +287,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # The chip comes out of idle at a low clock and the order of the lights in k_shadow_mfma settles after a few frames:
+    # PREWARM untimed frames before the W warm-up steps of the contract (reported in the line as `untimed_frames_before_warmup`).
+    for _ in range(PREWARM):
+        step()
     for _ in range(args.warmup):
         step()
     sync()
@@ -293,8 +304,8 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     # the last step of this rank: render of its band, and what followed until the frame was complete (exposed exchange)
-    rank_render_ms = marks["start"].elapsed_time(marks["rendered"])
-    rank_total_ms = marks["start"].elapsed_time(marks["end"])
+    rank_render_ms = marks["start"].elapsed_time(marks["rendered"]) if n > 1 else dt / args.steps * 1e3
+    rank_total_ms = marks["start"].elapsed_time(marks["end"]) if n > 1 else dt / args.steps * 1e3
     if n > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         if staged:
@@ -396,7 +407,7 @@ def main():
                          "note": "per-kernel utilisation is reported by the N = 1 line; here launch_ms is the slowest rank's sum over its pieces"})
         out = {
             "metric": "primary Mrays/s (whole node)", "value": primary / (dt / args.steps) / 1e6, "unit": "Mrays/s",
-            "n_gpus": n, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
+            "n_gpus": n, "steps": args.steps, "warmup": args.warmup, "untimed_frames_before_warmup": PREWARM, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{wname} ({nleaves} leaves), {nlt} point light(s) + ambient, "
