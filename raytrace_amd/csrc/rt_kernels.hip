@@ -779,26 +779,33 @@ __global__ void __launch_bounds__(RT_SETUP_THREADS) k_setup(const RenderParams P
 // Exclusive prefix sums of one light's per-block job counts (in place), the light's total into qcount and the
 // shadow-ray counter.  One block of 1024 threads per light.
 __global__ void __launch_bounds__(1024) k_queue_offsets(const RenderParams P) {
-    __shared__ unsigned s_part[1024];
-    const int pl = (int)blockIdx.x, t = (int)threadIdx.x;
+    __shared__ unsigned s_w[16];
+    const int pl = (int)blockIdx.x, t = (int)threadIdx.x, lane = t & 63, wv = t >> 6;
     unsigned *cnt = P.tcount + (size_t)pl * (size_t)P.setup_blocks;
-    const int per = (P.setup_blocks + 1023) / 1024;
-    const int lo = t * per, hi = min(P.setup_blocks, lo + per);
-    unsigned sum = 0;
-    for (int k = lo; k < hi; ++k) sum += cnt[k];
-    s_part[t] = sum;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {                         // inclusive scan of the partial sums
-        const unsigned v = t >= o ? s_part[t - o] : 0u;
+    const int n = P.setup_blocks;
+    // 1024 consecutive counts at a time (coalesced; the next chunk's are loaded while this one is scanned): a scan inside
+    // every wave, the waves' totals through LDS, the running total of the chunks before in a register
+    unsigned carry = 0;
+    unsigned c_next = t < n ? cnt[t] : 0u;
+    for (int base = 0; base < n; base += 1024) {
+        const int k = base + t;
+        const unsigned c = c_next;
+        c_next = k + 1024 < n ? cnt[k + 1024] : 0u;
+        unsigned incl = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const unsigned up = __shfl_up(incl, o); if (lane >= o) incl += up; }
+        if (lane == 63) s_w[wv] = incl;
         __syncthreads();
-        s_part[t] += v;
+        unsigned before = 0, total = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { const unsigned v = s_w[j]; total += v; if (j < wv) before += v; }
+        if (k < n) cnt[k] = carry + before + incl - c;
+        carry += total;
         __syncthreads();
     }
-    unsigned run = s_part[t] - sum;
-    for (int k = lo; k < hi; ++k) { const unsigned c = cnt[k]; cnt[k] = run; run += c; }
     if (t == 1023) {
-        P.qcount[pl] = s_part[1023];
-        if (s_part[1023]) stat_add(P, 0, (unsigned long long)s_part[1023]);
+        P.qcount[pl] = carry;
+        if (carry) stat_add(P, 0, (unsigned long long)carry);
     }
     // The order k_shadow_mfma takes the lights in: the light whose waves took longest on average (a sample of the waves
     // of the renders before this one) first.  The kernel ends when its last wave ends, and with 3 waves per SIMD that
@@ -819,12 +826,17 @@ __global__ void __launch_bounds__(1024) k_queue_offsets(const RenderParams P) {
 }
 
 // Moves every k_setup block's run of jobs to its place in the light's dense queue.
-__global__ void __launch_bounds__(RT_SETUP_THREADS) k_queue_compact(const RenderParams P) {
+#ifndef RT_COMPACT_THREADS
+#define RT_COMPACT_THREADS 128
+#endif
+__global__ void __launch_bounds__(RT_COMPACT_THREADS) k_queue_compact(const RenderParams P) {
     const int pl = (int)blockIdx.y;
     const size_t slot = (size_t)pl * (size_t)P.setup_blocks + blockIdx.x;
     const unsigned off = P.tcount[slot];
     const unsigned end = (int)blockIdx.x + 1 < P.setup_blocks ? P.tcount[slot + 1] : P.qcount[pl];
-    if (threadIdx.x < end - off) P.queue[(size_t)pl * (size_t)P.qcap + off + threadIdx.x] = P.qsparse[slot * RT_SETUP_THREADS + threadIdx.x];
+    // (a run holds a third of RT_SETUP_THREADS jobs on average: a thread per possible job was mostly idle waves)
+    for (unsigned i = threadIdx.x; i < end - off; i += RT_COMPACT_THREADS)
+        P.queue[(size_t)pl * (size_t)P.qcap + off + i] = P.qsparse[slot * RT_SETUP_THREADS + i];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2780,7 +2792,7 @@ int render_rows(rt_scene *s, DeviceScene &D, const Workspace &W, size_t crow, in
                     hipLaunchKernelGGL(k_setup, dim3(ublocks), dim3(RT_SETUP_THREADS), 0, st, P);
                     if (np > 0) {
                         hipLaunchKernelGGL(k_queue_offsets, dim3((unsigned)np), dim3(1024), 0, st, P);
-                        hipLaunchKernelGGL(k_queue_compact, dim3(ublocks, (unsigned)np), dim3(RT_SETUP_THREADS), 0, st, P);
+                        hipLaunchKernelGGL(k_queue_compact, dim3(ublocks, (unsigned)np), dim3(RT_COMPACT_THREADS), 0, st, P);
                     }
                     if (timed && (rc = next_event(D, st, 2))) return rc;
                     if (np > 0) {
