@@ -205,7 +205,7 @@ __device__ __forceinline__ RayD camera_ray(const RenderParams &P, int x, int y) 
 constexpr int RT_STAT_SLOTS = 256;
 // Workspace::qcount: [0, 32) shadow jobs per point light; [32, 32 + RT_MAX_LEVELS] rays per bounce level; then the
 // number of hit points waiting for a normal callback
-constexpr int RT_QCOUNT_CB = 32 + RT_MAX_LEVELS + 1, RT_QCOUNT_CLEAR = RT_QCOUNT_CB + 1;
+constexpr int RT_QCOUNT_CB = 32 + RT_MAX_LEVELS + 1, RT_QCOUNT_CLEAR = (RT_QCOUNT_CB + 1 + 3) / 4 * 4;   // (cleared as whole 16-byte units: one fill kernel)
 // ... then, NOT cleared between renders: [RT_QCOUNT_HIST, + 64) per point light of a group {wall-clock ticks, waves} of a
 // sample of its k_shadow_mfma waves, halved at every launch (a moving average); [RT_QCOUNT_ORDER, + 32) the order the
 // lights' waves are dispatched in, costliest light first (k_queue_offsets).
