@@ -2472,8 +2472,6 @@ int device_prepare(rt_scene &s, DeviceScene &D, int device, int w, int h) {
     if (!D.copy_stream2) { hipStream_t st; HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); D.copy_stream2 = st; }
     for (void *&e : D.band_done) if (!e) { hipEvent_t ev; HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); e = ev; }
     for (void *&e : D.hits_done) if (!e) { hipEvent_t ev; HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); e = ev; }
-    if (!D.stats_ev) { hipEvent_t ev; HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); D.stats_ev = ev; }
-    if (!D.host_counters) HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&D.host_counters), RT_STAT_SLOTS * 16 * sizeof(unsigned long long), hipHostMallocPortable));
     if (D.version == s.version && D.eye_version == s.eye_version) return RT_OK;
     const double t0 = now_ms();
     int rc;
@@ -2827,14 +2825,6 @@ int render_rows(rt_scene *s, DeviceScene &D, const Workspace &W, size_t crow, in
         if (timed && (rc = next_event(D, st, 4))) return rc;
     }
     HIP_TRY(hipGetLastError());
-    // the counters follow the render to page-locked host memory on the same stream: rt_get_stats then waits for an event
-    // instead of issuing a blocking copy (20 us per query for a caller that polls the statistics of every frame)
-    D.counters_on_host = false;
-    if (timed && D.host_counters && D.stats_ev) {      // (not from rt_render_device_noalloc: nothing but kernels and memsets there)
-        HIP_TRY(hipMemcpyAsync(D.host_counters, W.counters, RT_STAT_SLOTS * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipEventRecord((hipEvent_t)D.stats_ev, st));
-        D.counters_on_host = true;
-    }
     D.stats_pending = true;
     return RT_OK;
 }
@@ -2911,8 +2901,6 @@ void rt_scene_destroy(rt_scene *s) {
         for (void *e : d.evpool) if (e) (void)hipEventDestroy((hipEvent_t)e);
         for (void *e : d.band_done) if (e) (void)hipEventDestroy((hipEvent_t)e);
         for (void *e : d.hits_done) if (e) (void)hipEventDestroy((hipEvent_t)e);
-        if (d.stats_ev) (void)hipEventDestroy((hipEvent_t)d.stats_ev);
-        if (d.host_counters) (void)hipHostFree(d.host_counters);
         if (d.stream) (void)hipStreamDestroy((hipStream_t)d.stream);
         if (d.copy_stream) (void)hipStreamDestroy((hipStream_t)d.copy_stream);
         if (d.copy_stream2) (void)hipStreamDestroy((hipStream_t)d.copy_stream2);
@@ -3004,16 +2992,10 @@ namespace {
 // statistics of the last render of the (scene, device) pair; synchronises with it
 int device_stats(rt_scene *s, DeviceScene &D, rt_stats *out) {
     if (D.stats_pending) {
-        static thread_local std::vector<unsigned long long> staged(RT_STAT_SLOTS * 16);
-        const unsigned long long *all = staged.data();
-        if (D.counters_on_host) {
-            HIP_TRY(hipEventSynchronize((hipEvent_t)D.stats_ev));
-            all = D.host_counters;
-        } else {
-            if (D.ev_used > 0) HIP_TRY(hipEventSynchronize((hipEvent_t)D.evpool[D.ev_used - 1]));
-            else HIP_TRY(hipDeviceSynchronize());
-            HIP_TRY(hipMemcpy(staged.data(), D.last_counters, staged.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-        }
+        static thread_local std::vector<unsigned long long> all(RT_STAT_SLOTS * 16);
+        if (D.ev_used > 0) HIP_TRY(hipEventSynchronize((hipEvent_t)D.evpool[D.ev_used - 1]));
+        else HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(all.data(), D.last_counters, all.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         unsigned long long c[16] = {0};
         for (int slot = 0; slot < RT_STAT_SLOTS; ++slot) for (int k = 0; k < 16; ++k) c[k] += all[(size_t)slot * 16 + k];
         double ms[5] = {0, 0, 0, 0, 0};

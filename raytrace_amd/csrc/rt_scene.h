@@ -75,9 +75,6 @@ struct DeviceScene {          // the scene on ONE device (HBM), owned by the rt_
     std::vector<int> evkind;         // which kernel ended at that event (1 primary .. 4 final)
     int ev_used = 0;
     bool stats_pending = false;
-    unsigned long long *host_counters = nullptr;           // page-locked copy of the last render's counters (follows it on its stream)
-    void *stats_ev = nullptr;                              // hipEvent_t: that copy has arrived
-    bool counters_on_host = false;
     uint64_t last_primary = 0;
     rt_stats stats{};
 };
