@@ -239,8 +239,9 @@ int  rt_render_device_noalloc(rt_scene *, int w, int h, int depth, int spp, uint
 int  rt_synchronize(void);                      /* waits for everything enqueued on the calling thread's device */
 /* Page-locked host memory for rt_render's output buffers, in place of the reference's storable-vector
  * allocation behind `generateImage` (Main.hs:621 builds the image rt_render now fills).  Optional: any
- * host pointer works, but into these buffers the copy back is DMA at PCIe rate and hides behind the
- * render.  NULL on failure (rt_last_error).  Free with rt_host_free only. */
+ * host pointer works, but into these buffers the hit IDs travel by DMA beside the shading kernels and the
+ * last kernel stores the colours straight into them over PCIe, so no copy is left behind the render
+ * (DESIGN.md section 8).  NULL on failure (rt_last_error).  Free with rt_host_free only. */
 void *rt_host_alloc(size_t bytes);
 void  rt_host_free(void *p);
 int  rt_get_stats(rt_scene *, rt_stats *out);   /* synchronises; stats of the last render of this scene */
