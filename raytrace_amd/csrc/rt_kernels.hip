@@ -209,6 +209,7 @@ constexpr int RT_QCOUNT_CB = 32 + RT_MAX_LEVELS + 1, RT_QCOUNT_CLEAR = (RT_QCOUN
 // ... then, NOT cleared between renders: [RT_QCOUNT_HIST, + 64) per point light of a group {wall-clock ticks, waves} of a
 // sample of its k_shadow_mfma waves, halved at every launch (a moving average); [RT_QCOUNT_ORDER, + 32) the order the
 // lights' waves are dispatched in, costliest light first (k_queue_offsets).
+constexpr size_t RT_COUNTER_BYTES = (size_t)RT_STAT_SLOTS * 16 * sizeof(unsigned long long);
 constexpr int RT_QCOUNT_HIST = RT_QCOUNT_CLEAR, RT_QCOUNT_ORDER = RT_QCOUNT_HIST + 64, RT_QCOUNT_WORDS = RT_QCOUNT_ORDER + 32;
 __device__ __forceinline__ void stat_add(const RenderParams &P, int k, unsigned long long v) {
     const unsigned wave = (blockIdx.x + blockIdx.y * gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -2593,9 +2594,9 @@ WsNeeds ws_needs(int w, int nrows, size_t crow, int npoint, int levels, int spp,
 int ws_grow(DeviceScene &D, const WsNeeds &n) {
     int rc;
     Workspace &W = D.ws;
-    if (!W.counters) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&W.counters), RT_STAT_SLOTS * 16 * sizeof(unsigned long long)));
-    if (!W.qcount) {
-        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&W.qcount), RT_QCOUNT_WORDS * sizeof(unsigned)));
+    if (!W.counters) {      // the queue counters sit right behind the statistics counters: a render clears both with one fill
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&W.counters), RT_COUNTER_BYTES + RT_QCOUNT_WORDS * sizeof(unsigned)));
+        W.qcount = reinterpret_cast<unsigned *>(reinterpret_cast<unsigned char *>(W.counters) + RT_COUNTER_BYTES);
         HIP_TRY(hipMemset(W.qcount, 0, RT_QCOUNT_WORDS * sizeof(unsigned)));
     }
     if (n.hit_id && (rc = ensure(W.hit_id, D.hit_id_cap, n.hit_id))) return rc;
@@ -2675,7 +2676,9 @@ int render_rows(rt_scene *s, DeviceScene &D, const Workspace &W, size_t crow, in
     int32_t *hit = (int32_t *)d_hit_id;
     if (!hit) hit = W.hit_id;
     if (spp > 1 && d_rgba) HIP_TRY(hipMemsetAsync(W.accum, 0, 3 * npix * sizeof(uint32_t), st));
-    if (!more) HIP_TRY(hipMemsetAsync(W.counters, 0, RT_STAT_SLOTS * 16 * sizeof(unsigned long long), st));
+    // (a render's first chunk finds its queue counters cleared by the same fill as the statistics counters)
+    if (!more) HIP_TRY(hipMemsetAsync(W.counters, 0, RT_COUNTER_BYTES + RT_QCOUNT_CLEAR * sizeof(unsigned), st));
+    bool queues_clear = !more;
 
 #ifdef RT_VALU_FILTER
     // the vector-ALU kernels are compiled for Main.hs only: a Talk.hs scene always takes the matrix-core kernels
@@ -2764,7 +2767,8 @@ int render_rows(rt_scene *s, DeviceScene &D, const Workspace &W, size_t crow, in
             uint8_t *const rgba0 = P.rgba;
             uint32_t *const accum0 = P.accum;
             unsigned *const lvl_count = W.qcount + 32;
-            HIP_TRY(hipMemsetAsync(W.qcount, 0, RT_QCOUNT_CLEAR * sizeof(unsigned), st));
+            if (!queues_clear) HIP_TRY(hipMemsetAsync(W.qcount, 0, RT_QCOUNT_CLEAR * sizeof(unsigned), st));
+            queues_clear = false;
             for (int lvl = 0; lvl < levels; ++lvl) {
                 if (lvl > 0) {      // trace (n-1) lights world reflected, Main.hs:554
                     HIP_TRY(hipMemsetAsync(W.qcount, 0, 32 * sizeof(unsigned), st));
@@ -2890,7 +2894,7 @@ void rt_scene_destroy(rt_scene *s) {
                           &d.gen_tri_ssph, &d.gen_rect_ssph};
         for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
         Workspace &W = d.ws;
-        void *ptrs[] = {W.counters, W.qcount, W.hit_id, W.accum, W.hitrec, W.queue, W.qsparse, W.tcount, W.lit,
+        void *ptrs[] = {W.counters, W.hit_id, W.accum, W.hitrec, W.queue, W.qsparse, W.tcount, W.lit,
                         W.cb_slot, W.cb_xy, W.cb_group, W.cb_normal, d.rgba, d.hit_out, d.stage_rgba, d.stage_hit};
         for (void *p : ptrs) if (p) (void)hipFree(p);
         for (int k = 0; k < RT_MAX_LEVELS; ++k) {
@@ -3270,8 +3274,8 @@ size_t ws_carve(unsigned char *base, size_t cap, const WsNeeds &n, Workspace &W)
         used += count * sizeof(T);
     };
     W = Workspace{};
-    take(W.counters, (size_t)RT_STAT_SLOTS * 16);
-    take(W.qcount, (size_t)RT_QCOUNT_WORDS);
+    take(W.counters, (size_t)RT_STAT_SLOTS * 16 + ((size_t)RT_QCOUNT_WORDS + 1) / 2);
+    if (fits) W.qcount = reinterpret_cast<unsigned *>(reinterpret_cast<unsigned char *>(W.counters) + RT_COUNTER_BYTES);
     if (n.hit_id) take(W.hit_id, n.hit_id);
     if (n.accum) take(W.accum, n.accum);
     if (n.hitrec) take(W.hitrec, n.hitrec);
