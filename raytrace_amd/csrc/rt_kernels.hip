@@ -1978,12 +1978,12 @@ __device__ __forceinline__ bool run_meets(const RunBound &b, float Cx, float Cy,
 
 // The same test on a record staged in LDS (WaveQueues::rec: c[k] of row r at rec[32 k + r]); R = rec + row.
 template <int KIND>
-__device__ __forceinline__ float filter_gen_staged(const float *R, float ox, float oy, float oz, float dx, float dy, float dz) {
+__device__ __forceinline__ float filter_gen_staged(const float *R, float ox, float oy, float oz, float dx, float dy, float dz, float &a, float &b) {
     const float n0 = R[0 * 32], n1 = R[1 * 32], n2 = R[2 * 32];
     const float g0 = R[4 * 32], g1 = R[5 * 32], g2 = R[6 * 32];
     const float k0 = R[8 * 32], k1 = R[9 * 32], k2 = R[10 * 32];
-    const float a = __builtin_fmaf(n0, dx, __builtin_fmaf(n1, dy, n2 * dz));
-    const float b = __builtin_fmaf(n0, ox, __builtin_fmaf(n1, oy, __builtin_fmaf(n2, oz, R[3 * 32])));
+    a = __builtin_fmaf(n0, dx, __builtin_fmaf(n1, dy, n2 * dz));
+    b = __builtin_fmaf(n0, ox, __builtin_fmaf(n1, oy, __builtin_fmaf(n2, oz, R[3 * 32])));
     const float e1 = __builtin_fmaf(g0, ox, __builtin_fmaf(g1, oy, __builtin_fmaf(g2, oz, R[7 * 32])));
     const float f1 = __builtin_fmaf(g0, dx, __builtin_fmaf(g1, dy, g2 * dz));
     const float e2 = __builtin_fmaf(k0, ox, __builtin_fmaf(k1, oy, __builtin_fmaf(k2, oz, R[11 * 32])));
@@ -2052,7 +2052,8 @@ __device__ __forceinline__ f32x16 mfma2(const i32x4 a0, const f16x8 b0, const i3
 
 template <int KIND, class EX>
 __device__ __forceinline__ void general_blocks(const RenderParams &P, const GenRec *recs, const uint16_t *rows, const float *spheres,
-                                               const float *sspheres, int n, const RunBound &rb, const GenRays &G, const double *s_ray, bool anybad,
+                                               const float *sspheres, int n, const RunBound &rb, const GenRays &G, const double *s_ray, const float *s_rn,
+                                               const unsigned long long *s_bt, bool depth_skip, bool anybad,
                                                uint16_t *list, WaveQueues &Q, unsigned &nblocks, EX &&exact) {
     const int lane = (int)(threadIdx.x & 63), c = lane & 31, h = lane >> 5, nblk = (n + 31) / 32;
     const i32x4 *rows4 = reinterpret_cast<const i32x4 *>(rows);
@@ -2061,9 +2062,26 @@ __device__ __forceinline__ void general_blocks(const RenderParams &P, const GenR
         const int e = (int)(entry & 63u), row = (int)((entry >> 8) & 31u);
         const float *R = Q.rec + row;
         const float ox = (float)s_ray[0 * 64 + e], oy = (float)s_ray[1 * 64 + e], oz = (float)s_ray[2 * 64 + e];
-        const float dx = (float)s_ray[3 * 64 + e], dy = (float)s_ray[4 * 64 + e], dz = (float)s_ray[5 * 64 + e];
-        const float z = filter_gen_staged<KIND>(R, ox, oy, oz, dx, dy, dz);
+        // the record's margin is for a direction of unit length; a reflection off a normal that is not (an `fnorm` may
+        // return any vector, Main.hs:550, 956-965) is as long as it likes, and the signs the test reads do not depend on it
+        const float rn = s_rn[e];
+        const float dx = (float)s_ray[3 * 64 + e] * rn, dy = (float)s_ray[4 * 64 + e] * rn, dz = (float)s_ray[5 * 64 + e] * rn;
+        float a, b;
+        const float z = filter_gen_staged<KIND>(R, ox, oy, oz, dx, dy, dz, a, b);
         entry2 = ((uint32_t)__float_as_int(R[15 * 32]) << 8) | ((uint32_t)KIND << 6) | (uint32_t)e;
+#ifndef RT_NO_DEPTH_SKIP
+        // Behind the nearest hit this ray has so far?  The plane is met at t = -b / a (in units of the ray's own direction:
+        // |b| rn / |a| with the unit direction); c[13], c[14] bound the FP32 error of a and b (make_gen_rec), 2^-18 covers the
+        // roundings of this line and of rn, and the last term covers rayDistance's own error (Main.hs:122-127 divides a
+        // difference of z by the direction's z: 16 ulp (|oz| / |dz| + t), which is why a ray with a flat z is left alone).
+        // A pair that is skipped would have lost strictly, so ties still go to the left-most leaf.
+        if (depth_skip && __builtin_fabsf(dz) >= 0x1p-10f) {
+            const float best = (float)__longlong_as_double((long long)s_bt[e]);        // no hit yet: NaN, skips nothing
+            const float lhs = (__builtin_fabsf(b) - R[14 * 32]) * rn * (1.f - 0x1p-18f);
+            const float rhs = __builtin_fmaf(0x1p-36f * __builtin_fabsf(oz), rn, best) * (__builtin_fabsf(a) + R[13 * 32]);
+            if (lhs > rhs) return false;
+        }
+#endif
         return z >= R[12 * 32];
     };
     // Works off the blocks list[0..cnt-1]; list[cnt] names the padding block (the loads run one block ahead).
@@ -2228,6 +2246,16 @@ __global__ void __attribute__((amdgpu_waves_per_eu(RT_WAVES_EU_GEN, 8))) __launc
                               : f16x8{Dh[0], Dm[0], Dh[0], Dh[1], Dm[1], Dh[1], Dh[2], Dm[2]};
         G.d5h[b] = Dh[5]; G.d5m[b] = Dm[5];
     }
+    // s_flag has been read: from here on the same words hold 1 / |direction| of every ray (1 for a ray that is none)
+    float *const s_rn = reinterpret_cast<float *>(s_flag);
+    {
+        const float dd = __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, dz * dz));
+        const bool usable = s_flag[lane] == 1;
+        __builtin_amdgcn_wave_barrier();
+        s_rn[lane] = usable ? __builtin_amdgcn_rsqf(dd) : 1.f;
+        __builtin_amdgcn_wave_barrier();
+    }
+    const bool depth_skip = !RT_TALK(P);        // (Talk.hs:97-128 picks the nearest by squared distance, not by rayDistance)
     RT_WAVE_PHASE(0)
     RT_WAVE_PHASE(1)
     WaveQueues Q = {s_q1, s_q2, 0u, 0u, 0u, s_rec};
@@ -2255,8 +2283,8 @@ __global__ void __attribute__((amdgpu_waves_per_eu(RT_WAVES_EU_GEN, 8))) __launc
         __builtin_amdgcn_wave_barrier();
         if (win) atomicMin(&s_bid[e], gid);
     };
-    general_blocks<LEAF_TRI>(P, P.gen_tri, P.gen_tri_rows, P.gen_tri_sph, P.gen_tri_ssph, P.ntri, rb, G, s_ray, anybad, s_list, Q, nblocks, exact);
-    general_blocks<LEAF_RECT>(P, P.gen_rect, P.gen_rect_rows, P.gen_rect_sph, P.gen_rect_ssph, P.nrect, rb, G, s_ray, anybad, s_list, Q, nblocks, exact);
+    general_blocks<LEAF_TRI>(P, P.gen_tri, P.gen_tri_rows, P.gen_tri_sph, P.gen_tri_ssph, P.ntri, rb, G, s_ray, s_rn, s_bt, depth_skip, anybad, s_list, Q, nblocks, exact);
+    general_blocks<LEAF_RECT>(P, P.gen_rect, P.gen_rect_rows, P.gen_rect_sph, P.gen_rect_ssph, P.nrect, rb, G, s_ray, s_rn, s_bt, depth_skip, anybad, s_list, Q, nblocks, exact);
     if (P.nsph > 0) {           // spheres (few per scene): delta/4 = (d.o)^2 - (o.o - r^2) with o = origin - centre, Main.hs:396-400
         CGenPtr recs = as_const(P.gen_sph);
         CIntPtr gids = as_const(P.sph_gid);

@@ -625,7 +625,10 @@ static GenRec make_gen_rec(const LeafD &L, const double omax[3]) {
     for (int i = 0; i < 3; ++i) { r.c[i] = (float)n[i]; r.c[4 + i] = (float)g1[i]; r.c[8 + i] = (float)g2[i]; }
     r.c[3] = (float)L.d; r.c[7] = (float)c1; r.c[11] = (float)c2;
     r.c[12] = f_down(-m);
-    for (int i = 0; i < 13; ++i)
+    // bounds of the FP32 error of a (for a unit direction) and of b: k_general's "behind the nearest hit so far" skip
+    r.c[13] = -f_down(-std::ldexp(An, -21));
+    r.c[14] = -f_down(-(std::ldexp(Bn, -21) + 1e-30));
+    for (int i = 0; i < 15; ++i)
         if (!std::isfinite(r.c[i])) { GenRec a{}; a.c[12] = -1.0f; return a; }   // overflow: always pass, exact path decides
     return r;
 }

@@ -234,6 +234,29 @@ def test_arbitrary_fnorm_closures(gpu_lib):
     sc.close()
 
 
+def test_reflection_off_normals_of_any_length(gpu_lib):
+    """An `fnorm` may return a vector of any length (Main.hs:956-965 only fixes its sign), and trace reflects about it as
+    it is (Main.hs:550): the reflected rays are then many times longer than a unit vector.  The bounce levels' FP32 stages
+    and their "behind the nearest hit so far" skip must not depend on that length."""
+    import math
+    from raytrace_amd.api import CallbackNormals, black, green, mconcat, orange, rectangle, triangle
+
+    def fnorm(x, y):
+        return (0.6 * math.sin(3 * x), 4.0 + math.cos(2 * y), 0.6 * math.sin(x + y))
+    mirror = black.replace(reflectivity=0.8, specular=(255, 255, 255), specularity=20)
+    a, b, c, d = (-20, -7, 0), (20, -7, 0), (-20, -7, -40), (20, -7, -40)
+    two = mconcat([triangle(mirror, a, b, c), triangle(mirror, b, d, c)])
+    clutter, lights = scenes.synthetic(ntri=300, ncuboid=40)
+    walls = [rectangle(green, (0, 0, -32), (40, 0, 0), (0, 40, 0)), rectangle(orange, (0, 8, -18), (40, 0, 0), (0, 0, 40))]
+    world = mconcat([clutter] + walls + [CallbackNormals(two, 0.25, (0.0, -7.0, -20.0), fnorm)])
+    ref, hit, rgb = compare(world, lights, 240, 135, depth=4, label="long-normals")
+    assert (rgb == ref["rgb"]).all()
+    sc = api.Scene(world, lights)
+    sc.render(240, 135, depth=4)
+    assert sc.stats()["bounce_rays"] > 2000               # (the floor does reflect)
+    sc.close()
+
+
 def test_render_multi_equals_single_render(gpu_lib):
     """rt_render_multi on one device: 1, 3 and 5 bands of measured-cost rows, rendered in place and through the
     staging buffer + peer copy path, give the bytes of rt_render; statistics cover the whole frame."""
