@@ -2052,7 +2052,7 @@ __device__ __forceinline__ f32x16 mfma2(const i32x4 a0, const f16x8 b0, const i3
 
 template <int KIND, class EX>
 __device__ __forceinline__ void general_blocks(const RenderParams &P, const GenRec *recs, const uint16_t *rows, const float *spheres,
-                                               const float *sspheres, int n, const RunBound &rb, const GenRays &G, const double *s_ray, const float *s_rn,
+                                               const float *sspheres, int n, const RunBound &rb, const GenRays &G, const double *s_ray, const float *s_rayf,
                                                const unsigned long long *s_bt, bool depth_skip, bool anybad,
                                                uint16_t *list, WaveQueues &Q, unsigned &nblocks, EX &&exact) {
     const int lane = (int)(threadIdx.x & 63), c = lane & 31, h = lane >> 5, nblk = (n + 31) / 32;
@@ -2061,11 +2061,12 @@ __device__ __forceinline__ void general_blocks(const RenderParams &P, const GenR
     auto stage1 = [&](uint32_t entry, uint32_t &entry2) -> bool {
         const int e = (int)(entry & 63u), row = (int)((entry >> 8) & 31u);
         const float *R = Q.rec + row;
-        const float ox = (float)s_ray[0 * 64 + e], oy = (float)s_ray[1 * 64 + e], oz = (float)s_ray[2 * 64 + e];
-        // the record's margin is for a direction of unit length; a reflection off a normal that is not (an `fnorm` may
-        // return any vector, Main.hs:550, 956-965) is as long as it likes, and the signs the test reads do not depend on it
-        const float rn = s_rn[e];
-        const float dx = (float)s_ray[3 * 64 + e] * rn, dy = (float)s_ray[4 * 64 + e] * rn, dz = (float)s_ray[5 * 64 + e] * rn;
+        // FP32 copy of the ray: origin and UNIT direction.  The record's margin is for a direction of unit length; a
+        // reflection off a normal that is not (an `fnorm` may return any vector, Main.hs:550, 956-965) is as long as it
+        // likes, and the signs the test reads do not depend on the length.
+        const float ox = s_rayf[0 * 64 + e], oy = s_rayf[1 * 64 + e], oz = s_rayf[2 * 64 + e];
+        const float dx = s_rayf[3 * 64 + e], dy = s_rayf[4 * 64 + e], dz = s_rayf[5 * 64 + e];
+        const float rn = s_rayf[6 * 64 + e];                       // 1 / |direction|
         float a, b;
         const float z = filter_gen_staged<KIND>(R, ox, oy, oz, dx, dy, dz, a, b);
         entry2 = ((uint32_t)__float_as_int(R[15 * 32]) << 8) | ((uint32_t)KIND << 6) | (uint32_t)e;
@@ -2187,7 +2188,7 @@ __device__ __forceinline__ void general_blocks(const RenderParams &P, const GenR
 }
 
 #ifndef RT_WAVES_EU_GEN
-#define RT_WAVES_EU_GEN 4
+#define RT_WAVES_EU_GEN 3      // (168 registers, nothing spilled; the 12.5 KiB of LDS per wave allow no more than 3.25 anyway)
 #endif
 __global__ void __attribute__((amdgpu_waves_per_eu(RT_WAVES_EU_GEN, 8))) __launch_bounds__(64) k_general(const RenderParams P) {
     RT_WAVE_T0
@@ -2198,6 +2199,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(RT_WAVES_EU_GEN, 8))) __launc
     __shared__ uint16_t s_q1[RT_Q1_CAP];
     __shared__ uint32_t s_q2[RT_Q2_CAP];
     __shared__ double s_ray[9 * 64];
+    __shared__ float s_rayf[7 * 64];
     __shared__ float s_rec[16 * 32];
     const unsigned count = num_slots(P);
     const unsigned wave = blockIdx.x;
@@ -2246,13 +2248,12 @@ __global__ void __attribute__((amdgpu_waves_per_eu(RT_WAVES_EU_GEN, 8))) __launc
                               : f16x8{Dh[0], Dm[0], Dh[0], Dh[1], Dm[1], Dh[1], Dh[2], Dm[2]};
         G.d5h[b] = Dh[5]; G.d5m[b] = Dm[5];
     }
-    // s_flag has been read: from here on the same words hold 1 / |direction| of every ray (1 for a ray that is none)
-    float *const s_rn = reinterpret_cast<float *>(s_flag);
-    {
-        const float dd = __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, dz * dz));
+    {       // FP32 copies for stage 1: origin, unit direction (as it is for a ray that is no usable number), 1 / |direction|
         const bool usable = s_flag[lane] == 1;
-        __builtin_amdgcn_wave_barrier();
-        s_rn[lane] = usable ? __builtin_amdgcn_rsqf(dd) : 1.f;
+        const float rn = usable ? __builtin_amdgcn_rsqf(__builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, dz * dz))) : 1.f;
+        s_rayf[0 * 64 + lane] = ox; s_rayf[1 * 64 + lane] = oy; s_rayf[2 * 64 + lane] = oz;
+        s_rayf[3 * 64 + lane] = dx * rn; s_rayf[4 * 64 + lane] = dy * rn; s_rayf[5 * 64 + lane] = dz * rn;
+        s_rayf[6 * 64 + lane] = rn;
         __builtin_amdgcn_wave_barrier();
     }
     const bool depth_skip = !RT_TALK(P);        // (Talk.hs:97-128 picks the nearest by squared distance, not by rayDistance)
@@ -2283,8 +2284,8 @@ __global__ void __attribute__((amdgpu_waves_per_eu(RT_WAVES_EU_GEN, 8))) __launc
         __builtin_amdgcn_wave_barrier();
         if (win) atomicMin(&s_bid[e], gid);
     };
-    general_blocks<LEAF_TRI>(P, P.gen_tri, P.gen_tri_rows, P.gen_tri_sph, P.gen_tri_ssph, P.ntri, rb, G, s_ray, s_rn, s_bt, depth_skip, anybad, s_list, Q, nblocks, exact);
-    general_blocks<LEAF_RECT>(P, P.gen_rect, P.gen_rect_rows, P.gen_rect_sph, P.gen_rect_ssph, P.nrect, rb, G, s_ray, s_rn, s_bt, depth_skip, anybad, s_list, Q, nblocks, exact);
+    general_blocks<LEAF_TRI>(P, P.gen_tri, P.gen_tri_rows, P.gen_tri_sph, P.gen_tri_ssph, P.ntri, rb, G, s_ray, s_rayf, s_bt, depth_skip, anybad, s_list, Q, nblocks, exact);
+    general_blocks<LEAF_RECT>(P, P.gen_rect, P.gen_rect_rows, P.gen_rect_sph, P.gen_rect_ssph, P.nrect, rb, G, s_ray, s_rayf, s_bt, depth_skip, anybad, s_list, Q, nblocks, exact);
     if (P.nsph > 0) {           // spheres (few per scene): delta/4 = (d.o)^2 - (o.o - r^2) with o = origin - centre, Main.hs:396-400
         CGenPtr recs = as_const(P.gen_sph);
         CIntPtr gids = as_const(P.sph_gid);

@@ -53,3 +53,11 @@ for name, sel in (("k_primary_mfma", (rec[:, 0] & 0xff) == 0), ("k_shadow_mfma",
     print(f"   per wave: blocks {r[:, 4].mean():.1f} (max {r[:, 4].max()}), record tests {r[:, 5].mean():.0f} (max {r[:, 5].max()}), exact {r[:, 6].mean():.0f} (max {r[:, 6].max()})")
     print(f"   fit dur = {coef[0]:.2f} us + {coef[1]:.3f} us/block + {coef[2] * 64:.3f} us/64 record tests + {coef[3] * 64:.3f} us/64 exact;  R^2 {1 - ((dur - pred) ** 2).sum() / ((dur - dur.mean()) ** 2).sum():.3f}")
     print(f"   shares of mean duration: const {coef[0] / dur.mean():.2f}, blocks {coef[1] * r[:, 4].mean() / dur.mean():.2f}, records {coef[2] * r[:, 5].mean() / dur.mean():.2f}, exact {coef[3] * r[:, 6].mean() / dur.mean():.2f}")
+    # how many waves are resident over the kernel's span, and how heavy the waves are along the launch order
+    edges = np.linspace(t0.min(), t1.max(), 11)
+    conc = [float(np.clip(np.minimum(t1, edges[k + 1]) - np.maximum(t0, edges[k]), 0, None).sum() / (edges[k + 1] - edges[k])) for k in range(10)]
+    print("   resident waves in tenths of the span: " + " ".join(f"{c:.0f}" for c in conc) + f"  (slots {slots})")
+    order = np.argsort(r[:, 1], kind="stable")
+    tenth = np.array_split(order, 10)
+    print("   mean wave duration (us) in tenths of the launch order: " + " ".join(f"{dur[ix].mean():.0f}" for ix in tenth))
+    print("   mean start (us) in tenths of the launch order: " + " ".join(f"{(t0[ix] - t0.min()).mean():.0f}" for ix in tenth))
