@@ -1297,6 +1297,11 @@ __device__ __forceinline__ void mfma_scan(const i32x4 *base, const FilterRec *re
             }
             q_drain(Q, 0u, false, stage1, exact);       // q1 is empty before `rec` is overwritten
             __builtin_amdgcn_wave_barrier();
+#ifndef RT_MF_KEEP_ACC
+            // the first MFMA of the next block once more (bit-identical): its 16 result registers then need not live through
+            // the candidate stages above, which is where the kernels run out of registers
+            acc = mfma0(a_nxt, B[0]);
+#endif
             RT_TOCK(Q.t_loop, tl)
         }
     };
