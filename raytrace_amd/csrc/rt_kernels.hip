@@ -647,6 +647,24 @@ __device__ __forceinline__ int round8(double v) {
 }
 __device__ __forceinline__ double hs_max0(double v) { return 0.0 <= v ? v : 0.0; }    // max 0 v
 
+// x ** specularity (Main.hs:483).  Materials carry small whole exponents (1, 20, 100, 400 in the reference's scenes): those
+// are powers by squaring, at most 2 log2(n) roundings away from the real power (libm's pow is within one), which moves an
+// 8-bit colour only if f * 255 lies within 1e-13 of a rounding boundary; anything else goes through pow.
+#ifndef RT_POWI
+#define RT_POWI 1
+#endif
+__device__ __forceinline__ double pow_spec(double x, double sp) {
+#if RT_POWI
+    const int n = (int)sp;
+    if ((double)n == sp && n >= 0 && n <= 4096) {
+        double r = 1.0, b = x;
+        for (int k = n; k != 0; k >>= 1) { if (k & 1) r *= b; b *= b; }
+        return r;
+    }
+#endif
+    return pow(x, sp);
+}
+
 // What a point light adds to a pixel it reaches: pointLight (Main.hs:476-487) or Talk.hs's pointLight (Talk.hs:244-248).
 // k_final adds it for the lights that reach the pixel; k_setup evaluates the same function first and casts no shadow
 // ray where it is (0, 0, 0) — a black material, a grazing light: the shadow test could not change the pixel.
@@ -665,7 +683,7 @@ __device__ __forceinline__ void light_terms(const RenderParams &P, const LightD 
     const double rx = tx - k2 * H.nx, ry = ty - k2 * H.ny, rz = tz - k2 * H.nz;
     const double fDiffuse = Lt.diffuse * hs_max0(lndot);
     const double fSpecular = (lndot <= 0) ? 0.0
-        : Lt.specular * pow(hs_max0(rx * ray.dx + ry * ray.dy + rz * ray.dz), M.specularity);
+        : Lt.specular * pow_spec(hs_max0(rx * ray.dx + ry * ray.dy + rz * ray.dz), M.specularity);
     r = min(255, round8(fDiffuse * (double)M.diffuse[0]) + round8(fSpecular * (double)M.specular[0]));
     g = min(255, round8(fDiffuse * (double)M.diffuse[1]) + round8(fSpecular * (double)M.specular[1]));
     b = min(255, round8(fDiffuse * (double)M.diffuse[2]) + round8(fSpecular * (double)M.specular[2]));
