@@ -716,8 +716,9 @@ __global__ void __launch_bounds__(RT_SETUP_THREADS) k_setup(const RenderParams P
         ray = slot_ray(P, pix);
         mat = L.mat;
         double ix = 0, iy = 0, iz = 0, t;
-        if (L.kind == LEAF_RECT) leaf_isect<LEAF_RECT>(L, ray, ix, iy, iz, t, RT_TALK(P));
-        else if (L.kind == LEAF_TRI) leaf_isect<LEAF_TRI>(L, ray, ix, iy, iz, t, RT_TALK(P));
+        // only the hit point is wanted, and planeRayIsect (Main.hs:264-277) finds it the same way for a triangle as for a
+        // rectangle: one pass for a wave that holds both
+        if (L.kind != LEAF_SPHERE) leaf_isect<LEAF_RECT>(L, ray, ix, iy, iz, t, RT_TALK(P));
         else leaf_isect<LEAF_SPHERE>(L, ray, ix, iy, iz, t, RT_TALK(P));
         double nx = L.nx, ny = L.ny, nz = L.nz;
         if (L.kind == LEAF_SPHERE) {                                                   // scalar (recip radius) (isect - center), :410
