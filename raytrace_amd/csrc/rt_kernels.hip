@@ -1076,36 +1076,48 @@ __device__ __forceinline__ unsigned long long tile_guard_mask(const RenderParams
 // all origins lie in the box [lo, hi].  A ray crosses the plane a = f of a guard box at the fraction
 // u = (f - o_a) / (lp_a - o_a) of the way to the light (u > 0: ahead of the origin), which is monotone in o_a, and the
 // other two coordinates of the crossing, o_b + (lp_b - o_b) u, are bilinear in (o_b, u): their extremes over the box
-// of origins are at its corners.  If for some face every crossing lies inside the face, with a margin 10^6 times the
-// rounding errors of intersectBB's arithmetic, that face's test holds for every ray of the wave.
-__device__ __forceinline__ unsigned long long bundle_guard_mask(const RenderParams &P, const LightD &Lt, const double (&lo)[3], const double (&hi)[3]) {
+// of origins are at its corners.  If for some face every crossing lies inside the face, with a margin far above the
+// rounding errors of intersectBB's arithmetic AND of this function's own, that face's test holds for every ray of the wave.
+// The proof itself runs in FP32 (it is 6 faces x 2 divisions per box and wave: 4.8 us of a 79 us wave in FP64, 6 % of
+// the kernel).  Its error budget, with S_a = |f| + |lp_a| + |lo_a| + |hi_a|: the four inputs are rounded to FP32 and
+// subtracted, so n and d are off by < 3e-7 S_a; `tiny` = 1e-5 S_a keeps the sign of n certain; with |d| > `far` >= 1e-2 S_a
+// the fraction u is off by < 3e-5 (1 + u) + 3e-7 u (the reciprocal), and a crossing coordinate by
+// < 3.2e-5 (|lp_b| + |o_b|)(1 + u); the margin m is 1e-4 of that scale plus the box's own.  The box of origins was
+// rounded to FP32 as well (6e-8 of its coordinates: inside `tiny` and m).  A light within 1 % of the scale of a face's
+// plane, or a crossing within 1e-4 of the scale of the face's rim, is simply not proven: those pairs walk their chain.
+__device__ __forceinline__ unsigned long long bundle_guard_mask(const RenderParams &P, const LightD &Lt, const float (&lo)[3], const float (&hi)[3]) {
     const int lane = (int)(threadIdx.x & 63u);
     bool ok = false;
     int anc = -1;
     if (lane < P.nguard_cached) {
         const GuardD B = P.guards[lane];
         anc = B.parent;
-        const double b0[3] = {B.x0, B.y0, B.z0}, b1[3] = {B.x1, B.y1, B.z1}, lp[3] = {Lt.px, Lt.py, Lt.pz};
+        const float b0[3] = {(float)B.x0, (float)B.y0, (float)B.z0}, b1[3] = {(float)B.x1, (float)B.y1, (float)B.z1};
+        const float lp[3] = {(float)Lt.px, (float)Lt.py, (float)Lt.pz};
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                const double f = s ? b1[a] : b0[a];
-                const double n0 = f - lo[a], n1 = f - hi[a], d0 = lp[a] - lo[a], d1 = lp[a] - hi[a];
-                const double tiny = 1e-9 * (fabs(f) + fabs(lp[a]) + fabs(lo[a]) + fabs(hi[a])) + 1e-300;
+                const float f = s ? b1[a] : b0[a];
+                const float n0 = f - lo[a], n1 = f - hi[a], d0 = lp[a] - lo[a], d1 = lp[a] - hi[a];
+                const float S = __builtin_fabsf(f) + __builtin_fabsf(lp[a]) + __builtin_fabsf(lo[a]) + __builtin_fabsf(hi[a]);
+                const float tiny = 1e-5f * S + 1e-30f;
                 // every origin strictly on one side of the face and of the light's coordinate, and the face ahead; the light
                 // is farther than the 1e-5 that separates the origin from the hit point the direction was taken from
-                const double far = tiny + 1e-4;
+                const float far = 1e-2f * S + 1e-4f;
                 bool face = (n0 > tiny && n1 > tiny && d0 > far && d1 > far) || (n0 < -tiny && n1 < -tiny && d0 < -far && d1 < -far);
-                const double u0 = n0 / d0, u1 = n1 / d1;
-                const double ul = fmin(u0, u1), uh = fmax(u0, u1);
+                const float u0 = n0 * __builtin_amdgcn_rcpf(d0), u1 = n1 * __builtin_amdgcn_rcpf(d1);
+                const float ul = __builtin_fminf(u0, u1), uh = __builtin_fmaxf(u0, u1);
 #pragma unroll
                 for (int k = 1; k < 3; ++k) {
                     const int b = (a + k) % 3;
-                    const double v00 = lo[b] + (lp[b] - lo[b]) * ul, v01 = lo[b] + (lp[b] - lo[b]) * uh;
-                    const double v10 = hi[b] + (lp[b] - hi[b]) * ul, v11 = hi[b] + (lp[b] - hi[b]) * uh;
-                    const double vl = fmin(fmin(v00, v01), fmin(v10, v11)), vh = fmax(fmax(v00, v01), fmax(v10, v11));
-                    const double m = 1e-9 * (fabs(b0[b]) + fabs(b1[b]) + (fabs(lp[b]) + fabs(lo[b]) + fabs(hi[b])) * (1.0 + uh)) + 1e-300;
+                    const float v00 = lo[b] + (lp[b] - lo[b]) * ul, v01 = lo[b] + (lp[b] - lo[b]) * uh;
+                    const float v10 = hi[b] + (lp[b] - hi[b]) * ul, v11 = hi[b] + (lp[b] - hi[b]) * uh;
+                    const float vl = __builtin_fminf(__builtin_fminf(v00, v01), __builtin_fminf(v10, v11));
+                    const float vh = __builtin_fmaxf(__builtin_fmaxf(v00, v01), __builtin_fmaxf(v10, v11));
+                    const float m = 1e-4f * (__builtin_fabsf(b0[b]) + __builtin_fabsf(b1[b])
+                                             + (__builtin_fabsf(lp[b]) + __builtin_fabsf(lo[b]) + __builtin_fabsf(hi[b])) * (1.0f + uh)) + 1e-30f;
+                    // (a NaN anywhere fails a comparison: not proven)
                     face = face && b0[b] + m <= vl && vh <= b1[b] - m;
                 }
                 ok |= face;
@@ -1483,7 +1495,7 @@ __global__ void RT_HOT(RT_WAVES_EU_MF_SHADOW) k_shadow_mfma(const RenderParams P
     const int wv = (int)(threadIdx.x >> 6);
     f16x8 B[8];
     float ux[8], uy[8], uz[8];              // unit directions of the lane's 8 rays (0: no ray), for the bundle cone
-    double olo[3] = {INFINITY, INFINITY, INFINITY}, ohi[3] = {-INFINITY, -INFINITY, -INFINITY};   // box of the ray origins
+    float olo[3] = {INFINITY, INFINITY, INFINITY}, ohi[3] = {-INFINITY, -INFINITY, -INFINITY};   // box of the ray origins (for the guard proofs)
     // lane half h sets up the rays of blocks 4h .. 4h + 3 (hit record, FP64 direction to the light) and leaves them in
     // LDS; then every lane picks up column c of all 8 blocks
 #pragma unroll
@@ -1500,7 +1512,11 @@ __global__ void RT_HOT(RT_WAVES_EU_MF_SHADOW) k_shadow_mfma(const RenderParams P
             to_light(RT_TALK(P), Lt, H.px, H.py, H.pz, tx, ty, tz);
             const double o[3] = {H.px + 0.00001 * tx, H.py + 0.00001 * ty, H.pz + 0.00001 * tz};
 #pragma unroll
-            for (int k = 0; k < 3; ++k) { olo[k] = fmin(olo[k], o[k]); ohi[k] = fmax(ohi[k], o[k]); if (o[k] != o[k]) olo[k] = o[k]; }
+            for (int k = 0; k < 3; ++k) {
+                const float of = (float)o[k];
+                olo[k] = __builtin_fminf(olo[k], of); ohi[k] = __builtin_fmaxf(ohi[k], of);
+                if (of != of) olo[k] = of;                 // a NaN origin: nothing is certain
+            }
             dx = (float)(o[0] - Lt.px);
             dy = (float)(o[1] - Lt.py);
             dz = (float)(o[2] - Lt.pz);
@@ -1591,9 +1607,9 @@ __global__ void RT_HOT(RT_WAVES_EU_MF_SHADOW) k_shadow_mfma(const RenderParams P
         for (int k = 0; k < 3; ++k)
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) {
-                const double l2 = __shfl_xor(olo[k], o), h2 = __shfl_xor(ohi[k], o);
-                olo[k] = (l2 != l2 || olo[k] != olo[k]) ? (double)NAN : fmin(olo[k], l2);       // a NaN origin: nothing is certain
-                ohi[k] = fmax(ohi[k], h2);
+                const float l2 = __shfl_xor(olo[k], o), h2 = __shfl_xor(ohi[k], o);
+                olo[k] = (l2 != l2 || olo[k] != olo[k]) ? NAN : __builtin_fminf(olo[k], l2);     // a NaN origin: nothing is certain
+                ohi[k] = __builtin_fmaxf(ohi[k], h2);
             }
         passed = bundle_guard_mask(P, Lt, olo, ohi);
     }
