@@ -625,9 +625,12 @@ static GenRec make_gen_rec(const LeafD &L, const double omax[3]) {
     for (int i = 0; i < 3; ++i) { r.c[i] = (float)n[i]; r.c[4 + i] = (float)g1[i]; r.c[8 + i] = (float)g2[i]; }
     r.c[3] = (float)L.d; r.c[7] = (float)c1; r.c[11] = (float)c2;
     r.c[12] = f_down(-m);
-    // bounds of the FP32 error of a (for a unit direction) and of b: k_general's "behind the nearest hit so far" skip
-    r.c[13] = -f_down(-std::ldexp(An, -21));
-    r.c[14] = -f_down(-(std::ldexp(Bn, -21) + 1e-30));
+    // bounds of the FP32 error of a (for a unit direction) and of b: k_general's "behind the nearest hit so far" skip.
+    // a = n . u^: the coefficients are rounded (2^-24 each), so are the components of u^ (the direction as a float, times
+    // a rounded 1 / |d| that is itself 1 ulp off: 3 x 2^-24), and three fused steps add 3 x 2^-24 of the partial sums:
+    // < 8 x 2^-24 An = 2^-21 An in all; b likewise with 6 x 2^-24 Bn.  Twice that is stored.
+    r.c[13] = -f_down(-std::ldexp(An, -20));
+    r.c[14] = -f_down(-(std::ldexp(Bn, -20) + 1e-30));
     for (int i = 0; i < 15; ++i)
         if (!std::isfinite(r.c[i])) { GenRec a{}; a.c[12] = -1.0f; return a; }   // overflow: always pass, exact path decides
     return r;
