@@ -257,6 +257,23 @@ def test_reflection_off_normals_of_any_length(gpu_lib):
     sc.close()
 
 
+def test_whole_and_fractional_specular_exponents(gpu_lib):
+    """`x ** specularity` (Main.hs:483): k_final takes whole-number exponents by squaring and everything else through pow;
+    both against the oracle's libm pow, to the suite's bar (colours within 1 LSB, 99.9 % equal; in practice all equal)."""
+    from raytrace_amd.api import mconcat, rectangle, sphere, triangle, white, red, blue
+    shapes = []
+    for k, sp in enumerate((0.0, 0.5, 1.0, 2.5, 7.0, 33.3, 100.0, 400.0, 4096.0, 5000.0)):
+        m = (red if k % 2 else blue).replace(specular=(255, 255, 255), specularity=sp)
+        x = -4.5 + k
+        shapes.append(rectangle(m, (x, 0.0, -6.0 - 0.1 * k), (0.8, 0, 0.3), (0, 1.6, 0.2)))
+        shapes.append(triangle(m, (x - 0.4, -2.0, -5.0), (x + 0.4, -2.0, -5.5), (x, -1.0, -5.2)))
+    shapes.append(sphere(white.replace(specular=(255, 255, 255), specularity=12.5), (0.0, 2.2, -6.0), 0.8))
+    lights = api.mconcat_lights([api.pointLight(0.5, 0.9, (0.5, 1.0, -1.0)), api.pointLight(0.2, 0.7, (-3.0, -1.0, -2.0)), api.ambient(0.1)])
+    ref, hit, rgb = compare(mconcat(shapes), lights, 400, 240, label="specular-exponents")
+    assert (np.abs(rgb.astype(np.int16) - ref["rgb"].astype(np.int16)) <= 1).all()
+    assert (ref["rgb"].max(axis=2) > 200).sum() > 200             # (highlights are in the picture)
+
+
 def test_render_multi_equals_single_render(gpu_lib):
     """rt_render_multi on one device: 1, 3 and 5 bands of measured-cost rows, rendered in place and through the
     staging buffer + peer copy path, give the bytes of rt_render; statistics cover the whole frame."""
