@@ -5,7 +5,7 @@ set -e
 name=$1; shift
 cd "$(dirname "$0")/../raytrace_amd/csrc"
 mkdir -p ../lib/ab /tmp/abbuild
-/opt/rocm/bin/hipcc "$@" -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -Wall -Wno-unused-function -c -o /tmp/abbuild/$name.o rt_kernels.hip
+/opt/rocm/bin/hipcc -O3 "$@" -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -Wall -Wno-unused-function -c -o /tmp/abbuild/$name.o rt_kernels.hip
 scene=rt_scene.o
 if [ -n "$SCENE_FLAGS" ]; then
   g++ $SCENE_FLAGS -O2 -std=c++17 -fPIC -pthread -ffp-contract=off -Wall -c -o /tmp/abbuild/${name}_scene.o rt_scene.cpp

@@ -1,3 +1,5 @@
+# Round evidence on the GPU box (everything under profiles/r02_* except the rocprofv3 passes).  Build the timeline variant first,
+# here on the CPU: tools/build_variant.sh wt -DRT_WAVE_TIMES
 set -e
 O=gpurun_out/ev
 mkdir -p $O
