@@ -143,6 +143,7 @@ typedef struct { int kind; double diffuse, specular, f; v3 pos; } lightsrc; /* k
 
 struct orc_scene {
     int talk;      /* 1: the rules of src/Talk.hs (orc_scene_set_talk) */
+    int literal_mconcat; /* 1: orc_mconcat builds the right-nested mappend chain itself (orc_scene_set_literal_mconcat) */
     node *nodes; int nnodes, capnodes;
     orc_material *mats; int nmats, capmats;
     lightsrc *lights; int nlights, caplights;
@@ -189,6 +190,12 @@ int orc_scene_set_talk(orc_scene *s, int on) {
 /* Talk.hs:66-67: normalize v = scalar (recip (norm v)) v */
 static inline v3 normalize_talk(v3 v) { double rn = 1.0 / norm(v); return V(rn * v.x, rn * v.y, rn * v.z); }
 
+/* Test switch: every later orc_mconcat (also the ones inside orc_colorcuboid, orc_cylinder and
+ * orc_linear_interpolation_gaussian) becomes the literal chain x0 `mappend` (x1 `mappend` (... `mappend` mempty)) of
+ * N_APPEND nodes, evaluated by the plain mappend rule, instead of the list node with suffix boxes.  The two must render
+ * the same image (tests/test_oracle_known_answers.py): the list node is the oracle's one non-literal rewriting. */
+int orc_scene_set_literal_mconcat(orc_scene *s, int on) { s->literal_mconcat = on ? 1 : 0; return 0; }
+
 int orc_mempty(orc_scene *s) { return new_node(s, N_EMPTY); }                          /* :204 */
 
 int orc_mappend(orc_scene *s, int l, int r) {                                          /* :205-216 */
@@ -203,6 +210,11 @@ int orc_mappend(orc_scene *s, int l, int r) {                                   
  * node with the bounding box of every suffix, so that evaluation needs no deep recursion. */
 int orc_mconcat(orc_scene *s, const int *kids, int n) {
     for (int k = 0; k < n; ++k) if (kids[k] < 0 || kids[k] >= s->nnodes) return -1;
+    if (s->literal_mconcat) {       /* foldr mappend mempty, spelled out: Main.hs:196-217 with the Monoid default */
+        int acc = orc_mempty(s);
+        for (int k = n - 1; k >= 0; --k) acc = orc_mappend(s, kids[k], acc);
+        return acc;
+    }
     int i = new_node(s, N_LIST);
     node *nd = &s->nodes[i];
     nd->nkids = n;

@@ -50,6 +50,10 @@ void       orc_scene_free(orc_scene *);
  * intensity is passed as `diffuse`), no reflection (:255-258).  Rectangles only. */
 int orc_scene_set_talk(orc_scene *, int on);
 
+/* Test switch (before the first shape): orc_mconcat builds the literal right-nested chain of mappend nodes ending in
+ * mempty (foldr mappend mempty, Main.hs:196-217) instead of its list node with suffix boxes; same image either way. */
+int orc_scene_set_literal_mconcat(orc_scene *, int on);
+
 /* Shape constructors; every call returns a node handle (>= 0) or a negative error. */
 int orc_mempty(orc_scene *);                                                        /* Main.hs:204 */
 int orc_mappend(orc_scene *, int left, int right);                                  /* Main.hs:205-216 */

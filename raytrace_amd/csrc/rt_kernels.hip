@@ -1636,6 +1636,9 @@ __global__ void RT_HOT(RT_WAVES_EU_MF_SHADOW) k_shadow_mfma(const RenderParams P
         },
         [&](uint32_t entry) {                   // exact: intersect world ray_to_light, t <= distance (Main.hs:472-474)
             const int e = (int)(entry & 255u);
+#ifdef RT_X_SCANONLY      // measurement only (wrong pixels): what the kernel costs without its exact stage and without the early-out of occluded rays
+            s_own[wv][e] = (int)(entry >> 9); ++nexact; return;
+#endif
             const int kind = (int)((entry >> 8) & 1u), gid = (int)(entry >> 9);
             const LeafD &L = P.leaves[gid];
             const HitRec H = P.hitrec[s_pix[wv][e]];
@@ -1773,6 +1776,9 @@ __global__ void RT_HOT(RT_WAVES_EU_MF_PRIMARY) k_primary_mfma(const RenderParams
         },
         [&](uint32_t entry) {                   // exact: intersect leaf (cast camera x y), Main.hs:543
             const int e = (int)(entry & 255u);
+#ifdef RT_X_SCANONLY      // measurement only (wrong pixels): what the kernel costs without its exact stage
+            bid[e] = (int)(entry >> 9); ++nexact; return;
+#endif
             const int kind = (int)((entry >> 8) & 1u), gid = (int)(entry >> 9);
             const LeafD &L = P.leaves[gid];
             const RayD ray = camera_ray(P, x0 + ex(e), P.row0 + ly0 + ey(e));

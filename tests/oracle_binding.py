@@ -31,6 +31,7 @@ def lib():
         L.orc_scene_new.restype = C.c_void_p
         L.orc_scene_free.argtypes = [C.c_void_p]
         L.orc_scene_set_talk.argtypes = [C.c_void_p, C.c_int]
+        L.orc_scene_set_literal_mconcat.argtypes = [C.c_void_p, C.c_int]
         L.orc_mempty.argtypes = [C.c_void_p]
         L.orc_mappend.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.orc_mconcat.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_int]
@@ -72,10 +73,12 @@ def _m(m):
 
 
 class OracleScene:
-    def __init__(self, world, lights):
+    def __init__(self, world, lights, literal_mconcat=False):
         self.L = lib()
         self.h = C.c_void_p(self.L.orc_scene_new())
         self._callbacks = []
+        if literal_mconcat:      # every mconcat as the spelled-out chain of mappend nodes (Main.hs:196-217)
+            assert self.L.orc_scene_set_literal_mconcat(self.h, 1) == 0
         if isinstance(world, api.TalkDialect):        # src/Talk.hs rules
             assert self.L.orc_scene_set_talk(self.h, 1) == 0
             world = world.child

@@ -568,3 +568,15 @@ def test_host_render_copy_bands_and_page_locked_buffers(gpu_lib):
     sc.close()
     with pytest.raises(ValueError):
         api.Scene(*scenes.stacked_cubes()).render(64, 64, out_rgba=np.zeros((64, 64, 3), np.uint8))
+
+
+@pytest.mark.parametrize("name", sorted(__import__("known_answers").CASES))
+def test_hand_derived_pixel_on_the_gpu(gpu_lib, name):
+    """The closed-form pixels of tests/known_answers.py (derived from Main.hs by hand, no oracle involved) through the
+    C ABI: the one pin of the GPU path that does not go through the CPU restatement."""
+    import known_answers as ka
+    world, lights, w, h, (row0, nrows), _ = ka.CASES[name]()
+    sc = api.Scene(world, lights)
+    rgba, hit = sc.render(w, h, depth=4, row0=row0, nrows=nrows)
+    sc.close()
+    ka.check(name, hit, rgba, row0)

@@ -146,3 +146,52 @@ def test_talk_dialect_main2():
     r, g, b = (int(v) for v in o["rgb"][400, 128])
     assert r == 0 and g == 0 and 26 <= b <= 255
     assert set(np.unique(o["hit_id"])) <= {-1, 0, 1, 2, 3, 4, 5, 6}
+
+
+# ---- the oracle's one non-literal rewriting: mconcat as a list node with suffix boxes -----------------------------
+# Main.hs:196-217 defines only mempty and mappend; `mconcat xs` is the Monoid default foldr mappend mempty, i.e. the chain
+# x0 <> (x1 <> (... <> mempty)) whose every node guards with the union box of its suffix.  oracle.c evaluates a list node
+# instead (stop at the first failed suffix guard, strict < keeps the left child on ties) and the GPU's guard chains share
+# that reading.  Here every mconcat of every reference scene is built as the literal chain of mappend nodes and must
+# render the same hit IDs, distances and colours — including `intersection`, where guards clip rectangles.
+import pytest
+
+
+@pytest.mark.parametrize("name,wh,depth", [
+    ("default_scene", (96, 96), 4), ("planes", (80, 60), 4), ("axes", (64, 64), 4), ("cubes", (96, 54), 4),
+    ("stacked_cubes", (96, 96), 4), ("triangle_example", (90, 50), 4), ("spec_test", (64, 64), 4),
+    ("intersection", (128, 128), 4), ("cylinder_axes", (80, 64), 4), ("spheres", (96, 96), 4), ("mirror_room", (96, 72), 5),
+    ("adversarial", (96, 72), 4), ("viewport_plane", (64, 48), 4)])
+def test_literal_mappend_chain_renders_like_the_list_node(name, wh, depth):
+    world, lights = getattr(scenes, name)()
+    w, h = wh
+    a = ob.OracleScene(world, lights)
+    b = ob.OracleScene(world, lights, literal_mconcat=True)
+    assert a.num_leaves == b.num_leaves
+    ra = a.render(w, h, depth=depth, want_t=True)
+    rb = b.render(w, h, depth=depth, want_t=True)
+    assert np.array_equal(ra["hit_id"], rb["hit_id"])
+    assert np.array_equal(ra["t"], rb["t"])
+    assert np.array_equal(ra["rgb"], rb["rgb"])
+    if name == "intersection":      # the guards do clip here: the test is not vacuous
+        off = ob.OracleScene(world, lights).render(w, h, depth=depth, use_bbox=0)
+        assert (off["hit_id"] != ra["hit_id"]).any()
+
+
+def test_literal_chain_on_a_synthetic_scene_with_cuboids_and_cylinders():
+    for world, lights in (scenes.synthetic(ntri=300, ncuboid=30), scenes.synthetic_cylinders(ncyl=6, ncuboid=15)):
+        a = ob.OracleScene(world, lights)
+        b = ob.OracleScene(world, lights, literal_mconcat=True)
+        ra, rb = a.render(96, 54, want_t=True), b.render(96, 54, want_t=True)
+        assert np.array_equal(ra["hit_id"], rb["hit_id"]) and np.array_equal(ra["t"], rb["t"]) and np.array_equal(ra["rgb"], rb["rgb"])
+
+
+# ---- hand-derived pixels (closed form in tests/known_answers.py): they pin the oracle independently of its author's reading
+import known_answers as ka
+
+
+@pytest.mark.parametrize("name", sorted(ka.CASES))
+def test_hand_derived_pixel(name):
+    world, lights, w, h, (row0, nrows), _ = ka.CASES[name]()
+    r = ob.OracleScene(world, lights).render(w, h, depth=4, row0=row0, nrows=nrows)
+    ka.check(name, r["hit_id"], r["rgb"], row0)
