@@ -3,10 +3,11 @@
 // Not part of the product path.
 //
 // Method: W waves per SIMD (W = 1, 2, 4, 8; every CU gets W blocks of 256 threads = one wave per SIMD each) run a loop
-// of 8 independent copies of ONE instruction, 64 loops x 32 instructions; every wave stamps s_memtime (the shader clock,
-// MI355X_MICROARCH.md "s_memtime tick = shader cycle") and the 100 MHz wall clock around its loop.  Reported per
-// instruction and W: SIMD cycles per wave-instruction = (mean cycles of a wave's loop) / (W x instructions per wave):
-// with W waves sharing the SIMD's issue port the loop of each takes W times as long if the port is the limit.
+// of 8 independent copies of ONE instruction, 1024 loops x 32 instructions; every wave stamps s_memtime (the shader
+// clock, MI355X_MICROARCH.md "s_memtime tick = shader cycle") and the 100 MHz wall clock around its loop, which gives
+// the clock the chip really ran at; the launch is timed with HIP events.  Reported per instruction and W: SIMD cycles
+// per wave-instruction = launch time x clock / (W x instructions per wave) — the whole launch, so it does not matter
+// whether the W waves of a SIMD really were resident together.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -18,7 +19,7 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((__vector_size__(16 * sizeof(float)))) float f32x16;
 
-constexpr int LOOPS = 64, PER_LOOP = 32;
+constexpr int LOOPS = 1024, PER_LOOP = 32;   // (a wave runs for tens of microseconds: all W waves of a SIMD are resident together)
 
 struct Stamp { unsigned long long cyc, wall; };
 
@@ -66,7 +67,7 @@ __global__ void __launch_bounds__(256) name(Stamp *out, float seed) { \
 #define I_DIVFX(k)   asm volatile("v_div_fixup_f64 %0, %0, %1, %2" : "+v"(d[k]) : "v"(dx), "v"(dy));
 #define I_CVT_FD(k)  asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(a[k]) : "v"(d[k]));
 #define I_CVT_DF(k)  asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(d[k]) : "v"(a[k]));
-#define I_CNDM(k)    asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(n[k]) : "v"(ix) : "vcc");
+#define I_CNDM(k)    asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(n[k]) : "v"(ix));
 #define I_MOV(k)     asm volatile("v_mov_b32 %0, %1" : "=v"(n[k]) : "v"(ix));
 #define I_LSHLOR(k)  asm volatile("v_lshl_or_b32 %0, %0, 1, %1" : "+v"(n[k]) : "v"(ix));
 #define B_RFL { int t_[8]; asm volatile("v_readfirstlane_b32 %0, %8\nv_readfirstlane_b32 %1, %8\nv_readfirstlane_b32 %2, %8\nv_readfirstlane_b32 %3, %8\nv_readfirstlane_b32 %4, %8\nv_readfirstlane_b32 %5, %8\nv_readfirstlane_b32 %6, %8\nv_readfirstlane_b32 %7, %8" : "=s"(t_[0]), "=s"(t_[1]), "=s"(t_[2]), "=s"(t_[3]), "=s"(t_[4]), "=s"(t_[5]), "=s"(t_[6]), "=s"(t_[7]) : "v"(n[0])); for (int k = 0; k < 8; ++k) sm[k] = (unsigned)t_[k]; }
@@ -172,8 +173,9 @@ int main() {
     hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
     const int cus = prop.multiProcessorCount;
     printf("# device %s, %d CUs; %d loops x %d instructions per wave; cycles = s_memtime, wall = 100 MHz wall_clock64\n", prop.name, cus, LOOPS, PER_LOOP);
-    printf("# SIMD cycles per wave64 instruction = mean cycles of a wave's loop / (W x instructions per wave), W = waves per SIMD\n");
-    printf("%-26s %-8s %8s %8s %8s %8s   %s\n", "instruction", "class", "W=1", "W=2", "W=4", "W=8", "clock GHz (W=4)");
+    printf("# SIMD cycles per wave64 instruction at W waves per SIMD = launch time (HIP events) x shader clock / (W x instructions per wave);\n");
+    printf("# shader clock = s_memtime ticks / wall-clock time of the waves' loops; 'alone' = one wave's own loop, cycles per instruction\n");
+    printf("%-26s %-8s %8s %8s %8s %8s %8s   %s\n", "instruction", "class", "alone", "W=1", "W=2", "W=4", "W=8", "clock GHz (W=4)");
     const int N = LOOPS * PER_LOOP;
     const Test tests[] = {
         {"v_fma_f32", k_fma32, N, "fp32"}, {"v_pk_fma_f32", k_pkfma, N, "fp32"}, {"v_add_f32", k_add32, N, "fp32"},
@@ -192,22 +194,30 @@ int main() {
     };
     Stamp *out; CK(hipMalloc(&out, sizeof(Stamp) * cus * 8 * 4));
     std::vector<Stamp> h((size_t)cus * 8 * 4);
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (const Test &t : tests) {
-        double res[4] = {0, 0, 0, 0}, ghz = 0;
+        double res[4] = {0, 0, 0, 0}, solo = 0, ghz = 0;
         for (int wi = 0; wi < 4; ++wi) {
             const int W = 1 << wi, blocks = cus * W;
+            float ms = 0;
             for (int rep = 0; rep < 3; ++rep) {     // the last repetition counts (clocks ramped, code cached)
+                CK(hipEventRecord(e0));
                 hipLaunchKernelGGL(t.fn, dim3(blocks), dim3(256), 0, 0, out, 0.999f);
+                CK(hipEventRecord(e1));
                 CK(hipDeviceSynchronize());
+                CK(hipEventElapsedTime(&ms, e0, e1));
             }
             CK(hipMemcpy(h.data(), out, sizeof(Stamp) * blocks * 4, hipMemcpyDeviceToHost));
             double cyc = 0, wall = 0;
             for (int k = 0; k < blocks * 4; ++k) { cyc += (double)h[k].cyc; wall += (double)h[k].wall; }
             cyc /= blocks * 4; wall /= blocks * 4;
-            res[wi] = cyc / ((double)W * t.per_wave);
-            if (W == 4) ghz = cyc / (wall * 10.0) ;     // cycles per 10 ns -> GHz
+            const double clock = cyc / (wall * 10.0);                 // shader cycles per ns while the loop ran
+            // the whole launch: every SIMD issued W x per_wave instructions in (launch time x clock) cycles
+            res[wi] = (double)ms * 1e6 * clock / ((double)W * t.per_wave);
+            if (W == 1) solo = cyc / t.per_wave;
+            if (W == 4) ghz = clock;
         }
-        printf("%-26s %-8s %8.2f %8.2f %8.2f %8.2f   %.2f\n", t.name, t.cls, res[0], res[1], res[2], res[3], ghz);
+        printf("%-26s %-8s %8.2f %8.2f %8.2f %8.2f %8.2f   %.2f\n", t.name, t.cls, solo, res[0], res[1], res[2], res[3], ghz);
     }
     printf("# rows 'mfma + F v_max3_i32': cycles per (MFMA + F vector instructions) step\n");
     return 0;
