@@ -136,7 +136,6 @@ def main():
                     help="first stage: bounding cones on the matrix cores (the product) or the FP32 vector-ALU kernels of the cross-check build")
     ap.add_argument("--no-extra-legs", action="store_true", help="profiling runs: only the timed steps (no brute-force, rt_render or 16K legs)")
     ap.add_argument("--no-cull", action="store_true", help="every wave scans every block of the leaf stream: the plain all-pairs scan")
-    ap.add_argument("--no-split", action="store_true", help="nearest hit of the camera rays in ONE kernel (scan + exact stage fused) instead of scan kernel -> candidate lists -> exact kernel")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the measured path) or gloo (rehearsal on one GPU)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank renders on GPU 0 (gloo only)")
     ap.add_argument("--pieces", type=int, default=0, help="N > 1: pieces per band (0 = from the band's render time, about 1 ms each, at most 4)")
@@ -191,8 +190,6 @@ def main():
         scene.set_option(_lib.RT_OPT_FILTER, 1)
     if args.no_cull:
         scene.set_option(_lib.RT_OPT_CULL, 0)
-    if args.no_split:
-        scene.set_option(_lib.RT_OPT_SPLIT, 0)
     if ntri is None:
         kinds = [scene.leaf(i)[0] for i in range(scene.num_leaves)]
         ntri, nrect = kinds.count(1.0), kinds.count(0.0)

@@ -107,12 +107,8 @@ int  rt_scene_set_dialect(rt_scene *, int dialect);
  *   RT_OPT_HOST_BANDS  copy bands of rt_render, 1..8 (0 = default: one per 4 Mi pixels; a band's hit IDs travel to the
  *                      host as soon as its nearest-hit kernel has ended, its colours beside the next band's kernels).
  *   RT_OPT_MULTI_STAGE 1: rt_render_multi sends the bands of devices[0] through a staging buffer and a peer copy too,
- *                      like those of the other devices (default 0: they are rendered in place; tests use 1).
- *   RT_OPT_SPLIT       1 (default): the nearest hit of the camera rays is found by two kernels — one scans and filters and
- *                      leaves the surviving (ray, leaf) pairs in per-tile lists in HBM (16 KiB of room per 32 x 8 pixels),
- *                      one evaluates them exactly; a tile whose list overflows falls back to 0: one kernel does both
- *                      (what rt_render_device_noalloc always uses).  Same pixels either way. */
-enum { RT_OPT_CULL = 0, RT_OPT_FILTER = 1, RT_OPT_HOST_BANDS = 2, RT_OPT_MULTI_STAGE = 3, RT_OPT_SPLIT = 4 };
+ *                      like those of the other devices (default 0: they are rendered in place; tests use 1). */
+enum { RT_OPT_CULL = 0, RT_OPT_FILTER = 1, RT_OPT_HOST_BANDS = 2, RT_OPT_MULTI_STAGE = 3 };
 int  rt_scene_set_option(rt_scene *, int option, int value);
 
 /* ---- scene construction (replaces the closure-building constructors) -------------------- */

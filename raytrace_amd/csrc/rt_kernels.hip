@@ -72,8 +72,7 @@ typedef const int32_t RT_CONST *CIntPtr;
 
 namespace {
 
-struct PosRec;
-struct NrmRec;
+struct HitRec;
 struct RenderParams {
     const LeafD *leaves;
     const AuxD *aux;
@@ -95,13 +94,7 @@ struct RenderParams {
     int32_t *hit_id;                // band-local output, indexed out_off + pix
     uint8_t *rgba;                  // band-local output (spp == 1) or nullptr
     uint32_t *accum;                // band-local 3 x u32 sums (spp > 1) or nullptr
-    PosRec *hitpos;                 // per chunk slot: exact hit point, its leaf and material (k_primary_exact at level 0, else k_setup)
-    NrmRec *hitnrm;                 // per chunk slot: shading normal (k_setup)
-    // the split nearest-hit pass of level 0 (k_primary_scan -> k_primary_exact): per 32 x 8 pixel tile a list of the (ray,
-    // leaf) pairs that passed the filters, RT_CAND_CAP entries of room, and their number (RT_CAND_OVERFLOW: the tile did not
-    // fit and is done by the one-kernel form k_primary_mfma instead); nullptr: k_primary_mfma does every tile
-    uint32_t *cand;
-    unsigned *cand_count;
+    HitRec *hitrec;                 // per chunk pixel: exact hit point and shading normal
     uint32_t *queue;                // npoint blocks of qcap shadow jobs (chunk pixel indices)
     unsigned *qcount;               // shadow jobs per point light
     uint32_t *qsparse;              // k_setup's output: per light, RT_SETUP_THREADS slots per block, the block's jobs first
@@ -153,12 +146,7 @@ struct RenderParams {
     long long lit_stride;           // slots per group of 32 point lights in `lit`
 };
 
-struct HitRec { double px, py, pz, nx, ny, nz; };      // (in registers)
-struct PosRec { double x, y, z; int32_t id, mat; };    // 32 bytes: one sector per gather
-struct NrmRec { double x, y, z; };
-// entries of room per tile in RenderParams::cand (the benchmark frame's fullest tile holds 2 528), and the count that marks a
-// tile that needed more
-constexpr unsigned RT_CAND_CAP = 4096u, RT_CAND_OVERFLOW = 0xffffffffu;
+struct HitRec { double px, py, pz, nx, ny, nz; };
 
 // ------------------------------------------------------------------------------------------
 // Exact path (IEEE double, reference expression order)
@@ -196,18 +184,11 @@ __device__ __forceinline__ void sample_offset(const RenderParams &P, int x, int 
     } else { ox = u1 - 0.5; oy = u2 - 0.5; }
 }
 
-// SPP1: the kernel was launched for spp == 1 (the reference's one ray through the integer pixel coordinate): no offset code
-template <bool SPP1>
-__device__ __forceinline__ void sample_offset_t(const RenderParams &P, int x, int y, double &ox, double &oy) {
-    if (SPP1) { ox = 0; oy = 0; return; }
-    sample_offset(P, x, y, ox, oy);
-}
-
 // cast camera x y — Main.hs:528-533
-template <bool MAY_TALK = true, bool SPP1 = false>
+template <bool MAY_TALK = true>
 __device__ __forceinline__ RayD camera_ray(const RenderParams &P, int x, int y) {
     double ox, oy;
-    sample_offset_t<SPP1>(P, x, y, ox, oy);
+    sample_offset(P, x, y, ox, oy);
     const double posX = P.cam.scaleX * ((double)x + ox) + P.cam.dX;
     const double posY = P.cam.scaleY * ((double)y + oy) + P.cam.dY;
     const double n = sqrt(posX * posX + posY * posY + P.cam.d * P.cam.d);
@@ -344,34 +325,6 @@ __device__ __forceinline__ bool leaf_isect(const LeafD &L, const RayD &r, double
         const double ss = (L.c0 * wu - L.c1 * wv) / L.c3;                              // :380
         return rr >= 0 && ss >= 0 && rr + ss <= 1;                                     // :382
     }
-}
-
-// The same for a planar leaf whose kind is a per-lane value: planeRayIsect (Main.hs:252-277) is the same arithmetic for a
-// rectangle and a triangle, so a wave that holds both kinds runs it ONCE and only the inside tests diverge (as two
-// template instances the whole function ran twice for such a wave: 4 of its 4 to 6 divisions).
-__device__ __forceinline__ bool planar_isect(const LeafD &L, int kind, const RayD &r, double &ix, double &iy, double &iz, double &t, bool talk) {
-    const double a = L.nx, b = L.ny, c = L.nz;
-    const double frac = (a * r.dx + b * r.dy + c * r.dz) / r.dz;                       // Main.hs:269
-    const double z = (-L.d - a * r.px - b * r.py + (frac - c) * r.pz) / frac;          // :270
-    const double x = (r.dx * (z - r.pz) / r.dz) + r.px;                                // :271
-    const double y = (r.dy * (z - r.pz) / r.dz) + r.py;                                // :272
-    bool ok = !(fabs(frac) <= 0.00001);                                                // :273
-    if (talk) {                       // Talk.hs:121-122: ray_direction *@ (i - ray_position) >= 0; key = squared distance, :192-193
-        const double vx = x - r.px, vy = y - r.py, vz = z - r.pz;
-        ok = ok && (r.dx * vx + r.dy * vy + r.dz * vz >= 0);
-        t = vx * vx + vy * vy + vz * vz;
-    } else {
-        t = (z - r.pz) * r.rz;                                                         // :256, 122-126
-        ok = ok && (t >= 0);                                                           // :257
-    }
-    ix = x; iy = y; iz = z;
-    const double wx = x - L.p0x, wy = y - L.p0y, wz = z - L.p0z;
-    const double w1 = wx * L.e1x + wy * L.e1y + wz * L.e1z;                            // rect dw :239, tri wu :378
-    const double w2 = wx * L.e2x + wy * L.e2y + wz * L.e2z;                            // rect dh :240, tri wv :377
-    if (kind == LEAF_RECT) return ok && 0 <= w1 && w1 <= L.c0 && 0 <= w2 && w2 <= L.c1;   // :241
-    const double rr = (L.c0 * w2 - L.c2 * w1) / L.c3;                                  // :379
-    const double ss = (L.c0 * w1 - L.c1 * w2) / L.c3;                                  // :380
-    return ok && rr >= 0 && ss >= 0 && rr + ss <= 1;                                   // :382
 }
 
 // intersectBB — Main.hs:152-174 — for every mappend node above the leaf (Main.hs:209).
@@ -746,7 +699,6 @@ __global__ void __launch_bounds__(RT_SETUP_THREADS) k_setup(const RenderParams P
     // wave of k_shadow_mfma) leave from neighbouring pixels and form a narrow bundle; bounce levels: slots in order
     int pix = (int)(blockIdx.x * RT_SETUP_THREADS + threadIdx.x);
     bool act = (unsigned)pix < num_slots(P);
-    bool have_pos = false;          // (wave-uniform) k_primary_exact left the hit points of this wave's pixels in hitpos
     if (!P.rays) {
         // a wave takes 8 x 8 pixels of the tile (objects are blobs: fewer waves straddle an outline than with 32 x 2 strips)
         const int tx = (int)blockIdx.x % P.tiles_x, ty = (int)blockIdx.x / P.tiles_x;
@@ -754,27 +706,20 @@ __global__ void __launch_bounds__(RT_SETUP_THREADS) k_setup(const RenderParams P
         const int x = tx * 32 + (wq & 3) * 8 + (lq & 7), y = ty * (RT_SETUP_THREADS / 32) + (wq >> 2) * 8 + (lq >> 3);
         act = x < P.w && y < P.nrows;
         pix = act ? y * P.w + x : 0;
-        const int pty = ty * (RT_SETUP_THREADS / 32 / RT_TILE_H) + (wq >> 2);      // the nearest-hit pass's 32 x 8 tile of this wave
-        if (P.cand_count && pty < P.tiles_y) have_pos = P.cand_count[(size_t)pty * (size_t)P.tiles_x + tx] != RT_CAND_OVERFLOW;
     }
     const int id = act ? P.hit_id[P.out_off + pix] : -1;
     HitRec H = {0, 0, 0, 0, 0, 0};
+    RayD ray = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     int mat = 0;
     if (id >= 0) {
-        const LeafD &L = P.leaves[id];
+        const LeafD L = P.leaves[id];
+        ray = slot_ray(P, pix);
+        mat = L.mat;
         double ix = 0, iy = 0, iz = 0, t;
-        if (have_pos) {             // the exact stage of the nearest-hit pass computed the point: moved, not re-derived
-            const PosRec R = P.hitpos[pix];
-            ix = R.x; iy = R.y; iz = R.z; mat = R.mat;
-        } else {
-            const RayD ray = slot_ray(P, pix);
-            mat = L.mat;
-            // only the hit point is wanted, and planeRayIsect (Main.hs:264-277) finds it the same way for a triangle as for a
-            // rectangle: one pass for a wave that holds both
-            if (L.kind != LEAF_SPHERE) leaf_isect<LEAF_RECT>(L, ray, ix, iy, iz, t, RT_TALK(P));
-            else leaf_isect<LEAF_SPHERE>(L, ray, ix, iy, iz, t, RT_TALK(P));
-            P.hitpos[pix] = PosRec{ix, iy, iz, id, mat};
-        }
+        // only the hit point is wanted, and planeRayIsect (Main.hs:264-277) finds it the same way for a triangle as for a
+        // rectangle: one pass for a wave that holds both
+        if (L.kind != LEAF_SPHERE) leaf_isect<LEAF_RECT>(L, ray, ix, iy, iz, t, RT_TALK(P));
+        else leaf_isect<LEAF_SPHERE>(L, ray, ix, iy, iz, t, RT_TALK(P));
         double nx = L.nx, ny = L.ny, nz = L.nz;
         if (L.kind == LEAF_SPHERE) {                                                   // scalar (recip radius) (isect - center), :410
             const double rr = 1.0 / L.c0;
@@ -805,7 +750,7 @@ __global__ void __launch_bounds__(RT_SETUP_THREADS) k_setup(const RenderParams P
             nx = sg * ux; ny = sg * uy; nz = sg * uz;
         }
         H.px = ix; H.py = iy; H.pz = iz; H.nx = nx; H.ny = ny; H.nz = nz;
-        P.hitnrm[pix] = NrmRec{nx, ny, nz};
+        P.hitrec[pix] = H;
     }
     if (act) P.lit_w[pix] = 0u;
     const int lane = (int)(threadIdx.x & 63), wv = (int)(threadIdx.x >> 6);
@@ -826,7 +771,6 @@ __global__ void __launch_bounds__(RT_SETUP_THREADS) k_setup(const RenderParams P
                 need = (round8(fd * (double)M.diffuse[0]) | round8(fd * (double)M.diffuse[1]) | round8(fd * (double)M.diffuse[2])) != 0;
                 if (!need && !RT_TALK(P) && (M.specular[0] | M.specular[1] | M.specular[2]) != 0) {
                     int r, g, b;
-                    const RayD ray = slot_ray(P, pix);
                     light_terms(P, Lt, M, H, ray, r, g, b);
                     need = (r | g | b) != 0;
                 }
@@ -961,10 +905,10 @@ __device__ __forceinline__ void shadow_loop(const RenderParams &P, CRecPtr recs,
                     if (cand[r] & (own[r] != gid)) {
                         uint32_t pr = pix[r];
                         asm volatile("" : "+v"(pr));   // keep the exact-path ray set-up inside this rare branch
-                        const PosRec H = P.hitpos[pr];
+                        const HitRec H = P.hitrec[pr];
                         double tx, ty, tz;
-                        to_light(false, Lt, H.x, H.y, H.z, tx, ty, tz);
-                        const RayD ray = mkray(H.x + 0.00001 * tx, H.y + 0.00001 * ty, H.z + 0.00001 * tz,
+                        to_light(false, Lt, H.px, H.py, H.pz, tx, ty, tz);
+                        const RayD ray = mkray(H.px + 0.00001 * tx, H.py + 0.00001 * ty, H.pz + 0.00001 * tz,
                                                tx, ty, tz, P.eps);                     // Main.hs:472
                         double ix, iy, iz, t;
                         ++nexact;
@@ -1012,10 +956,10 @@ __device__ __forceinline__ void shadow_sphere_loop(const RenderParams &P, CRecPt
                 if ((z[r] >= cur.c[9]) & need[r]) {
                     uint32_t pr = pix[r];
                     asm volatile("" : "+v"(pr));
-                    const PosRec H = P.hitpos[pr];
+                    const HitRec H = P.hitrec[pr];
                     double tx, ty, tz;
-                    to_light(false, Lt, H.x, H.y, H.z, tx, ty, tz);
-                    const RayD ray = mkray(H.x + 0.00001 * tx, H.y + 0.00001 * ty, H.z + 0.00001 * tz, tx, ty, tz, P.eps);
+                    to_light(false, Lt, H.px, H.py, H.pz, tx, ty, tz);
+                    const RayD ray = mkray(H.px + 0.00001 * tx, H.py + 0.00001 * ty, H.pz + 0.00001 * tz, tx, ty, tz, P.eps);
                     double ix, iy, iz, t;
                     ++nexact;
                     if (leaf_isect<LEAF_SPHERE>(L, ray, ix, iy, iz, t, false) && guards_ok<false>(P.guards, L.guard, ray)) {
@@ -1046,16 +990,15 @@ __global__ void RT_HOT(RT_WAVES_EU_SHADOW) k_shadow(const RenderParams P) {
         const unsigned j = wave * 256u + (unsigned)(r * 64 + lane);
         need[r] = j < count;
         pix[r] = need[r] ? q[j] : 0u;
-        own[r] = -1;
+        own[r] = need[r] ? P.hit_id[P.out_off + pix[r]] : -1;
         ddx[r] = ddy[r] = ddz[r] = 0.f;
         if (need[r]) {
-            const PosRec H = P.hitpos[pix[r]];
-            own[r] = H.id;
+            const HitRec H = P.hitrec[pix[r]];
             double tx, ty, tz;
-            to_light(false, Lt, H.x, H.y, H.z, tx, ty, tz);
-            ddx[r] = (float)((H.x + 0.00001 * tx) - Lt.px);
-            ddy[r] = (float)((H.y + 0.00001 * ty) - Lt.py);
-            ddz[r] = (float)((H.z + 0.00001 * tz) - Lt.pz);
+            to_light(false, Lt, H.px, H.py, H.pz, tx, ty, tz);
+            ddx[r] = (float)((H.px + 0.00001 * tx) - Lt.px);
+            ddy[r] = (float)((H.py + 0.00001 * ty) - Lt.py);
+            ddz[r] = (float)((H.pz + 0.00001 * tz) - Lt.pz);
         }
     }
     Dir4 D;
@@ -1562,14 +1505,12 @@ __global__ void RT_HOT(RT_WAVES_EU_MF_SHADOW) k_shadow_mfma(const RenderParams P
         const bool ok = j < count;
         float dx = 0.f, dy = 0.f, dz = 0.f;
         uint32_t pix = 0u;
-        int own = -1;
         if (ok) {
             pix = q[j];
-            const PosRec H = P.hitpos[pix];         // one 32-byte sector: the hit point and the leaf the ray starts on
-            own = H.id;
+            const HitRec H = P.hitrec[pix];
             double tx, ty, tz;
-            to_light(RT_TALK(P), Lt, H.x, H.y, H.z, tx, ty, tz);
-            const double o[3] = {H.x + 0.00001 * tx, H.y + 0.00001 * ty, H.z + 0.00001 * tz};
+            to_light(RT_TALK(P), Lt, H.px, H.py, H.pz, tx, ty, tz);
+            const double o[3] = {H.px + 0.00001 * tx, H.py + 0.00001 * ty, H.pz + 0.00001 * tz};
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 const float of = (float)o[k];
@@ -1583,7 +1524,7 @@ __global__ void RT_HOT(RT_WAVES_EU_MF_SHADOW) k_shadow_mfma(const RenderParams P
         const int e = b * 32 + c;
         s_d[wv][0][e] = dx; s_d[wv][1][e] = dy; s_d[wv][2][e] = dz;
         s_pix[wv][e] = pix;
-        s_own[wv][e] = own;
+        s_own[wv][e] = ok ? P.hit_id[P.out_off + pix] : -1;
         s_occ[wv][e] = ok ? 0u : 1u;          // a ray that does not exist counts as occluded: never lit
     }
     __builtin_amdgcn_wave_barrier();
@@ -1700,13 +1641,13 @@ __global__ void RT_HOT(RT_WAVES_EU_MF_SHADOW) k_shadow_mfma(const RenderParams P
 #endif
             const int kind = (int)((entry >> 8) & 1u), gid = (int)(entry >> 9);
             const LeafD &L = P.leaves[gid];
-            const PosRec H = P.hitpos[s_pix[wv][e]];
+            const HitRec H = P.hitrec[s_pix[wv][e]];
             double tx, ty, tz;
-            to_light(RT_TALK(P), Lt, H.x, H.y, H.z, tx, ty, tz);
-            const RayD ray = mkray(H.x + 0.00001 * tx, H.y + 0.00001 * ty, H.z + 0.00001 * tz, tx, ty, tz, P.eps);   // Main.hs:472
+            to_light(RT_TALK(P), Lt, H.px, H.py, H.pz, tx, ty, tz);
+            const RayD ray = mkray(H.px + 0.00001 * tx, H.py + 0.00001 * ty, H.pz + 0.00001 * tz, tx, ty, tz, P.eps);   // Main.hs:472
             double ix, iy, iz, tt;
             ++nexact;
-            const bool hit = planar_isect(L, kind, ray, ix, iy, iz, tt, RT_TALK(P));
+            const bool hit = kind == LEAF_TRI ? leaf_isect<LEAF_TRI>(L, ray, ix, iy, iz, tt, RT_TALK(P)) : leaf_isect<LEAF_RECT>(L, ray, ix, iy, iz, tt, RT_TALK(P));
             if (hit && guards_ok(P.guards, L.guard, ray, passed)) {
                 const double tl = (Lt.pz - ray.pz) * ray.rz;                       // rayDistance ray lpos
                 const bool occ = RT_TALK(P) ? ((Lt.px - ix) * tx + (Lt.py - iy) * ty + (Lt.pz - iz) * tz >= 0)   // Talk.hs:242
@@ -1755,85 +1696,10 @@ __global__ void RT_HOT(RT_WAVES_EU_MF_SHADOW) k_shadow_mfma(const RenderParams P
 // Kernel 1 on the matrix cores.  One wave = 32 x 8 pixel tile; ray block b = tile row b, column c = lane & 31.
 // The nearest hit of every pixel of the tile lives in LDS: t as the bit pattern of the double (t >= 0, so the
 // patterns order like the values) and the leaf index.
-//
-// Two forms.  ONE kernel (k_primary_mfma, MODE 0): block test, matrix-core scan, FP32 record test and the exact FP64
-// stage with the guard chains in one wave.  TWO kernels (the default at level 0 when the work buffers hold the lists):
-// k_primary_scan (MODE 1) does everything up to the record test and writes the surviving (ray, leaf) pairs to the
-// tile's list in HBM; k_primary_exact evaluates them 64 at a time with a register budget of its own.  The exact stage
-// with its guard walk needs about 90 registers of its own, the scan 110: together they spilled into the scan loop
-// (DESIGN.md section 3).  A tile with more than RT_CAND_CAP pairs is marked and done by the one-kernel form afterwards.
-
-// Ray e = 32 b + c of the wave is the pixel (ex(e), ey(e)) of the tile: ray block b is an 8 x 4 patch (four patches side
-// by side, two rows of them), not a 32 x 1 strip — a leaf covers a blob of pixels, a blob touches fewer patches than
-// strips, and only ray blocks with a candidate get their MFMA re-issued and their 16 registers compared.
-__device__ __forceinline__ int tile_ex(int e) { return ((e >> 5) & 3) * 8 + (e & 7); }
-__device__ __forceinline__ int tile_ey(int e) { return (e >> 7) * 4 + ((e >> 3) & 3); }
-
-// Nearest wins; equal t -> the left-most leaf of the tree (Main.hs:213-214).  Several lanes may hold hits of the same
-// pixel: the wave runs in lockstep and its LDS operations complete in order, so (1) all read the old t, (2) all fold
-// their t in with an atomic min, (3) the lanes whose t is the new minimum reset the leaf index if the minimum moved,
-// (4) and fold their leaf index in with an atomic min.  Returns: this lane's pair is the pixel's nearest hit so far.
-// t = -0.0 passes `t >= 0` (a leaf in the viewport plane) and must order as 0, not as the largest pattern.
-__device__ __forceinline__ bool fold_nearest(unsigned long long *bt, int *bid, int e, bool hit, double tt, int gid) {
-    const unsigned long long tb = (unsigned long long)__double_as_longlong(tt + 0.0);
-    unsigned long long old = 0;
-    if (hit) { old = bt[e]; atomicMin(&bt[e], tb); }
-    __builtin_amdgcn_wave_barrier();
-    const bool win = hit && bt[e] == tb;
-    if (win && tb < old) bid[e] = 0x7fffffff;
-    __builtin_amdgcn_wave_barrier();
-    if (win) atomicMin(&bid[e], gid);
-    __builtin_amdgcn_wave_barrier();
-    return win && bid[e] == gid;
-}
-
-// spheres seen from the eye for the lane's four pixels (few per scene: scalar-record loop, then the exact test)
-template <bool SPP1, class POS>
-__device__ __forceinline__ void primary_spheres(const RenderParams &P, const int (&px)[4], const int (&py)[4], const bool (&act)[4],
-                                                double (&mt)[4], int (&mid)[4], unsigned &nexact, POS &&on_win) {
-    const float dzf = (float)P.cam.d;
-    Dir4 D; f2 dd[2];
-    float dx[4], dy[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        double ox, oy;
-        sample_offset_t<SPP1>(P, px[r], P.row0 + py[r], ox, oy);
-        dx[r] = (float)(P.cam.scaleX * ((double)px[r] + ox) + P.cam.dX);
-        dy[r] = (float)(P.cam.scaleY * ((double)(P.row0 + py[r]) + oy) + P.cam.dY);
-    }
-#pragma unroll
-    for (int p = 0; p < 2; ++p) { D.x[p] = f2{dx[2 * p], dx[2 * p + 1]}; D.y[p] = f2{dy[2 * p], dy[2 * p + 1]}; D.z[p] = f2{dzf, dzf}; }
-    dir_norms(D, dd);
-    CRecPtr recs = as_const(P.sph_rec);
-    CIntPtr gids = as_const(P.sph_gid);
-    for (int i = 0; i < P.nsph; ++i) {
-        const FilterRec cur = load_rec(recs + i);
-        float z[4];
-        if (filter4_sphere(cur, D, dd, z)) {
-            const int gid = gids[i];
-            const LeafD &L = P.leaves[gid];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if ((z[r] >= cur.c[9]) & act[r]) {
-                    int yr = P.row0 + py[r];
-                    asm volatile("" : "+v"(yr));
-                    const RayD ray = camera_ray<true, SPP1>(P, px[r], yr);
-                    double ix, iy, iz, tt;
-                    ++nexact;
-                    if (leaf_isect<LEAF_SPHERE>(L, ray, ix, iy, iz, tt, RT_TALK(P)) && guards_ok(P.guards, L.guard, ray)) {
-                        if (tt < mt[r] || (tt == mt[r] && gid < mid[r]) || mid[r] < 0) { mt[r] = tt; mid[r] = gid; on_win(r, ix, iy, iz); }
-                    }
-                }
-            }
-        }
-    }
-}
-
-template <int MODE, bool SPP1>
-__device__ __forceinline__ void primary_tile(const RenderParams &P) {
+__global__ void RT_HOT(RT_WAVES_EU_MF_PRIMARY) k_primary_mfma(const RenderParams P) {
     RT_WAVE_T0
-    __shared__ unsigned long long s_bt[MODE == 0 ? RT_WAVES_PER_BLOCK * 256 : 1];
-    __shared__ int s_bid[MODE == 0 ? RT_WAVES_PER_BLOCK * 256 : 1];
+    __shared__ unsigned long long s_bt[RT_WAVES_PER_BLOCK][256];
+    __shared__ int s_bid[RT_WAVES_PER_BLOCK][256];
     __shared__ uint16_t s_q1[RT_WAVES_PER_BLOCK][RT_Q1_CAP];
     __shared__ uint32_t s_q2[RT_WAVES_PER_BLOCK][RT_Q2_CAP];
     __shared__ uint16_t s_list[RT_WAVES_PER_BLOCK][RT_LIST_CAP + 8];
@@ -1844,13 +1710,15 @@ __device__ __forceinline__ void primary_tile(const RenderParams &P) {
     const int lane = (int)(threadIdx.x & 63), c = lane & 31, h = lane >> 5;
     const int tx = wave % P.tiles_x, ty = wave / P.tiles_x;
     if (ty >= P.tiles_y) return;
-    if (MODE == 0 && P.cand_count && P.cand_count[wave] != RT_CAND_OVERFLOW) return;     // (the tile went through the two-kernel form)
     const int x0 = tx * RT_TILE_W;
     const int ly0 = ty * RT_TILE_H;
-    auto ex = [](int e) { return tile_ex(e); };
-    auto ey = [](int e) { return tile_ey(e); };
-    unsigned long long *bt = s_bt + (MODE == 0 ? wv * 256 : 0);
-    int *bid = s_bid + (MODE == 0 ? wv * 256 : 0);
+    // Ray e = 32 b + c of the wave is the pixel (ex(e), ey(e)) of the tile: ray block b is an 8 x 4 patch (four patches side
+    // by side, two rows of them), not a 32 x 1 strip — a leaf covers a blob of pixels, a blob touches fewer patches than
+    // strips, and only ray blocks with a candidate get their MFMA re-issued and their 16 registers compared.
+    auto ex = [](int e) { return ((e >> 5) & 3) * 8 + (e & 7); };
+    auto ey = [](int e) { return (e >> 7) * 4 + ((e >> 3) & 3); };
+    unsigned long long *bt = s_bt[wv];
+    int *bid = s_bid[wv];
     f16x8 B[8];
     const float dzf = (float)P.cam.d;
 #pragma unroll
@@ -1858,11 +1726,11 @@ __device__ __forceinline__ void primary_tile(const RenderParams &P) {
         const int x = x0 + ex(b * 32 + c), ly = ly0 + ey(b * 32 + c);
         const bool ok = x < P.w && ly < P.nrows;
         double ox, oy;
-        sample_offset_t<SPP1>(P, x, P.row0 + ly, ox, oy);
+        sample_offset(P, x, P.row0 + ly, ox, oy);
         const float dx = (float)(P.cam.scaleX * ((double)x + ox) + P.cam.dX);
         const float dy = (float)(P.cam.scaleY * ((double)(P.row0 + ly) + oy) + P.cam.dY);
         B[b] = ray_fragment(dx, dy, dzf, ok, h);
-        if (MODE == 0 && h == 0) { bt[b * 32 + c] = ~0ull; bid[b * 32 + c] = -1; }
+        if (h == 0) { bt[b * 32 + c] = ~0ull; bid[b * 32 + c] = -1; }
     }
     __builtin_amdgcn_wave_barrier();
     RT_WAVE_PHASE(0)
@@ -1885,11 +1753,9 @@ __device__ __forceinline__ void primary_tile(const RenderParams &P) {
         store_bundle(s_bun[wv], axis, axis, false, cmin, P.cull != 0);
     }
     __builtin_amdgcn_wave_barrier();
-    const unsigned long long passed = (MODE == 0 && P.nguard_cached > 0) ? tile_guard_mask(P, x0, P.row0 + ly0) : 0ull;
+    const unsigned long long passed = P.nguard_cached > 0 ? tile_guard_mask(P, x0, P.row0 + ly0) : 0ull;
     RT_WAVE_PHASE(1)
     unsigned nexact = 0, nblocks = 0;
-    unsigned nemit = 0;                                                            // MODE 1: pairs written to the tile's list (wave-uniform)
-    uint32_t *const cand = MODE == 1 ? P.cand + (size_t)wave * RT_CAND_CAP : nullptr;
     WaveQueues Q = {s_q1[wv], s_q2[wv], 0u, 0u, 0u, s_rec[wv]};
 #ifdef RT_X_NOSCAN
     if (P.w < 0)
@@ -1901,7 +1767,7 @@ __device__ __forceinline__ void primary_tile(const RenderParams &P) {
             const int xe = x0 + ex(e), ye = P.row0 + ly0 + ey(e);
             const int kind = __float_as_int(R[14 * 32]), gid = __float_as_int(R[15 * 32]);
             double ox, oy;
-            sample_offset_t<SPP1>(P, xe, ye, ox, oy);
+            sample_offset(P, xe, ye, ox, oy);
             const float px = (float)(P.cam.scaleX * ((double)xe + ox) + P.cam.dX);
             const float py = (float)(P.cam.scaleY * ((double)ye + oy) + P.cam.dY);
             entry2 = ((uint32_t)gid << 9) | ((uint32_t)kind << 8) | (uint32_t)e;
@@ -1909,138 +1775,93 @@ __device__ __forceinline__ void primary_tile(const RenderParams &P) {
             return gid >= 0 && record_test_staged(Q.rec, row, kind, px, py, 1.0f);
         },
         [&](uint32_t entry) {                   // exact: intersect leaf (cast camera x y), Main.hs:543
-            if (MODE == 1) {                    // ... in k_primary_exact: the pair goes to the tile's list (the active lanes hold one each)
-                const unsigned long long m = __builtin_amdgcn_ballot_w64(true);
-                const unsigned k = nemit + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                if (k < RT_CAND_CAP) cand[k] = entry;
-                nemit += (unsigned)__popcll(m);
-                return;
-            }
             const int e = (int)(entry & 255u);
 #ifdef RT_X_SCANONLY      // measurement only (wrong pixels): what the kernel costs without its exact stage
             bid[e] = (int)(entry >> 9); ++nexact; return;
 #endif
             const int kind = (int)((entry >> 8) & 1u), gid = (int)(entry >> 9);
             const LeafD &L = P.leaves[gid];
-            const RayD ray = camera_ray<true, SPP1>(P, x0 + ex(e), P.row0 + ly0 + ey(e));
+            const RayD ray = camera_ray(P, x0 + ex(e), P.row0 + ly0 + ey(e));
             double ix, iy, iz, tt;
             ++nexact;
-            const bool hit = planar_isect(L, kind, ray, ix, iy, iz, tt, RT_TALK(P)) && guards_ok(P.guards, L.guard, ray, passed);
+            const bool hit = (kind == LEAF_TRI ? leaf_isect<LEAF_TRI>(L, ray, ix, iy, iz, tt, RT_TALK(P)) : leaf_isect<LEAF_RECT>(L, ray, ix, iy, iz, tt, RT_TALK(P)))
+                             && guards_ok(P.guards, L.guard, ray, passed);
 #ifdef RT_COUNT_EVENTS
             if (hit) stat_add(P, 3, 1ull);
 #endif
-            fold_nearest(bt, bid, e, hit, tt, gid);
+            // Nearest wins; equal t -> the left-most leaf of the tree (Main.hs:213-214).  Several lanes may hold hits of
+            // the same pixel: the wave runs in lockstep and its LDS operations complete in order, so (1) all read the
+            // old t, (2) all fold their t in with an atomic min, (3) the lanes whose t is the new minimum reset the
+            // leaf index if the minimum moved, (4) and fold their leaf index in with an atomic min.
+            // t = -0.0 passes `t >= 0` (a leaf in the viewport plane) and must order as 0, not as the largest pattern
+            const unsigned long long tb = (unsigned long long)__double_as_longlong(tt + 0.0);
+            unsigned long long old = 0;
+            if (hit) { old = bt[e]; atomicMin(&bt[e], tb); }
+            __builtin_amdgcn_wave_barrier();
+            const bool win = hit && bt[e] == tb;
+            if (win && tb < old) bid[e] = 0x7fffffff;
+            __builtin_amdgcn_wave_barrier();
+            if (win) atomicMin(&bid[e], gid);
         });
     __builtin_amdgcn_wave_barrier();
     RT_WAVE_PHASE(2)
-    if (MODE == 1) {
-        if (lane == 0) P.cand_count[wave] = nemit <= RT_CAND_CAP ? nemit : RT_CAND_OVERFLOW;
-    } else {
-        // the lane finishes rays (4h + r) * 32 + c: the table, then spheres
-        double mt[4]; int mid[4]; bool act[4]; int px[4], py[4];
+    // the lane finishes rays (4h + r) * 32 + c: the table, then spheres
+    double mt[4]; int mid[4]; bool act[4]; int px[4], py[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int e = (4 * h + r) * 32 + c;
+        mid[r] = bid[e];
+        mt[r] = mid[r] >= 0 ? __longlong_as_double((long long)bt[e]) : (double)INFINITY;
+        px[r] = x0 + ex(e); py[r] = ly0 + ey(e);
+        act[r] = px[r] < P.w && py[r] < P.nrows;
+    }
+    if (P.nsph > 0) {
+        Dir4 D; f2 dd[2];
+        float dx[4], dy[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int e = (4 * h + r) * 32 + c;
-            mid[r] = bid[e];
-            mt[r] = mid[r] >= 0 ? __longlong_as_double((long long)bt[e]) : (double)INFINITY;
-            px[r] = x0 + ex(e); py[r] = ly0 + ey(e);
-            act[r] = px[r] < P.w && py[r] < P.nrows;
+            double ox, oy;
+            sample_offset(P, px[r], P.row0 + py[r], ox, oy);
+            dx[r] = (float)(P.cam.scaleX * ((double)px[r] + ox) + P.cam.dX);
+            dy[r] = (float)(P.cam.scaleY * ((double)(P.row0 + py[r]) + oy) + P.cam.dY);
         }
-        if (P.nsph > 0) primary_spheres<SPP1>(P, px, py, act, mt, mid, nexact, [](int, double, double, double) {});
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (act[r]) P.hit_id[P.out_off + (long long)py[r] * P.w + px[r]] = mid[r];
-        for (int o = 32; o > 0; o >>= 1) nexact += __shfl_down(nexact, o);
-        if (lane == 0 && nexact) stat_add(P, 1, (unsigned long long)nexact);
+        for (int p = 0; p < 2; ++p) { D.x[p] = f2{dx[2 * p], dx[2 * p + 1]}; D.y[p] = f2{dy[2 * p], dy[2 * p + 1]}; D.z[p] = f2{dzf, dzf}; }
+        dir_norms(D, dd);
+        CRecPtr recs = as_const(P.sph_rec);
+        CIntPtr gids = as_const(P.sph_gid);
+        for (int i = 0; i < P.nsph; ++i) {
+            const FilterRec cur = load_rec(recs + i);
+            float z[4];
+            if (filter4_sphere(cur, D, dd, z)) {
+                const int gid = gids[i];
+                const LeafD &L = P.leaves[gid];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if ((z[r] >= cur.c[9]) & act[r]) {
+                        int yr = P.row0 + py[r];
+                        asm volatile("" : "+v"(yr));
+                        const RayD ray = camera_ray(P, px[r], yr);
+                        double ix, iy, iz, tt;
+                        ++nexact;
+                        if (leaf_isect<LEAF_SPHERE>(L, ray, ix, iy, iz, tt, RT_TALK(P)) && guards_ok(P.guards, L.guard, ray)) {
+                            if (tt < mt[r] || (tt == mt[r] && gid < mid[r]) || mid[r] < 0) { mt[r] = tt; mid[r] = gid; }
+                        }
+                    }
+                }
+            }
+        }
     }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (act[r]) P.hit_id[P.out_off + (long long)py[r] * P.w + px[r]] = mid[r];
+    for (int o = 32; o > 0; o >>= 1) nexact += __shfl_down(nexact, o);
+    if (lane == 0 && nexact) stat_add(P, 1, (unsigned long long)nexact);
     if (lane == 0) stat_add(P, 6, (unsigned long long)nblocks);
     if (lane == 0 && Q.nrec) stat_add(P, 4, (unsigned long long)Q.nrec);
 #ifdef RT_WAVE_TIMES
     wave_ph[2] = (Q.t_s1 & 0xffff) | ((Q.t_ex & 0xffff) << 16) | ((Q.t_bits & 0xffff) << 32) | ((Q.t_loop & 0xffff) << 48);
     wave_record(P, 0u, (unsigned)wave, wave_t0, nblocks, Q.nrec, nexact, wave_ph);
-#endif
-}
-
-__global__ void RT_HOT(RT_WAVES_EU_MF_PRIMARY) k_primary_mfma(const RenderParams P) { primary_tile<0, false>(P); }
-
-#ifndef RT_WAVES_EU_SCAN
-#define RT_WAVES_EU_SCAN 4
-#endif
-template <bool SPP1>
-__global__ void RT_HOT(RT_WAVES_EU_SCAN) k_primary_scan(const RenderParams P) { primary_tile<1, SPP1>(P); }
-
-// The exact stage of the two-kernel form: one wave per tile works its list off 64 pairs at a time (intersect leaf (cast
-// camera x y), Main.hs:543, with the guard chain, Main.hs:209), folds the nearest hit per pixel in LDS, and leaves per
-// pixel the hit ID and — new — the hit POINT of the winning pair with its material, so that k_setup need not run
-// planeRayIsect again for it (the point is moved, not re-derived: the same expression evaluated once).
-#ifndef RT_WAVES_EU_EXACT
-#define RT_WAVES_EU_EXACT 4
-#endif
-template <bool SPP1>
-__global__ void __attribute__((amdgpu_waves_per_eu(RT_WAVES_EU_EXACT, 8))) __launch_bounds__(64) k_primary_exact(const RenderParams P) {
-    RT_WAVE_T0
-    __shared__ unsigned long long s_bt[256];
-    __shared__ int s_bid[256];
-    __shared__ double s_pos[3][256];
-    const int wave = (int)blockIdx.x;
-    const int lane = (int)(threadIdx.x & 63), c = lane & 31, h = lane >> 5;
-    const int tx = wave % P.tiles_x, ty = wave / P.tiles_x;
-    if (ty >= P.tiles_y) return;
-    const unsigned n = P.cand_count[wave];
-    if (n == RT_CAND_OVERFLOW) return;                   // k_primary_mfma does this tile
-    const int x0 = tx * RT_TILE_W, ly0 = ty * RT_TILE_H;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { s_bt[r * 64 + lane] = ~0ull; s_bid[r * 64 + lane] = -1; }
-    __builtin_amdgcn_wave_barrier();
-    const unsigned long long passed = (n > 0u && P.nguard_cached > 0) ? tile_guard_mask(P, x0, P.row0 + ly0) : 0ull;
-    RT_WAVE_PHASE(0)
-    RT_WAVE_PHASE(1)
-    const uint32_t *list = P.cand + (size_t)wave * RT_CAND_CAP;
-    unsigned nexact = 0;
-    for (unsigned base = 0; base < n; base += 64u) {     // wave-uniform
-        const bool have = base + (unsigned)lane < n;
-        const uint32_t entry = have ? list[base + lane] : 0u;
-        const int e = (int)(entry & 255u);
-        const int kind = (int)((entry >> 8) & 1u), gid = (int)(entry >> 9);
-        double ix = 0, iy = 0, iz = 0, tt = 0;
-        bool hit = false;
-        if (have) {
-            const LeafD &L = P.leaves[gid];
-            const RayD ray = camera_ray<true, SPP1>(P, x0 + tile_ex(e), P.row0 + ly0 + tile_ey(e));
-            ++nexact;
-            hit = planar_isect(L, kind, ray, ix, iy, iz, tt, RT_TALK(P)) && guards_ok(P.guards, L.guard, ray, passed);
-        }
-        if (fold_nearest(s_bt, s_bid, e, hit, tt, gid)) { s_pos[0][e] = ix; s_pos[1][e] = iy; s_pos[2][e] = iz; }
-    }
-    __builtin_amdgcn_wave_barrier();
-    RT_WAVE_PHASE(2)
-    // the lane finishes rays (4h + r) * 32 + c: the table, then spheres
-    double mt[4]; int mid[4]; bool act[4]; int px[4], py[4];
-    double mp[4][3];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int e = (4 * h + r) * 32 + c;
-        mid[r] = s_bid[e];
-        mt[r] = mid[r] >= 0 ? __longlong_as_double((long long)s_bt[e]) : (double)INFINITY;
-        mp[r][0] = s_pos[0][e]; mp[r][1] = s_pos[1][e]; mp[r][2] = s_pos[2][e];
-        px[r] = x0 + tile_ex(e); py[r] = ly0 + tile_ey(e);
-        act[r] = px[r] < P.w && py[r] < P.nrows;
-    }
-    if (P.nsph > 0) primary_spheres<SPP1>(P, px, py, act, mt, mid, nexact, [&](int r, double ix, double iy, double iz) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) if (k == r) { mp[k][0] = ix; mp[k][1] = iy; mp[k][2] = iz; }
-    });
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-        if (act[r]) {
-            const long long pix = (long long)py[r] * P.w + px[r];
-            P.hit_id[P.out_off + pix] = mid[r];
-            if (mid[r] >= 0) P.hitpos[pix] = PosRec{mp[r][0], mp[r][1], mp[r][2], mid[r], P.leaves[mid[r]].mat};
-        }
-    for (int o = 32; o > 0; o >>= 1) nexact += __shfl_down(nexact, o);
-    if (lane == 0 && nexact) stat_add(P, 1, (unsigned long long)nexact);
-#ifdef RT_WAVE_TIMES
-    wave_record(P, 3u, (unsigned)wave, wave_t0, 0u, 0u, nexact, wave_ph);
 #endif
 }
 
@@ -2064,10 +1885,8 @@ __global__ void __launch_bounds__(1024) k_final(const RenderParams P) {
     bool spawn = false;
     RayRec child = {0, 0, 0, 0, 0, 0, 0, 0u, 0u};
     if (id >= 0) {
-        const PosRec R = P.hitpos[pix];
-        const NrmRec N = P.hitnrm[pix];
-        const MaterialD M = P.mats[R.mat];
-        const HitRec H = {R.x, R.y, R.z, N.x, N.y, N.z};
+        const MaterialD M = P.mats[P.leaves[id].mat];
+        const HitRec H = P.hitrec[pix];
         uint32_t lit = 0u;
         const RayD ray = slot_ray(P, pix);
         int pl = 0;
@@ -2498,7 +2317,8 @@ __global__ void __attribute__((amdgpu_waves_per_eu(RT_WAVES_EU_GEN, 8))) __launc
         r.rx = s_ray[6 * 64 + e]; r.ry = s_ray[7 * 64 + e]; r.rz = s_ray[8 * 64 + e];
         double ix, iy, iz, tt = 0;
         ++nexact;
-        const bool hit = (kind != LEAF_SPHERE ? planar_isect(L, kind, r, ix, iy, iz, tt, RT_TALK(P)) : leaf_isect<LEAF_SPHERE>(L, r, ix, iy, iz, tt, RT_TALK(P)))
+        const bool hit = (kind == LEAF_TRI ? leaf_isect<LEAF_TRI>(L, r, ix, iy, iz, tt, RT_TALK(P))
+                          : (kind == LEAF_RECT ? leaf_isect<LEAF_RECT>(L, r, ix, iy, iz, tt, RT_TALK(P)) : leaf_isect<LEAF_SPHERE>(L, r, ix, iy, iz, tt, RT_TALK(P))))
                          && guards_ok(P.guards, L.guard, r);
         // nearest wins; equal t -> the left-most leaf of the tree (Main.hs:213-214); the same four steps as in k_primary_mfma
         const unsigned long long tb = (unsigned long long)__double_as_longlong(tt + 0.0);
@@ -2814,7 +2634,6 @@ bool levels_supported(const rt_scene *s, int depth) {
 // What one render needs beyond its inputs and outputs, in elements of each buffer.
 struct WsNeeds {
     size_t hit_id = 0, accum = 0, hitrec = 0, queue = 0, qsparse = 0, tcount = 0, lit = 0, lvl = 0, cb = 0;
-    size_t cand_tiles = 0;          // 32 x 8 pixel tiles of a chunk whose candidate lists the two-kernel nearest-hit pass keeps (0: one-kernel form)
     int levels = 1;
 };
 // slots of a bounce level: k_final hands every wave of 8 x 8 pixels that reflects anything a run of 64 slots, so a level
@@ -2827,7 +2646,7 @@ size_t setup_blocks_bound(int w, size_t crow, bool levels) {   // k_setup blocks
     return std::max((size_t)((w + 31) / 32) * ((crow + RT_SETUP_THREADS / 32 - 1) / (RT_SETUP_THREADS / 32)),
                     (slots + RT_SETUP_THREADS - 1) / RT_SETUP_THREADS);
 }
-WsNeeds ws_needs(int w, int nrows, size_t crow, int npoint, int levels, int spp, bool own_hit, bool shade, bool callbacks, bool split = false) {
+WsNeeds ws_needs(int w, int nrows, size_t crow, int npoint, int levels, int spp, bool own_hit, bool shade, bool callbacks) {
     WsNeeds n;
     const size_t npix = (size_t)w * (size_t)nrows, np = (size_t)(npoint > 0 ? std::min(npoint, 32) : 1);
     const size_t groups = (size_t)std::max(1, (npoint + 31) / 32);
@@ -2835,9 +2654,8 @@ WsNeeds ws_needs(int w, int nrows, size_t crow, int npoint, int levels, int spp,
     n.levels = levels;
     if (own_hit || spp > 1) n.hit_id = npix;
     if (!shade) return n;
-    if (split) n.cand_tiles = (size_t)((w + RT_TILE_W - 1) / RT_TILE_W) * ((crow + RT_TILE_H - 1) / RT_TILE_H);
     if (spp > 1) n.accum = 3 * npix;
-    n.hitrec = cpix * (sizeof(PosRec) + sizeof(NrmRec));
+    n.hitrec = cpix * sizeof(HitRec);
     n.lit = cpix * groups;
     n.queue = cpix * np;
     const size_t ub = setup_blocks_bound(w, crow, levels > 1);
@@ -2855,10 +2673,6 @@ int ws_grow(DeviceScene &D, const WsNeeds &n) {
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&W.counters), RT_COUNTER_BYTES + RT_QCOUNT_WORDS * sizeof(unsigned)));
         W.qcount = reinterpret_cast<unsigned *>(reinterpret_cast<unsigned char *>(W.counters) + RT_COUNTER_BYTES);
         HIP_TRY(hipMemset(W.qcount, 0, RT_QCOUNT_WORDS * sizeof(unsigned)));
-    }
-    if (n.cand_tiles) {
-        if ((rc = ensure(W.cand, D.cand_cap, n.cand_tiles * RT_CAND_CAP))) return rc;
-        if ((rc = ensure(W.cand_count, D.cand_count_cap, n.cand_tiles))) return rc;
     }
     if (n.hit_id && (rc = ensure(W.hit_id, D.hit_id_cap, n.hit_id))) return rc;
     if (n.accum && (rc = ensure(W.accum, D.accum_cap, n.accum))) return rc;
@@ -2953,12 +2767,7 @@ int render_rows(rt_scene *s, DeviceScene &D, const Workspace &W, size_t crow, in
     P.tri_rec = (const FilterRec *)D.tri_rec.p; P.rect_rec = (const FilterRec *)D.rect_rec.p;
     P.tri_gid = (const int32_t *)D.tri_gid.p; P.rect_gid = (const int32_t *)D.rect_gid.p;
     P.counters = W.counters;
-    {
-        const size_t cslots = render_levels(s, depth) > 1 ? level_capacity(w, crow) : crow * (size_t)w;     // as ws_needs lays them out
-        P.hitpos = reinterpret_cast<PosRec *>(W.hitrec);
-        P.hitnrm = reinterpret_cast<NrmRec *>(W.hitrec + cslots * sizeof(PosRec));
-    }
-    P.queue = W.queue; P.qcount = W.qcount; P.lit = W.lit;
+    P.hitrec = reinterpret_cast<HitRec *>(W.hitrec); P.queue = W.queue; P.qcount = W.qcount; P.lit = W.lit;
     P.qsparse = W.qsparse; P.tcount = W.tcount;
     P.cb_slot = W.cb_slot; P.cb_xy = W.cb_xy; P.cb_group = W.cb_group; P.cb_normal = W.cb_normal; P.cb_count = W.qcount + RT_QCOUNT_CB;
     P.gen_tri = (const GenRec *)D.gen_tri.p; P.gen_rect = (const GenRec *)D.gen_rect.p;
@@ -3015,20 +2824,6 @@ int render_rows(rt_scene *s, DeviceScene &D, const Workspace &W, size_t crow, in
             if (depth == 0) {      // trace 0 = black (Main.hs:542): every pixel misses
                 HIP_TRY(hipMemsetAsync(P.hit_id + P.out_off, 0xff, (size_t)P.qcap * sizeof(int32_t), st));
             } else {
-                // two kernels (scan -> lists -> exact) when the work buffers hold the lists; the one-kernel form then only does
-                // the tiles whose list overflowed (it looks at cand_count) — and everything when there are no lists
-                const bool split = use_mfma && W.cand && W.cand_count && s->opt_split && d_rgba;
-                P.cand = split ? W.cand : nullptr; P.cand_count = split ? W.cand_count : nullptr;
-                if (split) {
-                    const unsigned tgrid = (unsigned)tiles;
-                    if (spp == 1) {
-                        hipLaunchKernelGGL(k_primary_scan<true>, dim3(tblocks), dim3(RT_WAVES_PER_BLOCK * 64), 0, st, P);
-                        hipLaunchKernelGGL(k_primary_exact<true>, dim3(tgrid), dim3(64), 0, st, P);
-                    } else {
-                        hipLaunchKernelGGL(k_primary_scan<false>, dim3(tblocks), dim3(RT_WAVES_PER_BLOCK * 64), 0, st, P);
-                        hipLaunchKernelGGL(k_primary_exact<false>, dim3(tgrid), dim3(64), 0, st, P);
-                    }
-                }
                 if (use_mfma) hipLaunchKernelGGL(k_primary_mfma, dim3(tblocks), dim3(RT_WAVES_PER_BLOCK * 64), 0, st, P);
 #ifdef RT_VALU_FILTER
                 else if (spp == 1) hipLaunchKernelGGL(k_primary<true>, dim3(tblocks), dim3(RT_WAVES_PER_BLOCK * 64), 0, st, P);
@@ -3141,12 +2936,7 @@ int render_band(rt_scene *s, int device, int w, int h, int depth, int spp, uint6
     if (!levels_supported(s, depth)) return RT_ERR_UNSUPPORTED;
     const int levels = render_levels(s, depth);
     const size_t crow = chunk_rows(w, nrows, levels);
-#ifdef RT_VALU_FILTER
-    const bool split = s->opt_split && (s->opt_filter == 0 || s->talk) && depth > 0;
-#else
-    const bool split = s->opt_split && depth > 0;
-#endif
-    const WsNeeds need = ws_needs(w, nrows, crow, s->npoint, levels, spp, d_hit_id == nullptr, d_rgba != nullptr, !s->normal_fn.empty(), split);
+    const WsNeeds need = ws_needs(w, nrows, crow, s->npoint, levels, spp, d_hit_id == nullptr, d_rgba != nullptr, !s->normal_fn.empty());
     if ((rc = ws_grow(D, need))) return rc;
     return render_rows(s, D, D.ws, crow, w, h, depth, spp, seed, row0, nrows, d_rgba, d_hit_id, st ? st : (hipStream_t)D.stream, more, true, hits_done);
 }
@@ -3180,7 +2970,7 @@ void rt_scene_destroy(rt_scene *s) {
         for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
         Workspace &W = d.ws;
         void *ptrs[] = {W.counters, W.hit_id, W.accum, W.hitrec, W.queue, W.qsparse, W.tcount, W.lit,
-                        W.cb_slot, W.cb_xy, W.cb_group, W.cb_normal, W.cand, W.cand_count, d.rgba, d.hit_out, d.stage_rgba, d.stage_hit};
+                        W.cb_slot, W.cb_xy, W.cb_group, W.cb_normal, d.rgba, d.hit_out, d.stage_rgba, d.stage_hit};
         for (void *p : ptrs) if (p) (void)hipFree(p);
         for (int k = 0; k < RT_MAX_LEVELS; ++k) {
             if (W.lvl_rays[k]) (void)hipFree(W.lvl_rays[k]);

@@ -1082,7 +1082,6 @@ int rt_scene_set_option(rt_scene *s, int option, int value) {
         if (value < 0) { set_error("rt_scene_set_option: RT_OPT_HOST_BANDS must be >= 0"); return RT_ERR_ARG; }
         s->opt_host_bands = value; return RT_OK;
     case RT_OPT_MULTI_STAGE: s->opt_multi_stage = value != 0; return RT_OK;
-    case RT_OPT_SPLIT: s->opt_split = value != 0; return RT_OK;
     }
     set_error("rt_scene_set_option: unknown option");
     return RT_ERR_ARG;

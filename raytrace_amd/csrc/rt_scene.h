@@ -28,9 +28,7 @@ struct Workspace {
     unsigned *qcount = nullptr;              // shadow jobs per point light [0..31]; rays per bounce level [32..63]
     int32_t *hit_id = nullptr;               // per band pixel (only when the caller gives no buffer, or spp > 1)
     uint32_t *accum = nullptr;               // spp > 1: 3 x u32 per band pixel
-    char *hitrec = nullptr;                  // per chunk slot: 32-byte position records (hit point, leaf, material), then 24-byte normals
-    uint32_t *cand = nullptr;                // two-kernel nearest-hit pass: per 32 x 8 tile of a chunk, room for RT_CAND_CAP (ray, leaf) pairs
-    unsigned *cand_count = nullptr;          // ... and how many there are
+    char *hitrec = nullptr;                  // per chunk pixel: 48-byte HitRec
     uint32_t *queue = nullptr;               // shadow-job queues, npoint x chunk pixels
     uint32_t *qsparse = nullptr;             // k_setup's per-block runs of shadow jobs, before compaction
     unsigned *tcount = nullptr;              // shadow jobs per (light, k_setup block) -> offsets
@@ -67,7 +65,6 @@ struct DeviceScene {          // the scene on ONE device (HBM), owned by the rt_
     size_t hit_id_cap = 0, accum_cap = 0, hitrec_cap = 0, queue_cap = 0, qsparse_cap = 0, tcount_cap = 0, lit_cap = 0;
     size_t lvl_rays_cap[RT_MAX_LEVELS] = {}, lvl_hit_cap[RT_MAX_LEVELS] = {}, lvl_col_cap[RT_MAX_LEVELS] = {};
     size_t cb_cap[4] = {};
-    size_t cand_cap = 0, cand_count_cap = 0;
     uint8_t *rgba = nullptr;    size_t rgba_cap = 0;       // rt_render (host buffers) staging
     int32_t *hit_out = nullptr; size_t hit_out_cap = 0;
     uint8_t *stage_rgba = nullptr; size_t stage_rgba_cap = 0;   // rt_render_multi: this device's bands before the peer copy
@@ -127,9 +124,8 @@ struct rt_scene {
     // per-scene options (rt_scene_set_option)
     int opt_cull = 1;                     // 0: every wave scans every block of the leaf stream
     int opt_filter = 0;                   // 0: matrix-core first stage; 1: FP32 vector-ALU kernels (test build only)
-    int opt_host_bands = 0;               // copy bands of rt_render (0: one per 4 Mi pixels)
+    int opt_host_bands = 0;               // copy bands of rt_render (0: one per 2 Mi pixels)
     int opt_multi_stage = 0;              // rt_render_multi: also the home device's bands go through a staging buffer + peer copy
-    int opt_split = 1;                    // 1: nearest hit of the camera rays in two kernels (scan -> candidate lists -> exact); 0: one kernel
     // arbitrary `fnorm` closures (Main.hs:956-965): per callback group, the caller's function
     std::vector<rt_normal_fn> normal_fn;
     std::vector<void *> normal_user;
