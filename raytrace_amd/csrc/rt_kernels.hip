@@ -692,7 +692,10 @@ __device__ __forceinline__ void light_terms(const RenderParams &P, const LightD 
 #ifndef RT_SETUP_THREADS
 #define RT_SETUP_THREADS 512
 #endif
-__global__ void __launch_bounds__(RT_SETUP_THREADS) k_setup(const RenderParams P) {
+#ifndef RT_WAVES_EU_SETUP
+#define RT_WAVES_EU_SETUP 4
+#endif
+__global__ void __attribute__((amdgpu_waves_per_eu(RT_WAVES_EU_SETUP, 8))) __launch_bounds__(RT_SETUP_THREADS) k_setup(const RenderParams P) {
     // shadow jobs of the block per light: per-wave counts -> offsets inside the block's run
     __shared__ unsigned s_cnt[32][RT_SETUP_THREADS / 64];
     // level 0: a block takes a 32 x 16 pixel tile, so that the shadow rays it queues (256 consecutive entries make one
@@ -1870,7 +1873,10 @@ __global__ void RT_HOT(RT_WAVES_EU_MF_PRIMARY) k_primary_mfma(const RenderParams
 //   saturating 8-bit sums, coalesced RGBA8 store.
 
 // Launched with 256 threads, or with 1024 when reflected rays are handed to a next level (one atomic per BLOCK then).
-__global__ void __launch_bounds__(1024) k_final(const RenderParams P) {
+#ifndef RT_WAVES_EU_FINAL
+#define RT_WAVES_EU_FINAL 4
+#endif
+__global__ void __attribute__((amdgpu_waves_per_eu(RT_WAVES_EU_FINAL, 8))) __launch_bounds__(1024) k_final(const RenderParams P) {
     // level 0: a block takes a 32 x 8 (32 x 32) pixel tile, a wave 8 x 8 pixels of it; bounce levels: slots in order
     int pix = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     bool act = (unsigned)pix < num_slots(P);
