@@ -19,7 +19,7 @@ Also on the JSON line:
   roofline      — the dominant kernel (the longer of k_primary_mfma / k_shadow_mfma) as a UTILISATION (<= 1): the larger
                   of its vector-issue fraction (SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x kernel cycles)) and its
                   matrix-pipe fraction (MFMAs x 32768 flop / time / 2.5 PFLOP/s).  Instruction counts per launch, the
-                  clock and the HBM traffic are PMC readings: they come from profiles/r02_pmc.json (written by
+                  clock and the HBM traffic are PMC readings: they come from profiles/r03_pmc.json (written by
                   tools/profile_round.sh from separate rocprofv3 --pmc passes of this very command) and are combined
                   with the launch time measured live (HIP events on the render stream).  The MFMA count is also
                   counted live by the kernels.  The ALGORITHMIC rate (52/44 flops per ray x triangle/rectangle test,
@@ -50,34 +50,67 @@ PEAK_MFMA_F16_TFLOPS = 2500.0                   # MI355X_MICROARCH.md: peak BF16
 PEAK_CLOCK_GHZ = 2.4
 SIMDS = 256 * 4                                 # 256 CUs x 4 SIMDs; one wave64 VALU instruction holds a SIMD's issue port 4 cycles
 MFMA_FLOPS = 2 * 32 * 32 * 16                   # one v_mfma_f32_32x32x16_f16
-PMC_JSON = os.path.join(ROOT, "profiles", "r02_pmc.json")
+PMC_JSON = os.path.join(ROOT, "profiles", "r03_pmc.json")
+# Vector-issue cycles one wave64 instruction holds a SIMD's issue port, by the classes SQ_INSTS_VALU_* counts, measured on this
+# chip at 4-8 waves per SIMD (profiles/r03_issue_costs.txt, tools/microbench/issue_costs.hip).  Plain FP32 add / mul / fma are
+# the only instructions that reach the 2-cycle rate of MI355X_MICROARCH.md:485 (v_pk_fma_f32 costs 4.3 but these kernels' FP32
+# work is unpacked v_fma_f32); an MFMA holds the port for 8 of its 32 cycles.
+ISSUE_COST = {"fp32": 2.4, "fp64": 4.25, "trans_f32": 8.2, "trans_f64": 16.3, "int": 4.25, "cvt": 4.25, "rest": 4.25, "mfma_hold": 8.0}
+CLASS_COUNTERS = {"fp32": ("SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32"),
+                  "fp64": ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64"),
+                  "trans_f32": ("SQ_INSTS_VALU_TRANS_F32",), "trans_f64": ("SQ_INSTS_VALU_TRANS_F64",),
+                  "int": ("SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU_INT64"), "cvt": ("SQ_INSTS_VALU_CVT",)}
+PEAK_FP64_TFLOPS = 78.6                         # MI355X_MICROARCH.md: peak FP64 (vector)
 MULTI_W = MULTI_H = 16384                       # configs[3]
 
 
-def cpu_baseline(world, lights, w, h, depth, seconds=18.0):
+def host_threads():
+    """Threads the CPU leg may use: the cores this process may run on (its affinity mask), capped by the box's own
+    OMP_NUM_THREADS share when one is set (a GPU box hands a 1-GPU job 16 of the machine's cores and asks that worker pools
+    stay within them); os.cpu_count() is reported beside it as cores_available."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    share = os.environ.get("OMP_NUM_THREADS", "")
+    if share.isdigit() and int(share) > 0:
+        n = min(n, int(share))
+    return max(1, n)
+
+
+def cpu_baseline(world, lights, w, h, depth, seconds=13.0, seconds_n4=6.0):
+    """The CPU oracle on a bounded band of the same frame: on all the host cores this job may use (north_star: `+RTS
+    -N<cores>`) and on 4 threads (README:36 suggests `+RTS -N4`).  Contiguous row chunks per thread, as Repa's computeP."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_binding as ob
-    cores = min(16, os.cpu_count() or 1)
+    cores = host_threads()
     osc = ob.OracleScene(world, lights)
     row0 = h // 2 - 1
     osc.render(w, h, depth=depth, row0=row0, nrows=1, nthreads=1)       # first call numbers the leaves
     t0 = time.perf_counter()
     osc.render(w, h, depth=depth, row0=row0, nrows=2, nthreads=2)       # calibration: 2 rows on 2 threads
-    dt = time.perf_counter() - t0
-    nrows = int(max(cores, min(h // 2, cores * seconds / max(dt, 1e-6))))
-    nrows -= nrows % 2
-    row0 = h // 2 - nrows // 2
-    t0 = time.perf_counter()
-    osc.render(w, h, depth=depth, row0=row0, nrows=nrows, nthreads=cores)
-    dt = time.perf_counter() - t0
+    per_row_thread = (time.perf_counter() - t0)                          # seconds per row per thread
+
+    def leg(threads, budget):
+        nrows = int(max(threads, min(h // 2, threads * budget / max(per_row_thread, 1e-6))))
+        nrows -= nrows % 2
+        r0 = h // 2 - nrows // 2
+        t0 = time.perf_counter()
+        osc.render(w, h, depth=depth, row0=r0, nrows=nrows, nthreads=threads)
+        dt = time.perf_counter() - t0
+        return w * nrows / dt / 1e6, r0, nrows, dt
+    v, r0, nrows, dt = leg(cores, seconds)
+    v4, r04, nrows4, dt4 = leg(min(4, cores), seconds_n4)
     osc.close()
-    return {"value": w * nrows / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": f"rows {row0}..{row0 + nrows - 1} ({nrows} of {h}) of the same {w}x{h} frame, "
-                      f"{dt:.1f} s; C restatement of the reference (oracle/), not the Haskell program"}
+    return {"value": v, "unit": "Mrays/s", "cores": cores, "cores_available": os.cpu_count(), "kind": "port",
+            "sample": f"rows {r0}..{r0 + nrows - 1} ({nrows} of {h}) of the same {w}x{h} frame, "
+                      f"{dt:.1f} s; C restatement of the reference (oracle/), not the Haskell program",
+            "n4": {"value": v4, "unit": "Mrays/s", "cores": min(4, cores),
+                   "sample": f"rows {r04}..{r04 + nrows4 - 1} ({nrows4} of {h}), {dt4:.1f} s; the `+RTS -N4` of the reference's README:36"}}
 
 
 def load_pmc(workload_key):
-    """PMC readings per launch of the two big kernels for the default workload (profiles/r02_pmc.json)."""
+    """PMC readings per launch of the two big kernels for the default workload (profiles/r03_pmc.json)."""
     try:
         with open(PMC_JSON) as f:
             pmc = json.load(f)
@@ -99,7 +132,31 @@ def utilisation(kernel, ms, mfmas_live, pmc):
     out["mfma_frac"] = out["mfma_tflops"] / PEAK_MFMA_F16_TFLOPS
     if k.get("SQ_INSTS_VALU"):
         out["valu_insts_per_launch"] = k["SQ_INSTS_VALU"]
-        out["valu_issue_frac"] = k["SQ_INSTS_VALU"] * 4 / (SIMDS * cycles)
+        out["valu_issue_frac_flat4"] = k["SQ_INSTS_VALU"] * 4 / (SIMDS * cycles)        # round 2's figure: every instruction at 4 cycles
+        if all(c in k for cs in CLASS_COUNTERS.values() for c in cs):
+            # class-weighted: every class at its measured issue cost, what no class counter covers (moves, compares, ballots,
+            # mbcnt, readlane, ...) at 4.25, plus the 8 cycles an MFMA holds the vector issue port
+            counts = {cls: sum(k[c] for c in cs) for cls, cs in CLASS_COUNTERS.items()}
+            counts["rest"] = max(0.0, k["SQ_INSTS_VALU"] - sum(counts.values()))
+            issue = sum(counts[cls] * ISSUE_COST[cls] for cls in counts) + mfmas * ISSUE_COST["mfma_hold"]
+            out["valu_issue_frac"] = issue / (SIMDS * cycles)
+            out["issue_cycles_by_class"] = {cls: counts[cls] * ISSUE_COST[cls] / (SIMDS * cycles) for cls in counts}
+            out["issue_cycles_by_class"]["mfma_hold"] = mfmas * ISSUE_COST["mfma_hold"] / (SIMDS * cycles)
+            out["insts_by_class"] = counts
+            sec = ms * 1e-3
+            fp32 = (k["SQ_INSTS_VALU_ADD_F32"] + k["SQ_INSTS_VALU_MUL_F32"] + 2 * k["SQ_INSTS_VALU_FMA_F32"]) * 64
+            fp64 = (k["SQ_INSTS_VALU_ADD_F64"] + k["SQ_INSTS_VALU_MUL_F64"] + 2 * k["SQ_INSTS_VALU_FMA_F64"]) * 64
+            out["executed_fp32_tflops"] = fp32 / sec / 1e12
+            out["executed_fp64_tflops"] = fp64 / sec / 1e12
+            out["fp32_peak_frac"] = out["executed_fp32_tflops"] / PEAK_FP32_TFLOPS
+            out["fp64_peak_frac"] = out["executed_fp64_tflops"] / PEAK_FP64_TFLOPS
+            out["int_share"] = counts["int"] / k["SQ_INSTS_VALU"]
+        else:
+            out["valu_issue_frac"] = out["valu_issue_frac_flat4"]
+        if k.get("SQ_WAVE_CYCLES") and k.get("SQ_ACTIVE_INST_VALU") is not None and k.get("SQ_WAIT_INST_ANY") is not None:
+            # a wave's life (quad-cycles, summed over waves): issuing vector instructions / stalled on a dependency / parked at a wait
+            out["wave_life"] = {"issuing_valu": k["SQ_ACTIVE_INST_VALU"] / k["SQ_WAVE_CYCLES"], "stalled_on_dependency": k["SQ_WAIT_INST_ANY"] / k["SQ_WAVE_CYCLES"],
+                                "parked_at_a_wait_or_not_picked": 1.0 - (k["SQ_ACTIVE_INST_VALU"] + k["SQ_WAIT_INST_ANY"]) / k["SQ_WAVE_CYCLES"]}
     else:
         out["valu_insts_per_launch"] = None
         out["valu_issue_frac"] = None
@@ -376,26 +433,37 @@ def main():
             vf, mf = dom.get("valu_issue_frac"), dom["mfma_frac"]
             if vf is not None and vf >= mf:
                 clock = dom["clock_ghz"]
-                roof.update({"bound": "valu_issue", "achieved": dom["valu_insts_per_launch"] / (dom["launch_ms"] * 1e-3) / 1e9,
-                             "peak": SIMDS * clock / 4, "unit": "G wave-instructions/s", "frac": vf})
+                roof.update({"bound": "valu_issue", "achieved": vf * SIMDS * clock, "peak": SIMDS * clock,
+                             "unit": "G vector-issue cycles/s (1024 SIMDs x clock; a wave64 instruction holds a SIMD's port for its class's cycles)", "frac": vf})
             else:
                 roof.update({"bound": "mfma", "achieved": dom["mfma_tflops"], "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s", "frac": mf})
             roof.update({
                 "traffic": dom["traffic"],
                 "traffic_unit": "HBM bytes per launch: (2 x FETCH_SIZE + WRITE_SIZE) KiB x 1024 from separate rocprofv3 --pmc passes "
-                                "(profiles/r02_pmc.json; x 2 = the gfx950 correction for wide reads, MI355X_MICROARCH.md), "
+                                "(profiles/r03_pmc.json; x 2 = the gfx950 correction for wide reads, MI355X_MICROARCH.md), "
                                 "null when no PMC file matches this workload",
-                "valu_issue_frac": vf, "mfma_frac": mf, "mfma_tflops": dom["mfma_tflops"], "clock_ghz": dom["clock_ghz"],
+                "valu_issue_frac": vf, "valu_issue_frac_flat4": dom.get("valu_issue_frac_flat4"), "issue_cost_cycles": ISSUE_COST,
+                "issue_cost_source": "profiles/r03_issue_costs.txt (tools/microbench/issue_costs.hip, this chip, 4-8 waves per SIMD)",
+                "issue_cycles_by_class": dom.get("issue_cycles_by_class"), "insts_by_class": dom.get("insts_by_class"),
+                "executed_fp32_tflops": dom.get("executed_fp32_tflops"), "executed_fp64_tflops": dom.get("executed_fp64_tflops"),
+                "fp32_peak_frac": dom.get("fp32_peak_frac"), "fp64_peak_frac": dom.get("fp64_peak_frac"), "int_share": dom.get("int_share"),
+                "wave_life": dom.get("wave_life"),
+                "mfma_frac": mf, "mfma_tflops": dom["mfma_tflops"], "clock_ghz": dom["clock_ghz"],
                 "clock_source": dom["clock_source"],
                 "pmc_source": (pmc or {}).get("source"), "pmc_command": (pmc or {}).get("command"),
                 "algorithmic_tflops": dom["algorithmic_tflops"],
                 "speedup_vs_all_pairs": dom["algorithmic_tflops"] / PEAK_FP32_TFLOPS,
                 "leaf_blocks_scanned_frac": dom["leaf_blocks_scanned_frac"],
-                "other_kernel": {k: oth.get(k) for k in ("kernel", "launch_ms", "valu_issue_frac", "mfma_frac", "mfma_tflops", "traffic",
-                                                         "algorithmic_tflops", "leaf_blocks_scanned_frac")},
-                "note": "frac = the larger of the kernel's vector-issue fraction (SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x kernel cycles)) "
+                "other_kernel": {k: oth.get(k) for k in ("kernel", "launch_ms", "valu_issue_frac", "valu_issue_frac_flat4", "issue_cycles_by_class", "executed_fp32_tflops",
+                                                         "executed_fp64_tflops", "fp32_peak_frac", "fp64_peak_frac", "int_share", "wave_life", "mfma_frac", "mfma_tflops",
+                                                         "traffic", "algorithmic_tflops", "leaf_blocks_scanned_frac")},
+                "note": "frac = the larger of the kernel's vector-issue fraction (sum over instruction classes of SQ_INSTS_VALU_<class> x the class's "
+                        "measured issue cycles, + 8 cycles per MFMA, / (1024 SIMDs x kernel cycles)) "
                         "and matrix-pipe fraction (MFMAs x 32768 flop / launch time / 2.5 PFLOP/s dense FP16): how busy the issue ports "
-                        "are, not how much of the reference's arithmetic was avoided.  algorithmic_tflops = 53/45 flops per ray x "
+                        "are, not how much of the reference's arithmetic was avoided.  executed_fp32_tflops / fp32_peak_frac = the FP32 add, mul and "
+                        "fma instructions the kernel really executed (x 64 lanes, fma = 2) against the 157.3 TFLOP/s vector peak north_star names: "
+                        "a few per cent, because the pair tests run on the matrix cores and the rest of the issue slots go to integer bookkeeping "
+                        "and FP64.  algorithmic_tflops = 53/45 flops per ray x "
                         "triangle/rectangle pair (SURVEY.md 8d) x the pairs the launch decides / launch time; speedup_vs_all_pairs = that "
                         "over the 157.3 TFLOP/s FP32 vector peak a literal all-pairs kernel could not exceed."})
         elif n == 1:
