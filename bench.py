@@ -109,6 +109,39 @@ def cpu_baseline(world, lights, w, h, depth, seconds=13.0, seconds_n4=6.0):
                    "sample": f"rows {r04}..{r04 + nrows4 - 1} ({nrows4} of {h}), {dt4:.1f} s; the `+RTS -N4` of the reference's README:36"}}
 
 
+def cold_start_leg(workload, w, h, depth):
+    """examples/cold_start (C++, the C ABI only): every constructor call of the scene, rt_scene_prepare_device and the FIRST
+    rt_render into page-locked host memory, in a process of its own — what a one-shot caller like the reference's main
+    (Main.hs:569-621) pays.  Best of two runs; rt_init (the HIP runtime's own start-up) is reported beside it."""
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "examples", "cold_start")
+    if not os.path.exists(exe) or workload not in ("synthetic", "cylinders"):
+        return None
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import dump_scene
+    world, lights = (scenes.synthetic if workload == "synthetic" else scenes.synthetic_cylinders)()
+    runs = []
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "scene.txt")
+        dump_scene.dump(world, lights, path)
+        for _ in range(2):
+            try:
+                r = subprocess.run([exe, path, str(w), str(h), str(depth)], capture_output=True, text=True, timeout=120)
+                if r.returncode == 0:
+                    runs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+            except (subprocess.SubprocessError, ValueError, OSError):
+                pass
+    if not runs:
+        return None
+    best = min(runs, key=lambda d: d["cold_start_ms"])
+    best["note"] = ("cold_start_ms = rt_scene_create + every rt_add_* call (scene_build_ms) + rt_scene_prepare_device (host index build + one "
+                    "upload) + the first rt_render into page-locked host buffers, wall clock of examples/cold_start in a process of its own, "
+                    "best of 2; rt_init_ms is the HIP runtime's start-up, not counted; the very first process on a fresh machine pays "
+                    "~150 ms more inside the runtime's first stream creation (profiles/r03_cold_start.txt)")
+    return best
+
+
 def load_pmc(workload_key):
     """PMC readings per launch of the two big kernels for the default workload (profiles/r03_pmc.json)."""
     try:
@@ -558,6 +591,11 @@ def main():
                                                   "kernel_ms": {"k_primary": bst["ms_primary"], "k_setup": bst["ms_setup"], "k_shadow": bst["ms_shadow"], "k_final": bst["ms_final"]},
                                                   "note": "the frame `bench.py --gpus N` (N > 1) splits across ranks, on this one GPU: divide by it, not by `value`, for a scaling ratio"}
                 del big, bhit
+        if n == 1 and mfma and not args.no_extra_legs and args.spp == 1:
+            cs = cold_start_leg(args.workload, w, h, args.depth)
+            if cs:
+                out["cold_start"] = cs
+                out["cold_start_ms"] = cs["cold_start_ms"]
         if n == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(world, lights, w, h, args.depth)
         print(json.dumps(out), flush=True)

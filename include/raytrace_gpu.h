@@ -62,7 +62,8 @@ typedef void (*rt_normal_fn)(int n, const double *xy, double *normals, void *use
 /* Per-render statistics (filled by rt_get_stats after a render) */
 typedef struct {
     uint64_t primary_rays;       /* w * nrows * spp                                           */
-    uint64_t shadow_rays;        /* shadow rays actually cast (hit pixel, L.N > 0), all lights */
+    uint64_t shadow_rays;        /* shadow rays actually cast, all lights: hit pixel, L.N > 0, and a light whose
+                                    contribution to the pixel does not round to (0, 0, 0) anyway             */
     uint64_t tri_pairs;          /* ray x triangle pairs the render decided = rays x triangles (an identity, not a
                                     count: most pairs are decided 256 rays x 32 leaves at a time by a block's cone) */
     uint64_t rect_pairs;         /* ray x rectangle pairs decided, likewise                     */
@@ -218,20 +219,20 @@ int  rt_scene_prepare_device(rt_scene *, int w, int h);
  * its pieces finish, and from there to the caller's HOST buffers band by band.  Same pixels as rt_render. */
 int  rt_render_multi(rt_scene *, int w, int h, int depth, int spp, uint64_t seed, int ngpus, const int *devices,
                      uint8_t *rgba_out, int32_t *hit_id_out);
-/* The band splitter of rt_render_multi (and of raytrace_amd/distributed.py, which must agree with it): n contiguous
- * bands (row0[k], nrows[k]) of [0, h), cut at multiples of `align` rows, of about equal summed cost; `cost` is a
- * per-row estimate at any vertical resolution (ncost entries cover [0, h)).  No device needed. */
 /* Relative cost of `ncost` equal horizontal strips of the w x h frame on the calling thread's device, measured with
  * HIP events on a reduced-scale render of each strip (what rt_render_multi and bench.py cut their bands from). */
 int  rt_scene_row_costs(rt_scene *, int w, int h, int depth, int spp, int ncost, double *cost);
+/* The band splitter of rt_render_multi (and of raytrace_amd/distributed.py, which must agree with it): n contiguous
+ * bands (row0[k], nrows[k]) of [0, h), cut at multiples of `align` rows, of about equal summed cost; `cost` is a
+ * per-row estimate at any vertical resolution (ncost entries cover [0, h)).  No device needed. */
 int  rt_split_rows(const double *cost, int ncost, int h, int n, int align, int *row0, int *nrows);
 /* rt_render_device that ALLOCATES NOTHING.  No counterpart in the reference: it is for callers that cannot call
  * hipMalloc — code under HIP graph capture, tight serving loops, harnesses that forbid allocation.  Same arguments and
  * same pixels as rt_render_device; differences: the scene must already be resident on the calling thread's device for
  * this image size (rt_scene_prepare_device; RT_ERR_ARG otherwise), rt_init must have been called on this thread, and
  * every work buffer comes from a 64 MiB array in static device memory that each GPU the library runs on holds until
- * the process ends.  A band whose buffers exceed it is rendered as consecutive sub-bands that fit; an image so wide
- * that 16 rows of it do not fit (about 45 000 pixels with 4 point lights) is refused with RT_ERR_UNSUPPORTED, as are
+ * the process ends.  A band whose buffers exceed it is rendered as consecutive sub-bands that fit (multiples of 16 rows,
+ * single rows if need be); an image so wide that ONE row of it does not fit is refused with RT_ERR_UNSUPPORTED, as are
  * scenes with fnorm callbacks.  No kernel times in rt_get_stats (no events are created).  All calls on one GPU share
  * the array: calls that overlap in time on one GPU race, whatever their streams. */
 int  rt_render_device_noalloc(rt_scene *, int w, int h, int depth, int spp, uint64_t seed,

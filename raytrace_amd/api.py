@@ -341,56 +341,65 @@ class Scene:
 
     def __init__(self, world: Shape, lights, lib=None):
         self._L = lib or _lib.lib()
-        self._callbacks = []                      # keeps the ctypes callback objects alive
+        self._callbacks = {}                      # id(fnorm) -> ctypes callback object (kept alive; one thunk per distinct fnorm)
+        self._callback_error = None               # first exception an fnorm raised during a render (re-raised after it)
         h = C.c_void_p()
-        _lib.check(self._L.rt_scene_create(C.byref(h)), "rt_scene_create")
+        self._check(self._L.rt_scene_create(C.byref(h)), "rt_scene_create")
         self._h = h
         if isinstance(world, TalkDialect):        # src/Talk.hs rules; must be set before the first shape
-            _lib.check(self._L.rt_scene_set_dialect(self._h, 1), "rt_scene_set_dialect")
+            self._check(self._L.rt_scene_set_dialect(self._h, 1), "rt_scene_set_dialect")
             world = world.child
         self._add(world)
         for l in lights:
             if isinstance(l, PointLight):
-                _lib.check(self._L.rt_add_point_light(self._h, l.diffuse, l.specular, _lib.vec3(l.pos)))
+                self._check(self._L.rt_add_point_light(self._h, l.diffuse, l.specular, _lib.vec3(l.pos)))
             elif isinstance(l, Ambient):
-                _lib.check(self._L.rt_add_ambient(self._h, l.f))
+                self._check(self._L.rt_add_ambient(self._h, l.f))
             else:
                 raise TypeError(f"not a light: {l!r}")
+
+    def _check(self, rc, what=""):
+        return _lib.check(rc, what, self._L)
+
+    def _raise_callback_error(self):
+        err, self._callback_error = self._callback_error, None
+        if err is not None:
+            raise RuntimeError("an fnorm callback raised during the render; its normals were left (0, 0, 0)") from err
 
     def _add(self, s: Shape):
         L, h = self._L, self._h
         if isinstance(s, Empty):                 # mempty = mconcat []
-            _lib.check(L.rt_begin_mconcat(h))
-            _lib.check(L.rt_end_mconcat(h))
+            self._check(L.rt_begin_mconcat(h))
+            self._check(L.rt_end_mconcat(h))
             return
         if isinstance(s, Rectangle):
-            _lib.check(L.rt_add_rectangle(h, C.byref(_cmat(s.material)), _lib.vec3(s.point), _lib.vec3(s.width), _lib.vec3(s.height)))
+            self._check(L.rt_add_rectangle(h, C.byref(_cmat(s.material)), _lib.vec3(s.point), _lib.vec3(s.width), _lib.vec3(s.height)))
         elif isinstance(s, Triangle):
-            _lib.check(L.rt_add_triangle(h, C.byref(_cmat(s.material)), _lib.vec3(s.pa), _lib.vec3(s.pb), _lib.vec3(s.pc)))
+            self._check(L.rt_add_triangle(h, C.byref(_cmat(s.material)), _lib.vec3(s.pa), _lib.vec3(s.pb), _lib.vec3(s.pc)))
         elif isinstance(s, Sphere):
-            _lib.check(L.rt_add_sphere(h, C.byref(_cmat(s.material)), _lib.vec3(s.center), s.radius))
+            self._check(L.rt_add_sphere(h, C.byref(_cmat(s.material)), _lib.vec3(s.center), s.radius))
         elif isinstance(s, Cuboid):
             arr = (_lib.rt_material * len(s.materials))(*[_cmat(m) for m in s.materials])
-            _lib.check(L.rt_add_cuboid(h, arr, len(s.materials), _lib.vec3(s.point), s.l, s.h, s.d))
+            self._check(L.rt_add_cuboid(h, arr, len(s.materials), _lib.vec3(s.point), s.l, s.h, s.d))
         elif isinstance(s, Cylinder):
-            _lib.check(L.rt_add_cylinder(h, C.byref(_cmat(s.top)), C.byref(_cmat(s.bot)), C.byref(_cmat(s.mantle)),
+            self._check(L.rt_add_cylinder(h, C.byref(_cmat(s.top)), C.byref(_cmat(s.bot)), C.byref(_cmat(s.mantle)),
                                          _lib.vec3(s.point), s.n, s.h, s.r))
         elif isinstance(s, MAppend):
-            _lib.check(L.rt_begin_mappend(h))
+            self._check(L.rt_begin_mappend(h))
             self._add(s.left)
             self._add(s.right)
-            _lib.check(L.rt_end_mappend(h))
+            self._check(L.rt_end_mappend(h))
         elif isinstance(s, MConcat):
-            _lib.check(L.rt_begin_mconcat(h))
+            self._check(L.rt_begin_mconcat(h))
             for c in s.children:
                 self._add(c)
-            _lib.check(L.rt_end_mconcat(h))
+            self._check(L.rt_end_mconcat(h))
         elif isinstance(s, GaussianNormals):
             first = L.rt_scene_num_leaves(h)
             self._add(s.child)
             n = L.rt_scene_num_leaves(h) - first
             params = (C.c_double * 4)(s.scale_inv, *s.offset)
-            _lib.check(L.rt_set_normal_mode(h, first, n, 2, params, 4))
+            self._check(L.rt_set_normal_mode(h, first, n, 2, params, 4))
         elif isinstance(s, CallbackNormals):
             first = L.rt_scene_num_leaves(h)
             self._add(s.child)
@@ -398,14 +407,22 @@ class Scene:
             params = (C.c_double * 4)(s.scale_inv, *s.offset)
             fnorm = s.fnorm
 
-            def thunk(count, xy, normals, _user, fnorm=fnorm):
-                for i in range(count):
-                    v = fnorm(xy[2 * i], xy[2 * i + 1])
-                    normals[3 * i], normals[3 * i + 1], normals[3 * i + 2] = float(v[0]), float(v[1]), float(v[2])
+            cb = self._callbacks.get(id(fnorm))
+            if cb is None:
+                def thunk(count, xy, normals, _user, fnorm=fnorm):
+                    # ctypes would print an exception and carry on with (0, 0, 0) normals: keep it and re-raise after the render
+                    try:
+                        for i in range(count):
+                            v = fnorm(xy[2 * i], xy[2 * i + 1])
+                            normals[3 * i], normals[3 * i + 1], normals[3 * i + 2] = float(v[0]), float(v[1]), float(v[2])
+                    except Exception as e:          # noqa: BLE001
+                        if self._callback_error is None:
+                            self._callback_error = e
 
-            cb = _lib.NORMAL_FN(thunk)
-            self._callbacks.append(cb)
-            _lib.check(L.rt_set_normal_callback(h, first, n, params, cb, None))
+                cb = _lib.NORMAL_FN(thunk)
+                self._callbacks[id(fnorm)] = cb
+                self._callback_fns = getattr(self, "_callback_fns", []) + [fnorm]      # keeps id(fnorm) unique while the scene lives
+            self._check(L.rt_set_normal_callback(h, first, n, params, cb, None))
         else:
             raise TypeError(f"not a shape: {s!r}")
 
@@ -419,7 +436,7 @@ class Scene:
 
     def leaf(self, i):
         out = (C.c_double * 20)()
-        _lib.check(self._L.rt_scene_get_leaf(self._h, i, out))
+        self._check(self._L.rt_scene_get_leaf(self._h, i, out))
         return list(out)
 
     def render(self, w, h, depth=4, spp=1, seed=0, row0=0, nrows=None, want_rgba=True, want_hit=True,
@@ -435,24 +452,25 @@ class Scene:
         want_rgba, want_hit = want_rgba or out_rgba is not None, want_hit or out_hit is not None
         rgba = (out_rgba if out_rgba is not None else np.empty((nrows, w, 4), np.uint8)) if want_rgba else None
         hit = (out_hit if out_hit is not None else np.empty((nrows, w), np.int32)) if want_hit else None
-        _lib.check(self._L.rt_render(self._h, w, h, depth, spp, seed, row0, nrows,
+        self._check(self._L.rt_render(self._h, w, h, depth, spp, seed, row0, nrows,
                                      rgba.ctypes.data if want_rgba else None,
-                                     hit.ctypes.data if want_hit else None), "rt_render", self._L)
+                                     hit.ctypes.data if want_hit else None), "rt_render")
+        self._raise_callback_error()
         return rgba, hit
 
     def set_option(self, option, value):
         """rt_scene_set_option: _lib.RT_OPT_CULL / RT_OPT_FILTER / RT_OPT_HOST_BANDS / RT_OPT_MULTI_STAGE."""
-        _lib.check(self._L.rt_scene_set_option(self._h, option, value), "rt_scene_set_option", self._L)
+        self._check(self._L.rt_scene_set_option(self._h, option, value), "rt_scene_set_option")
         return self
 
     def prepare(self, w, h):
         """rt_scene_prepare_device: build the records and upload the scene now (keeps it out of a timed region)."""
-        _lib.check(self._L.rt_scene_prepare_device(self._h, w, h), "rt_scene_prepare_device", self._L)
+        self._check(self._L.rt_scene_prepare_device(self._h, w, h), "rt_scene_prepare_device")
 
     def row_costs(self, w, h, ncost=32, depth=4, spp=1):
         """rt_scene_row_costs: measured relative cost of ncost equal strips of the frame."""
         out = (C.c_double * ncost)()
-        _lib.check(self._L.rt_scene_row_costs(self._h, w, h, depth, spp, ncost, out), "rt_scene_row_costs", self._L)
+        self._check(self._L.rt_scene_row_costs(self._h, w, h, depth, spp, ncost, out), "rt_scene_row_costs")
         return [float(v) for v in out]
 
     def render_multi(self, w, h, devices, depth=4, spp=1, seed=0, want_rgba=True, want_hit=True):
@@ -461,27 +479,26 @@ class Scene:
         devs = (C.c_int * len(devices))(*devices)
         rgba = np.empty((h, w, 4), np.uint8) if want_rgba else None
         hit = np.empty((h, w), np.int32) if want_hit else None
-        _lib.check(self._L.rt_render_multi(self._h, w, h, depth, spp, seed, len(devices), devs,
+        self._check(self._L.rt_render_multi(self._h, w, h, depth, spp, seed, len(devices), devs,
                                            rgba.ctypes.data if want_rgba else None,
-                                           hit.ctypes.data if want_hit else None), "rt_render_multi", self._L)
+                                           hit.ctypes.data if want_hit else None), "rt_render_multi")
+        self._raise_callback_error()
         return rgba, hit
 
     def render_device(self, w, h, d_rgba, d_hit, depth=4, spp=1, seed=0, row0=0, nrows=None, stream=None):
         """Device-buffer render (rt_render_device); d_rgba/d_hit are device addresses (int) or None."""
         nrows = h - row0 if nrows is None else nrows
-        _lib.check(self._L.rt_render_device(self._h, w, h, depth, spp, seed, row0, nrows, d_rgba, d_hit, stream),
-                   "rt_render_device", self._L)
+        self._check(self._L.rt_render_device(self._h, w, h, depth, spp, seed, row0, nrows, d_rgba, d_hit, stream), "rt_render_device")
 
     def render_device_noalloc(self, w, h, d_rgba, d_hit, depth=4, spp=1, seed=0, row0=0, nrows=None, stream=None):
         """rt_render_device_noalloc: as render_device, but allocates nothing (static device scratch); the scene must
         have been made resident with prepare(w, h)."""
         nrows = h - row0 if nrows is None else nrows
-        _lib.check(self._L.rt_render_device_noalloc(self._h, w, h, depth, spp, seed, row0, nrows, d_rgba, d_hit, stream),
-                   "rt_render_device_noalloc", self._L)
+        self._check(self._L.rt_render_device_noalloc(self._h, w, h, depth, spp, seed, row0, nrows, d_rgba, d_hit, stream), "rt_render_device_noalloc")
 
     def stats(self):
         st = _lib.rt_stats()
-        _lib.check(self._L.rt_get_stats(self._h, C.byref(st)))
+        self._check(self._L.rt_get_stats(self._h, C.byref(st)))
         return {k: getattr(st, k) for k, _ in st._fields_}
 
     def close(self):

@@ -17,7 +17,7 @@ constexpr int RT_MAX_DEVICES = 16;       // HIP devices one process may render o
 constexpr int RT_HOST_BANDS_MAX = 8;     // copy bands of rt_render
 constexpr int RT_MAX_LEVELS = 64;        // bounce levels kept for the fold of the colours (trace depth with mirrors)
 
-// One uploaded array: capacity is kept, so a re-upload of the same size neither frees nor allocates.
+// One uploaded array (a view of DeviceScene::arena) or one allocation with its capacity.
 struct DevBuf { void *p = nullptr; size_t cap = 0; };
 
 // Device memory of one render beyond its inputs and outputs.  rt_render / rt_render_device grow it on demand
@@ -25,7 +25,7 @@ struct DevBuf { void *p = nullptr; size_t cap = 0; };
 // array instead (rt_kernels.hip: `scratch`).
 struct Workspace {
     unsigned long long *counters = nullptr;  // RT_STAT_SLOTS x 16 x u64
-    unsigned *qcount = nullptr;              // shadow jobs per point light [0..31]; rays per bounce level [32..63]
+    unsigned *qcount = nullptr;              // shadow jobs per point light [0..31]; rays per bounce level [32..96]; callback count; lights' cost history
     int32_t *hit_id = nullptr;               // per band pixel (only when the caller gives no buffer, or spp > 1)
     uint32_t *accum = nullptr;               // spp > 1: 3 x u32 per band pixel
     char *hitrec = nullptr;                  // per chunk pixel: 48-byte HitRec
@@ -46,6 +46,8 @@ struct DeviceScene {          // the scene on ONE device (HBM), owned by the rt_
     int device = -1;
     uint64_t version = 0;            // rt_scene::version of the uploaded copy (0: nothing uploaded)
     uint64_t eye_version = 0;        // rt_scene::eye_version of the uploaded eye-apex records
+    DevBuf arena;                    // ONE allocation: every array below is a view of it (device_prepare)
+    DevBuf ws_arena;                 // ONE allocation: the work buffers `ws` are views of it (ws_grow)
     DevBuf leaves, aux, guards, mats, lights;
     DevBuf tri_rec, rect_rec;        // (1 + npoint) blocks of ntri / nrect records: eye, then each point light (VALU filter build)
     DevBuf tri_gid, rect_gid;        // per-type slot -> leaf index
@@ -55,6 +57,7 @@ struct DeviceScene {          // the scene on ONE device (HBM), owned by the rt_
     DevBuf gen_tri_gid, gen_rect_gid, gen_tri_sph, gen_rect_sph;   // that order's leaf indices; bounding spheres of its blocks of 32
     DevBuf gen_tri_rows, gen_rect_rows;                            // the blocks' matrix-core rows (leaf bounding spheres as linear forms)
     DevBuf gen_tri_ssph, gen_rect_ssph;                            // super-blocks of 32 blocks: bounding sphere = the frame of their rows
+    void *helper = nullptr;          // rt_kernels.hip: Helper — the thread that makes the streams beside the first host index build
     void *stream = nullptr;          // hipStream_t: renders of this scene on this device (when the caller passes none)
     void *copy_stream = nullptr;     // hipStream_t: rt_render's copies to host memory, band by band; rt_render_multi's peer copies
     void *copy_stream2 = nullptr;    // hipStream_t: rt_render_multi's copies from the home device to host memory
@@ -62,9 +65,6 @@ struct DeviceScene {          // the scene on ONE device (HBM), owned by the rt_
     void *hits_done[RT_HOST_BANDS_MAX] = {};   // hipEvent_t: the band's hit-ID buffer is complete (rt_render copies it early)
     // work buffers of rt_render / rt_render_device, grown on demand
     Workspace ws;
-    size_t hit_id_cap = 0, accum_cap = 0, hitrec_cap = 0, queue_cap = 0, qsparse_cap = 0, tcount_cap = 0, lit_cap = 0;
-    size_t lvl_rays_cap[RT_MAX_LEVELS] = {}, lvl_hit_cap[RT_MAX_LEVELS] = {}, lvl_col_cap[RT_MAX_LEVELS] = {};
-    size_t cb_cap[4] = {};
     uint8_t *rgba = nullptr;    size_t rgba_cap = 0;       // rt_render (host buffers) staging
     int32_t *hit_out = nullptr; size_t hit_out_cap = 0;
     uint8_t *stage_rgba = nullptr; size_t stage_rgba_cap = 0;   // rt_render_multi: this device's bands before the peer copy

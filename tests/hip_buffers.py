@@ -41,6 +41,10 @@ class DeviceBuffer:
         self.ptr = p.value
         if hip().hipMemset(self.ptr, fill, max(self.nbytes, 1)) != 0:
             raise RuntimeError("hipMemset failed")
+        # the fill runs on the null stream; the library renders on a non-blocking stream of its own, which the null stream
+        # does not order: the fill is complete before anything can overwrite it
+        if hip().hipDeviceSynchronize() != 0:
+            raise RuntimeError("hipDeviceSynchronize failed")
 
     def numpy(self):
         if hip().hipDeviceSynchronize() != 0:

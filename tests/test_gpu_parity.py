@@ -590,3 +590,15 @@ def test_stack_of_walls(gpu_lib):
              for k in range(24)]
     lights = api.mconcat_lights([api.pointLight(0.5, 0.4, (3.0, 4.0, 2.0)), api.ambient(0.2)])
     compare(api.mconcat(walls), lights, 160, 100, label="stack-of-walls")
+
+
+def test_an_fnorm_that_raises_is_reported(gpu_lib):
+    """A Python fnorm that raises must not leave a 'successful' render with (0, 0, 0) normals behind (ctypes would only
+    print the traceback): the exception comes back from render()."""
+    def bad(x, y):
+        raise ZeroDivisionError("fnorm failed")
+    world, lights = api.linearInterpolation(api.gaussian, bad, (-1.0, -1.0), (1.0, 1.0), 0.5, (0.01, -7.0, -25.0), 10.0)
+    sc = api.Scene(world, lights)
+    with pytest.raises(RuntimeError, match="fnorm callback raised"):
+        sc.render(96, 96)
+    sc.close()
