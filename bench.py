@@ -42,7 +42,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from raytrace_amd import api, scenes, _lib  # noqa: E402
-from raytrace_amd.distributed import gather_bands, split_rows, sub_bands  # noqa: E402
+from raytrace_amd.distributed import gather_bands, piece_fractions, plan_frame, split_rows, sub_bands  # noqa: E402
 
 FLOPS_TRI, FLOPS_RECT = 52 + 1, 44 + 1
 PEAK_FP32_TFLOPS = 157.3                        # MI355X_MICROARCH.md: peak FP32 (vector), packed FMA
@@ -228,7 +228,9 @@ def main():
     ap.add_argument("--no-cull", action="store_true", help="every wave scans every block of the leaf stream: the plain all-pairs scan")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the measured path) or gloo (rehearsal on one GPU)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank renders on GPU 0 (gloo only)")
-    ap.add_argument("--pieces", type=int, default=0, help="N > 1: pieces per band (0 = from the band's render time, about 1 ms each, at most 4)")
+    ap.add_argument("--pieces", type=int, default=0, help="N > 1: pieces per band (0 = what the pipeline model picks: raytrace_amd/distributed.py plan_frame)")
+    ap.add_argument("--link-gbps", type=float, default=48.0, help="N > 1: what the model assumes one xGMI link carries in one direction under ncclSend/ncclRecv (GB/s)")
+    ap.add_argument("--piece-overhead-ms", type=float, default=0.05, help="N > 1: what the model charges per piece for its launches and kernel tails")
     ap.add_argument("--verify", action="store_true", help="rank 0 re-renders the whole frame alone and compares it with the gathered one")
     args = ap.parse_args()
 
@@ -314,8 +316,13 @@ def main():
             info = info.to(dev)
             dist.broadcast(info, 0)
             info = info.cpu()
-        bands = split_rows(info[:32].numpy(), h, n)
         n1_same_frame_ms = float(info[32])
+        # the frame on paper first (every rank computes the same plan): pieces per band and their sizes, rank 0's larger share
+        plan_parts, plan_fr, plan_weights, predicted_ms, plan_detail = plan_frame(
+            n1_same_frame_ms, n, float(w) * h * 4 / n, args.link_gbps, args.piece_overhead_ms)
+        if args.pieces > 0:
+            plan_parts, plan_fr = args.pieces, piece_fractions(args.pieces)
+        bands = split_rows(info[:32].numpy(), h, n, weights=plan_weights)
     row0, nrows = bands[rank]
     # frame buffer: rank 0 owns the whole image (bands of the other ranks land in it), others own a band
     frame = torch.empty((h if rank == 0 else nrows, w, 4), dtype=torch.uint8, device=dev)
@@ -329,11 +336,8 @@ def main():
     # every band is rendered in `pieces` consecutive pieces; piece k of all peers travels to GPU 0 in one group
     # of send/recv while piece k+1 renders, so only the last piece's exchange is exposed.  A piece should take about
     # a millisecond: 6 kernel launches and their tails are then a few per cent of it.
-    if n > 1:
-        pieces = args.pieces if args.pieces > 0 else max(1, min(4, int(n1_same_frame_ms / n / 1.0)))
-    else:
-        pieces = 1
-    subs = [sub_bands(b, pieces) for b in bands]
+    pieces = plan_parts if n > 1 else 1
+    subs = [sub_bands(b, pieces, fractions=plan_fr if n > 1 else None) for b in bands]
     # (the three events of a step are made once and recorded again every step: the last step's are the ones read)
     marks = {k: torch.cuda.Event(enable_timing=True) for k in ("start", "rendered", "end")}
     frame_ptr, hit_ptr = mine.data_ptr(), hit.data_ptr()
@@ -379,7 +383,15 @@ def main():
 
     # The chip comes out of idle at a low clock and the order of the lights in k_shadow_mfma settles after a few frames:
     # PREWARM untimed frames before the W warm-up steps of the contract (reported in the line as `untimed_frames_before_warmup`).
-    for _ in range(PREWARM):
+    # what a caller sees who renders a few frames and stops: ONE warm-up frame, then 5 timed ones, before anything else has run
+    step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        step()
+    sync()
+    ms_after_one_warmup = (time.perf_counter() - t0) / 5 * 1e3
+    for _ in range(max(0, PREWARM - 6)):
         step()
     for _ in range(args.warmup):
         step()
@@ -509,6 +521,7 @@ def main():
         out = {
             "metric": "primary Mrays/s (whole node)", "value": primary / (dt / args.steps) / 1e6, "unit": "Mrays/s",
             "n_gpus": n, "steps": args.steps, "warmup": args.warmup, "untimed_frames_before_warmup": PREWARM, "ms_per_step": ms_step,
+            "ms_per_step_after_one_warmup": ms_after_one_warmup,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{wname} ({nleaves} leaves), {nlt} point light(s) + ambient, "
@@ -528,7 +541,12 @@ def main():
         if n > 1:
             out["distributed"] = {
                 "backend": "RCCL (torch.distributed nccl)" if not staged else "gloo (rehearsal, bands staged through host memory)",
-                "world_size": dist.get_world_size(), "bands": bands, "pieces_per_band": pieces,
+                "world_size": dist.get_world_size(), "bands": bands, "pieces_per_band": pieces, "piece_fractions": plan_fr,
+                "model": {"predicted_step_ms": predicted_ms, "predicted_speedup_vs_n1_same_frame": n1_same_frame_ms / predicted_ms,
+                          "link_gbps_assumed": args.link_gbps, "piece_overhead_ms_assumed": args.piece_overhead_ms,
+                          "band_weights": plan_weights, **plan_detail,
+                          "note": "raytrace_amd/distributed.py plan_frame: a sender renders its pieces back to back and its own xGMI link to GPU 0 carries "
+                                  "piece i as soon as it is rendered and piece i - 1 has arrived; rank 0 sends nothing and renders a larger band"},
                 "rank_render_ms": [float(v) for v in per_rank[:, 0].tolist()],
                 "rank_step_ms": [float(v) for v in per_rank[:, 1].tolist()],
                 "exposed_gather_ms": float(per_rank[0, 1] - per_rank[:, 0].max()),

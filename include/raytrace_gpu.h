@@ -81,6 +81,8 @@ typedef struct {
     uint64_t bounce_blocks;       /* (run of 64 reflected rays) x (block of 32 leaves) pairs k_general looked at */
     double   prepare_ms;          /* host time of the last rebuild of guard chains and filter records */
     double   upload_ms;           /* host time of the last upload of the scene to this device       */
+    uint64_t multi_bands_direct;  /* rt_render_multi: bands copied to devices[0] with peer access enabled (xGMI DMA)    */
+    uint64_t multi_bands_staged;  /* ... without (hipMemcpyPeerAsync then stages through host memory); 0 + 0: not a multi render */
 } rt_stats;
 
 /* ---- library / device ------------------------------------------------------------------- */
@@ -226,6 +228,10 @@ int  rt_scene_row_costs(rt_scene *, int w, int h, int depth, int spp, int ncost,
  * bands (row0[k], nrows[k]) of [0, h), cut at multiples of `align` rows, of about equal summed cost; `cost` is a
  * per-row estimate at any vertical resolution (ncost entries cover [0, h)).  No device needed. */
 int  rt_split_rows(const double *cost, int ncost, int h, int n, int align, int *row0, int *nrows);
+/* The same with unequal shares: band k gets weights[k] / sum(weights) of the cost (NULL: equal).  The device that collects
+ * the bands sends nothing and so may render longer than the ones whose last piece still has to travel: rt_render_multi and
+ * bench.py give it the weight their pipeline model works out (raytrace_amd/distributed.py: plan_frame). */
+int  rt_split_rows_weighted(const double *cost, int ncost, int h, int n, int align, const double *weights, int *row0, int *nrows);
 /* rt_render_device that ALLOCATES NOTHING.  No counterpart in the reference: it is for callers that cannot call
  * hipMalloc — code under HIP graph capture, tight serving loops, harnesses that forbid allocation.  Same arguments and
  * same pixels as rt_render_device; differences: the scene must already be resident on the calling thread's device for

@@ -21,7 +21,8 @@ class rt_stats(C.Structure):
                 ("rect_pairs", C.c_uint64), ("exact_evals", C.c_uint64), ("ms_primary", C.c_double),
                 ("ms_setup", C.c_double), ("ms_shadow", C.c_double), ("ms_final", C.c_double), ("ms_total", C.c_double),
                 ("mfma_blocks_primary", C.c_uint64), ("mfma_blocks_shadow", C.c_uint64),
-                ("record_tests", C.c_uint64), ("bounce_rays", C.c_uint64), ("bounce_blocks", C.c_uint64), ("prepare_ms", C.c_double), ("upload_ms", C.c_double)]
+                ("record_tests", C.c_uint64), ("bounce_rays", C.c_uint64), ("bounce_blocks", C.c_uint64), ("prepare_ms", C.c_double), ("upload_ms", C.c_double),
+                ("multi_bands_direct", C.c_uint64), ("multi_bands_staged", C.c_uint64)]
 
 
 # an `fnorm` closure as a C callback: void fn(int n, const double *xy, double *normals, void *user)
@@ -46,6 +47,7 @@ SYMBOLS = {
     "rt_scene_prepare_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "rt_scene_row_costs": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _D3]),
     "rt_split_rows": (C.c_int, [_D3, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "rt_split_rows_weighted": (C.c_int, [_D3, C.c_int, C.c_int, C.c_int, C.c_int, _D3, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "rt_render_multi": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, C.POINTER(C.c_int),
                                   C.c_void_p, C.c_void_p]),
     "rt_add_rectangle": (C.c_int, [C.c_void_p, _MAT, _D3, _D3, _D3]),

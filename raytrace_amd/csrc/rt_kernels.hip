@@ -3257,11 +3257,16 @@ int row_costs(rt_scene *s, int device, int w, int h, int depth, int spp, int nco
     return RT_OK;
 }
 
-void sub_bands(int r0, int nr, int parts, int align, int *p0, int *pn) {   // port of raytrace_amd/distributed.py: sub_bands
+// port of raytrace_amd/distributed.py: sub_bands with the piece sizes of piece_fractions (1 : 2 : ... : 2 : 1 — a small
+// first piece puts data on the link early, a small last one leaves little travelling when the render has ended)
+void sub_bands(int r0, int nr, int parts, int align, int *p0, int *pn) {
     const int units = (nr + align - 1) / align;
+    double total = 0, run = 0;
+    for (int k = 0; k < parts; ++k) total += (parts <= 2 || (k > 0 && k + 1 < parts)) ? 2.0 : 1.0;
     int done = 0;
     for (int k = 0; k < parts; ++k) {
-        const int upto = k + 1 < parts ? std::min(nr, (int)((long long)units * (k + 1) / parts) * align) : nr;
+        run += (parts <= 2 || (k > 0 && k + 1 < parts)) ? 2.0 : 1.0;
+        const int upto = k + 1 < parts ? std::min(nr, std::max(done, (int)((double)units * (run / total) + 0.5) * align)) : nr;
         p0[k] = r0 + done; pn[k] = upto - done;
         done = upto;
     }
@@ -3297,8 +3302,9 @@ extern "C" int rt_render_multi(rt_scene *s, int w, int h, int depth, int spp, ui
     struct Band { int dev, row0, nrows; size_t stage_off; bool staged; int p0[PIECES], pn[PIECES]; };
     Band band[RT_MAX_DEVICES];
     std::vector<hipEvent_t> ev;            // per (band, piece): rendered, arrived on the home device
-    bool first_on[RT_MAX_DEVICES];
+    bool first_on[RT_MAX_DEVICES], peer_ok[RT_MAX_DEVICES];
     for (bool &f : first_on) f = true;
+    for (bool &f : peer_ok) f = false;
     auto finish = [&](int code) {          // drain every stream that was used, restore the caller's device
         for (int k = 0; k < ngpus; ++k) {
             DeviceScene &D = s->dev[devs[k]];
@@ -3329,7 +3335,12 @@ extern "C" int rt_render_multi(rt_scene *s, int w, int h, int depth, int spp, ui
             const uint64_t key[5] = {s->version, (uint64_t)w, (uint64_t)h, (uint64_t)depth, (uint64_t)spp};
             std::copy(key, key + 5, s->multi_cost_key);
         }
-        split_rows(s->multi_cost.data(), ncost, h, ngpus, RT_TILE_H, b0, bn);
+        // devices[0] collects: it sends nothing, so it may render while the others' last pieces travel — one more of
+        // the PIECES * 3/2 - 1 units a band's pieces are made of (distributed.py: plan_frame has the long form)
+        double weight[RT_MAX_DEVICES];
+        for (int k = 0; k < ngpus; ++k) weight[k] = 1.0;
+        if (devs[0] != devs[ngpus - 1] || ngpus > 1) weight[0] = 1.0 + 1.0 / (2.0 * (PIECES - 1));
+        split_rows(s->multi_cost.data(), ncost, h, ngpus, RT_TILE_H, b0, bn, weight);
     }
     // 2. buffers: the whole frame on the home device, a staging buffer per other device
     if (rgba_out && (rc = ensure(H.rgba, H.rgba_cap, 4 * npix))) return finish(rc);
@@ -3354,37 +3365,62 @@ extern "C" int rt_render_multi(rt_scene *s, int w, int h, int depth, int spp, ui
         if ((rc = ensure(D.stage_hit, D.stage_hit_cap, stage_pix[d]))) return finish(rc);
         if (d != home) {                  // direct xGMI copies into the home device's memory
             const hipError_t e = hipDeviceEnablePeerAccess(home, 0);
-            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();   // falls back to staged copies
-            else (void)hipGetLastError();
+            peer_ok[d] = e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled;   // else hipMemcpyPeerAsync stages through the host
+            (void)hipGetLastError();
         }
     }
-    // 3. piece p of every band is enqueued before piece p + 1 of any: all devices work at once, and a piece travels to
-    // the home device (peer-to-peer over xGMI, on the band's copy stream) while the next one renders
+    // 3. every device is driven by a host thread of its own (enqueueing 6 kernels per piece costs the host ~0.1 ms: from
+    // one thread, 8 devices x 4 pieces would take as long as a device needs for its whole band); a device's pieces are
+    // enqueued in order, and a piece travels to the home device (peer-to-peer over xGMI, on the band's copy stream) while
+    // the next one renders.  Scenes with fnorm callbacks stay on this thread (the caller's closure is not ours to run
+    // concurrently).
     ev.assign((size_t)ngpus * PIECES * 2, nullptr);
-    for (int p = 0; p < PIECES; ++p)
-        for (int k = 0; k < ngpus; ++k) {
-            Band &B = band[k];
-            if (B.pn[p] <= 0) continue;
-            if ((rc = device_init(B.dev))) return finish(rc);
-            DeviceScene &D = s->dev[B.dev];
-            const size_t foff = (size_t)B.p0[p] * (size_t)w, n = (size_t)B.pn[p] * (size_t)w;
-            const size_t soff = B.stage_off + (size_t)(B.p0[p] - B.row0) * (size_t)w;
-            uint8_t *dst = !rgba_out ? nullptr : (B.staged ? D.stage_rgba + 4 * soff : H.rgba + 4 * foff);
-            int32_t *dhit = B.staged ? D.stage_hit + soff : H.hit_out + foff;
-            if ((rc = render_band(s, B.dev, w, h, depth, spp, seed, B.p0[p], B.pn[p], dst, dhit, (hipStream_t)D.stream, !first_on[B.dev]))) return finish(rc);
-            first_on[B.dev] = false;
-            hipEvent_t &er = ev[((size_t)k * PIECES + p) * 2], &ea = ev[((size_t)k * PIECES + p) * 2 + 1];
-            if (!hip_ok(hipEventCreateWithFlags(&er, hipEventDisableTiming), "hipEventCreate") ||
-                !hip_ok(hipEventRecord(er, (hipStream_t)D.stream), "hipEventRecord")) return finish(RT_ERR_HIP);
-            if (B.staged) {
-                hipStream_t cs = (hipStream_t)D.copy_stream;
-                if (!hip_ok(hipStreamWaitEvent(cs, er, 0), "hipStreamWaitEvent")) return finish(RT_ERR_HIP);
-                if (rgba_out && !hip_ok(hipMemcpyPeerAsync(H.rgba + 4 * foff, home, dst, B.dev, 4 * n, cs), "hipMemcpyPeerAsync")) return finish(RT_ERR_HIP);
-                if (!hip_ok(hipMemcpyPeerAsync(H.hit_out + foff, home, dhit, B.dev, n * sizeof(int32_t), cs), "hipMemcpyPeerAsync")) return finish(RT_ERR_HIP);
-                if (!hip_ok(hipEventCreateWithFlags(&ea, hipEventDisableTiming), "hipEventCreate") ||
-                    !hip_ok(hipEventRecord(ea, cs), "hipEventRecord")) return finish(RT_ERR_HIP);
+    for (size_t i = 0; i < ev.size(); ++i)
+        if (!hip_ok(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming), "hipEventCreate")) return finish(RT_ERR_HIP);
+    auto drive = [&](int dev, std::string &err) -> int {        // all bands of one device, piece by piece
+        int rc2;
+        if ((rc2 = device_init(dev))) { err = rt_last_error(); return rc2; }
+        DeviceScene &D = s->dev[dev];
+        bool first = true;
+        for (int p = 0; p < PIECES; ++p)
+            for (int k = 0; k < ngpus; ++k) {
+                Band &B = band[k];
+                if (B.dev != dev || B.pn[p] <= 0) continue;
+                const size_t foff = (size_t)B.p0[p] * (size_t)w, n = (size_t)B.pn[p] * (size_t)w;
+                const size_t soff = B.stage_off + (size_t)(B.p0[p] - B.row0) * (size_t)w;
+                uint8_t *dst = !rgba_out ? nullptr : (B.staged ? D.stage_rgba + 4 * soff : H.rgba + 4 * foff);
+                int32_t *dhit = B.staged ? D.stage_hit + soff : H.hit_out + foff;
+                if ((rc2 = render_band(s, dev, w, h, depth, spp, seed, B.p0[p], B.pn[p], dst, dhit, (hipStream_t)D.stream, !first))) { err = rt_last_error(); return rc2; }
+                first = false;
+                first_on[dev] = false;
+                hipEvent_t er = ev[((size_t)k * PIECES + p) * 2], ea = ev[((size_t)k * PIECES + p) * 2 + 1];
+                bool ok = hip_ok(hipEventRecord(er, (hipStream_t)D.stream), "hipEventRecord");
+                if (ok && B.staged) {
+                    hipStream_t cs = (hipStream_t)D.copy_stream;
+                    ok = hip_ok(hipStreamWaitEvent(cs, er, 0), "hipStreamWaitEvent") &&
+                         (!rgba_out || hip_ok(hipMemcpyPeerAsync(H.rgba + 4 * foff, home, dst, dev, 4 * n, cs), "hipMemcpyPeerAsync")) &&
+                         hip_ok(hipMemcpyPeerAsync(H.hit_out + foff, home, dhit, dev, n * sizeof(int32_t), cs), "hipMemcpyPeerAsync") &&
+                         hip_ok(hipEventRecord(ea, cs), "hipEventRecord");
+                }
+                if (!ok) { err = rt_last_error(); return RT_ERR_HIP; }
             }
+        return RT_OK;
+    };
+    {
+        int distinct[RT_MAX_DEVICES], nd = 0;
+        for (int k = 0; k < ngpus; ++k) { bool seen = false; for (int j = 0; j < nd; ++j) seen |= distinct[j] == devs[k]; if (!seen) distinct[nd++] = devs[k]; }
+        int rcs[RT_MAX_DEVICES] = {0};
+        std::string errs[RT_MAX_DEVICES];
+        if (nd > 1 && s->normal_fn.empty()) {
+            std::vector<std::thread> workers;
+            for (int j = 1; j < nd; ++j) workers.emplace_back([&, j] { rcs[j] = drive(distinct[j], errs[j]); });
+            rcs[0] = drive(distinct[0], errs[0]);
+            for (std::thread &t : workers) t.join();
+        } else {
+            for (int j = 0; j < nd && (j == 0 || rcs[j - 1] == RT_OK); ++j) rcs[j] = drive(distinct[j], errs[j]);
         }
+        for (int j = 0; j < nd; ++j) if (rcs[j] != RT_OK) { set_error(errs[j]); return finish(rcs[j]); }
+    }
     // 4. from the home device to the caller's memory, piece by piece as they arrive
     if ((rc = device_init(home))) return finish(rc);
     for (int p = 0; p < PIECES; ++p)
@@ -3417,6 +3453,10 @@ extern "C" int rt_render_multi(rt_scene *s, int w, int h, int depth, int spp, ui
         tot.ms_total = std::max(tot.ms_total, st.ms_total); tot.upload_ms = std::max(tot.upload_ms, st.upload_ms);
     }
     tot.prepare_ms = s->prepare_ms;
+    for (int k = 0; k < ngpus; ++k) {          // how the bands reached devices[0]
+        if (devs[k] == home) continue;
+        if (peer_ok[devs[k]]) ++tot.multi_bands_direct; else ++tot.multi_bands_staged;
+    }
     s->stats_multi = tot;
     s->multi_stats = true;
     if (caller >= 0) (void)hipSetDevice(caller);

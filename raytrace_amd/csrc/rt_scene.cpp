@@ -1018,7 +1018,7 @@ bool host_ready(const rt_scene &s, int w, int h) {
 }
 
 // C port of raytrace_amd/distributed.py: split_rows (the two must agree; tests/test_host_scene.py compares them).
-void split_rows(const double *cost_in, int ncost, int h, int n, int align, int *row0, int *nrows) {
+void split_rows(const double *cost_in, int ncost, int h, int n, int align, int *row0, int *nrows, const double *weights) {
     std::vector<double> cost(cost_in, cost_in + ncost);
     double tot = 0;
     for (double c : cost) tot += c;
@@ -1027,9 +1027,15 @@ void split_rows(const double *cost_in, int ncost, int h, int n, int align, int *
     for (int i = 0; i < ncost; ++i) cum[i + 1] = cum[i] + cost[i];
     const double total = cum[ncost];
     for (double &c : cum) c /= total;
+    std::vector<double> target(n + 1, 0.0);               // cumulative share of the cost at every cut
+    if (weights) {
+        double wsum = 0, run = 0;
+        for (int k = 0; k < n; ++k) wsum += weights[k];
+        for (int k = 0; k < n; ++k) { run += weights[k]; target[k + 1] = run / wsum; }
+    } else for (int k = 0; k <= n; ++k) target[k] = (double)k / (double)n;
     std::vector<int> cuts(1, 0);
     for (int k = 1; k < n; ++k) {
-        const double x = (double)k / (double)n;
+        const double x = target[k];
         // numpy.interp(x, cum, 0..ncost): the last j with cum[j] <= x, linear inside [cum[j], cum[j+1]]
         double pos;
         if (x >= cum[ncost]) pos = (double)ncost;
@@ -1088,9 +1094,14 @@ int rt_scene_set_option(rt_scene *s, int option, int value) {
 }
 
 int rt_split_rows(const double *cost, int ncost, int h, int n, int align, int *row0, int *nrows) {
+    return rt_split_rows_weighted(cost, ncost, h, n, align, nullptr, row0, nrows);
+}
+
+int rt_split_rows_weighted(const double *cost, int ncost, int h, int n, int align, const double *weights, int *row0, int *nrows) {
     if (!cost || !row0 || !nrows || ncost < 1 || h < 0 || n < 1 || align < 1) { set_error("rt_split_rows: bad argument"); return RT_ERR_ARG; }
     for (int i = 0; i < ncost; ++i) if (!(cost[i] >= 0)) { set_error("rt_split_rows: cost must be non-negative"); return RT_ERR_ARG; }
-    split_rows(cost, ncost, h, n, align, row0, nrows);
+    if (weights) for (int k = 0; k < n; ++k) if (!(weights[k] > 0)) { set_error("rt_split_rows: weights must be positive"); return RT_ERR_ARG; }
+    split_rows(cost, ncost, h, n, align, row0, nrows, weights);
     return RT_OK;
 }
 

@@ -149,7 +149,8 @@ bool host_ready(const rt_scene &s, int w, int h);
 // (Re)build the FP32 filter records for the eye of a w x h camera and for every point light.
 void build_filter_records(rt_scene &s, int w, int h, bool eye_only = false);
 // Contiguous row bands of about equal cost (C port of raytrace_amd/distributed.py: split_rows).
-void split_rows(const double *cost, int ncost, int h, int n, int align, int *row0, int *nrows);
+// weights (n positive numbers, or nullptr for equal ones): band k's share of the summed cost.
+void split_rows(const double *cost, int ncost, int h, int n, int align, int *row0, int *nrows, const double *weights = nullptr);
 // Compute every leaf's guard box from the bracket tree; false (and set_error) on an open bracket.
 bool compute_guards(rt_scene &s);
 

@@ -11,7 +11,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from raytrace_amd.distributed import gather_bands, split_rows, sub_bands
+from raytrace_amd.distributed import gather_bands, piece_fractions, plan_frame, predict_step_ms, split_rows, sub_bands
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -46,6 +46,43 @@ def test_sub_bands_properties():
         sub_bands((0, 8), 0)
 
 
+def test_weighted_split_and_shaped_pieces():
+    cost = np.concatenate([np.ones(40), 3 * np.ones(50), np.ones(38)])
+    h = 16384
+    eq = split_rows(cost, h, 8)
+    wt = split_rows(cost, h, 8, weights=[1.25] + [1.0] * 7)
+    assert wt[0][1] > eq[0][1] and sum(nr for _, nr in wt) == h and all(r0 % 8 == 0 for r0, _ in wt)
+    per_row = np.repeat(cost, h // len(cost))
+    c = [per_row[r0:r0 + nr].sum() for r0, nr in wt]
+    assert abs(c[0] / np.mean(c[1:]) - 1.25) < 0.03            # rank 0's band costs a quarter more than the others'
+    assert split_rows(cost, h, 8, weights=[1.0] * 8) == eq
+    with pytest.raises(ValueError):
+        split_rows(cost, h, 8, weights=[1.0] * 7)
+    # pieces 1 : 2 : 2 : 1
+    assert piece_fractions(1) == [1.0] and piece_fractions(2) == [0.5, 0.5]
+    assert np.allclose(piece_fractions(4), [1 / 6, 2 / 6, 2 / 6, 1 / 6])
+    sb = sub_bands((2048, 2040), 4, fractions=piece_fractions(4))
+    assert sb[0][0] == 2048 and sum(nr for _, nr in sb) == 2040 and [nr for _, nr in sb] == [344, 680, 680, 336]
+    for band, parts in [((0, 8), 4), ((16, 20), 3), ((0, 0), 2), ((24, 1000), 7), ((0, 1), 1)]:
+        sb = sub_bands(band, parts, fractions=piece_fractions(parts))
+        assert len(sb) == parts and sb[0][0] == band[0] and sum(nr for _, nr in sb) == band[1] and all(nr >= 0 for _, nr in sb)
+        assert all(nr == 0 or (r0 - band[0]) % 8 == 0 for r0, nr in sb)
+
+
+def test_pipeline_model():
+    # one piece: nothing overlaps; many small pieces: the slower of link and render plus one piece of the other
+    assert predict_step_ms(3.0, 2.0, [1.0], 0.0) == 5.0
+    assert abs(predict_step_ms(3.0, 2.0, [0.25] * 4, 0.0) - 3.5) < 1e-12            # render-bound: + the last quarter on the link
+    assert abs(predict_step_ms(2.0, 3.0, [0.25] * 4, 0.0) - 3.5) < 1e-12            # link-bound: + the first quarter's render
+    # the 16384 x 16384 frame of configs[3] on 8 GPUs: 23.6 ms on one GPU, 134 MB per sender
+    parts, fr, weights, t, detail = plan_frame(23.6, 8, 16384 * 16384 * 4 / 8, 48.0, 0.05)
+    assert parts >= 3 and abs(sum(fr) - 1) < 1e-12 and weights[0] > 1.0 and weights[1:] == [1.0] * 7
+    assert 23.6 / t > 6.0 and t >= detail["render_ms"]           # what the plan promises at these assumptions
+    faster = plan_frame(23.6, 8, 16384 * 16384 * 4 / 8, 64.0, 0.05)[3]
+    assert faster < t
+    assert plan_frame(5.0, 1, 1e6, 48.0)[3] == 5.0
+
+
 def _worker(rank, world, port, out_path):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -70,7 +107,7 @@ def _worker(rank, world, port, out_path):
     # the same frame again the way bench.py does it: every band in 3 pieces, piece k of both ranks in group k,
     # nothing waited on until the last piece has been handed over
     piped = torch.zeros((h, w, 3), dtype=torch.uint8) if rank == 0 else None
-    subs = [sub_bands(b, 3) for b in bands]
+    subs = [sub_bands(b, 3, fractions=piece_fractions(3)) for b in split_rows(1.0 + 2.0 * (coarse >= 0).mean(axis=1), h, world, weights=[1.5, 1.0])]
     pending, keep = [], []
     for k in range(3):
         p0, pn = subs[rank][k]

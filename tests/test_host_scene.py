@@ -225,7 +225,13 @@ def test_c_band_splitter_agrees_with_split_rows():
         assert L.rt_split_rows((C.c_double * ncost)(*cost), ncost, h, n, align, r0, nr) == 0
         assert list(zip(r0, nr)) == split_rows(cost, h, n, align), (trial, ncost, h, n, align)
         assert sum(nr) == h and r0[0] == 0 and all(r0[k] + nr[k] == r0[k + 1] for k in range(n - 1))
+        # ... and with unequal shares (the collecting device's larger band)
+        weights = rng.uniform(0.5, 2.0, n)
+        assert L.rt_split_rows_weighted((C.c_double * ncost)(*cost), ncost, h, n, align, (C.c_double * n)(*weights), r0, nr) == 0
+        assert list(zip(r0, nr)) == split_rows(cost, h, n, align, weights=weights), (trial, "weighted", ncost, h, n, align)
+        assert sum(nr) == h and r0[0] == 0 and all(r0[k] + nr[k] == r0[k + 1] for k in range(n - 1))
     assert L.rt_split_rows((C.c_double * 2)(1.0, -1.0), 2, 10, 2, 8, (C.c_int * 2)(), (C.c_int * 2)()) == -1
+    assert L.rt_split_rows_weighted((C.c_double * 2)(1.0, 1.0), 2, 64, 2, 8, (C.c_double * 2)(1.0, 0.0), (C.c_int * 2)(), (C.c_int * 2)()) == -1
 
 
 def test_scene_options_and_the_cross_check_build():
