@@ -230,7 +230,8 @@ def main():
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank renders on GPU 0 (gloo only)")
     ap.add_argument("--pieces", type=int, default=0, help="N > 1: pieces per band (0 = what the pipeline model picks: raytrace_amd/distributed.py plan_frame)")
     ap.add_argument("--link-gbps", type=float, default=48.0, help="N > 1: what the model assumes one xGMI link carries in one direction under ncclSend/ncclRecv (GB/s)")
-    ap.add_argument("--piece-overhead-ms", type=float, default=0.05, help="N > 1: what the model charges per piece for its launches and kernel tails")
+    ap.add_argument("--piece-overhead-ms", type=float, default=0.1, help="N > 1: what the model charges per piece for its launches and kernel tails "
+                    "(measured on one MI355X: 0.06-0.14 ms per extra piece of a 2048-row band of the 16384-wide frame, profiles/r03_piece_overhead.txt)")
     ap.add_argument("--verify", action="store_true", help="rank 0 re-renders the whole frame alone and compares it with the gathered one")
     args = ap.parse_args()
 

@@ -1,703 +1,32 @@
-// rt_kernels.hip — gfx950 (MI355X, CDNA4) kernels of the render path and the render entry points.
+// rt_kernels.hip — the gfx950 (MI355X, CDNA4) kernels of the render path, and the functions that launch them.
 //
 // Replaces parallelTrace / computeP (reference src/Main.hs:623-637) and everything its element
 // function calls: cast (506-533), trace (541-557), intersect world (196-217, 226-277, 363-385),
 // light lights (436-492).
 //
 // Design (DESIGN.md has the long form):
-//   * Brute force: every ray is tested against every leaf, through a chain of conservative filters in front of the
-//     exact test.  All rays of a pass leave a common apex (the eye; a light for shadow rays), so a leaf is seen from the
-//     apex under a bounding cone (stage 0, one linear form per pair) and its exact shape is three linear forms of the
-//     ray direction (stage 1, rt_scene.cpp).
-//   * Matrix-core kernels (k_primary_mfma, k_shadow_mfma; the default): stage 0 for 32 leaves x 32 rays is one
+//   * Every ray is decided against every leaf, through a chain of conservative filters in front of the exact test.  All rays
+//     of a pass leave a common apex (the eye; a light for shadow rays), so a leaf is seen from the apex under a bounding
+//     cone (stage 0, one linear form per pair) and its exact shape is three linear forms of the ray direction (stage 1,
+//     rt_scene.cpp); blocks of 32 leaves are tested against the bound of a wave's 256 rays first (stage -1).
+//   * Matrix-core kernels (k_primary_mfma, k_shadow_mfma, k_general): stage 0 for 32 leaves x 32 rays is one
 //     v_mfma_f32_32x32x16_f16; survivors go through per-wave LDS queues to stage 1 (FP32) and to the exact stage, 64
 //     entries at a time.
-//   * Vector-ALU kernels (k_primary, k_shadow; RT_FILTER=valu): stage 1 for every pair.  One wavefront owns a 32 x 8
-//     pixel tile, a lane 4 pixels as two float2 pairs (v_pk_fma_f32); leaf records are wave-uniform and are read with
-//     scalar loads into SGPRs: no VGPRs, no LDS bandwidth, no bank conflicts.
 //   * (ray, leaf) pairs that pass the filters — a handful per ray — are evaluated in IEEE double with the reference's
-//     own expression order (planeLineIsect etc.), which decides the hit, the tie-break (left-most leaf,
-//     Main.hs:213-214) and the colour exactly.  The file is compiled with -ffp-contract=off; the FP32 loops use
-//     explicit fma builtins.
-#include <hip/hip_runtime.h>
-#include <algorithm>
-#include <chrono>
-#include <cmath>
-#include <condition_variable>
-#include <mutex>
-#include <thread>
-#include <type_traits>
-#include <cstdio>
-#include <cstring>
-#include <string>
-#include <vector>
-
-#include "rt_scene.h"
-
-using namespace rt;
-
-typedef float f2 __attribute__((ext_vector_type(2)));
-// Wave-uniform, read-only scene data is addressed through the constant address space, which makes
-// hipcc fetch it with scalar loads (s_load_dwordx8 ...) no matter what else the kernel stores.
-#define RT_CONST __attribute__((address_space(4)))
-typedef const rt::FilterRec RT_CONST *CRecPtr;
-typedef const int32_t RT_CONST *CIntPtr;
-
-#define RT_TILE_W 32
-#define RT_TILE_H 8
-// One wave per work-group: the wave slots of a 4-wave group only came free when its slowest wave had finished, and the
-// waves of these kernels take between 10 and 200 us; measured on the benchmark frame, a third of the slots sat empty
-// (tools/wave_times.py), 9 % of the frame time.
-#ifndef RT_WAVES_PER_BLOCK
-#define RT_WAVES_PER_BLOCK 1
-#endif
-#ifndef RT_SHADOW_CLIP
-#define RT_SHADOW_CLIP 0       // 1: shadow filter tests "not beyond the ray origin" per leaf (6 more VALU per 4 rays)
-#endif
-#ifndef RT_PREFETCH
-#define RT_PREFETCH 1          // double-buffer the leaf records in SGPRs
-#endif
-// occupancy (waves per SIMD) the register allocator must reach for the two brute-force kernels
-#ifndef RT_WAVES_EU_PRIMARY
-#define RT_WAVES_EU_PRIMARY 8
-#endif
-#ifndef RT_WAVES_EU_SHADOW
-#define RT_WAVES_EU_SHADOW 6
-#endif
-#define RT_HOT(n) __attribute__((amdgpu_waves_per_eu(n, 8))) __launch_bounds__(RT_WAVES_PER_BLOCK * 64)
-
-// RT_TALK(P): is the scene in the Talk.hs dialect?  (-DRT_NO_TALK compiles the dialect out: measurement only.)
-#ifdef RT_NO_TALK
-#define RT_TALK(P) false
-#else
-#define RT_TALK(P) ((P).talk != 0)
-#endif
+//     own expression order (planeLineIsect etc., rt_device.h), which decides the hit, the tie-break (left-most leaf,
+//     Main.hs:213-214) and the colour exactly.  Compiled with -ffp-contract=off; the FP32 code uses explicit fma builtins.
+//   * The FP32 vector-ALU kernel family of the cross-check build lives in rt_kernels_valu.hip; the host runtime that
+//     enqueues all this in rt_render.hip.
+#include "rt_device.h"
 
 namespace {
 
-struct HitRec;
-struct RenderParams {
-    const LeafD *leaves;
-    const AuxD *aux;
-    const GuardD *guards;
-    const MaterialD *mats;
-    const LightD *lights;
-    const FilterRec *tri_rec;
-    const FilterRec *rect_rec;
-    const int32_t *tri_gid;
-    const int32_t *rect_gid;
-    const FilterRec *sph_rec;
-    const GenRec *gen_sph;
-    const int32_t *sph_gid;
-    const uint16_t *mf_rows;        // MFMA row blocks, per apex (rt_types.h)
-    const int32_t *mf_gid;          // MFMA stream position -> leaf index, per apex
-    const float *mf_cone;           // bounding cone of every block of the stream, per apex (rt_scene.cpp: block_cone)
-    const FilterRec *mf_rec;        // FP32 records in MFMA stream order, per apex (c[14] = kind, c[15] = leaf index)
-    unsigned long long *counters;   // [0] shadow rays cast, [1] exact evals (primary), [2] exact evals (shadow)
-    int32_t *hit_id;                // band-local output, indexed out_off + pix
-    uint8_t *rgba;                  // band-local output (spp == 1) or nullptr
-    uint32_t *accum;                // band-local 3 x u32 sums (spp > 1) or nullptr
-    HitRec *hitrec;                 // per chunk pixel: exact hit point and shading normal
-    uint32_t *queue;                // npoint blocks of qcap shadow jobs (chunk pixel indices)
-    unsigned *qcount;               // shadow jobs per point light
-    uint32_t *qsparse;              // k_setup's output: per light, RT_SETUP_THREADS slots per block, the block's jobs first
-    unsigned *tcount;               // jobs of every (light, k_setup block); k_queue_offsets turns them into offsets in place
-    int setup_blocks;               // k_setup blocks of this chunk
-    uint32_t *lit;                  // per chunk pixel and group of 32 point lights: bit l set = light 32 g + l reaches it
-    // RT_NORMAL_CALLBACK leaves (an arbitrary fnorm, Main.hs:956-965): k_cb_gather lists the hit points on them, the host
-    // evaluates the caller's function, k_setup reads the normals back
-    uint32_t *cb_slot;              // per slot of the chunk / level: index into the list
-    double *cb_xy;                  // per list entry: the arguments x, y of fnorm
-    int32_t *cb_group;              // per list entry: which callback
-    const double *cb_normal;        // per list entry: fnorm x y
-    unsigned *cb_count;             // entries in the list
-    unsigned long long *dbg;        // -DRT_WAVE_TIMES builds only (tools/wave_times.py): per-wave timeline records
-    // bounce levels (reflective scenes, trace depth > 1; Main.hs:546-556).  A "slot" is a pixel of the chunk at
-    // level 0 and an entry of the level's ray list above it.
-    const RayRec *rays;             // this level's rays (nullptr at level 0: camera rays)
-    const unsigned *count_ptr;      // number of slots of this level (nullptr at level 0: qcap)
-    RayRec *next_rays;              // where k_final appends the reflected rays (nullptr: none)
-    unsigned *next_count;
-    uint32_t *colour;               // per-slot colour of this level (nullptr: write RGBA8 / accum directly)
-    const GenRec *gen_tri;          // general-ray filter records, in a space-filling order of the leaves (rt_scene.cpp: spatial_order)
-    const GenRec *gen_rect;
-    const int32_t *gen_tri_gid;     // position in that order -> leaf index
-    const int32_t *gen_rect_gid;
-    const float *gen_tri_sph;       // bounding sphere of every block of 32 consecutive records: centre xyz, radius (inf: always scan)
-    const float *gen_rect_sph;
-    const uint16_t *gen_tri_rows;   // the blocks' matrix-core rows: 2 K steps x 64 x 16 bytes per block (lane (m, h): K-half h of leaf m), + one padding block
-    const uint16_t *gen_rect_rows;
-    const float *gen_tri_ssph;      // super-blocks of 32 blocks: bounding sphere = the frame their leaves' rows are written in
-    const float *gen_rect_ssph;
-    CameraD cam;
-    double eps;
-    int ntri, nrect, nsph, nlights, nleaves, npoint;
-    int mf_groups;                  // blocks of MF_LEAVES planar leaves per apex (+ 2 of padding)
-    int cull;                       // 0: every wave scans every block (RT_CULL=0)
-    int nguard_cached;              // guards [0, nguard_cached) are tested per tile (tile_guard_mask); 0: off
-    int w, h;
-    int row0, nrows;                // this chunk: first absolute image row, rows
-    long long out_off;              // index of the chunk's first pixel inside the band-local outputs
-    int qcap;                       // pixels in the chunk = capacity of one shadow queue
-    int lcap;                       // capacity of a bounce level's ray list: the chunk's pixels padded to whole 32 x 8 tiles
-    int spp, sample;
-    int talk;                       // 1: the rules of src/Talk.hs (rt_scene_set_dialect)
-    uint32_t seed_lo, seed_hi;
-    int tiles_x, tiles_y;
-    uint16_t point_light[32];       // index in `lights` of the k-th point light of the current group of 32
-    uint32_t *lit_w;                // the current group's word of `lit` (= lit + group * lit_stride)
-    long long lit_stride;           // slots per group of 32 point lights in `lit`
-};
-
-struct HitRec { double px, py, pz, nx, ny, nz; };
-
-// ------------------------------------------------------------------------------------------
-// Exact path (IEEE double, reference expression order)
-
-struct RayD { double px, py, pz, dx, dy, dz, rx, ry, rz; };
-
-__device__ __forceinline__ double clampd(double d, double eps) { return fabs(d) <= eps ? eps : d; } // Main.hs:112
-
-// mkray position direction — Main.hs:107-115
-__device__ __forceinline__ RayD mkray(double px, double py, double pz, double dx, double dy, double dz, double eps) {
-    RayD r;
-    r.px = px; r.py = py; r.pz = pz;
-    r.dx = clampd(dx, eps); r.dy = clampd(dy, eps); r.dz = clampd(dz, eps);
-    r.rx = 1.0 / r.dx; r.ry = 1.0 / r.dy; r.rz = 1.0 / r.dz;
-    return r;
-}
-
-// jittered supersampling offsets (extension): spp == 1 -> (0, 0) = the reference
-__device__ __forceinline__ uint32_t mix32(uint32_t h) {
-    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16; return h;
-}
-__device__ __forceinline__ void sample_offset(const RenderParams &P, int x, int y, double &ox, double &oy) {
-    if (P.spp <= 1) { ox = 0; oy = 0; return; }
-    uint32_t h = mix32(P.seed_lo ^ mix32(P.seed_hi + 0x9e3779b9u));
-    h = mix32(h ^ (uint32_t)x);
-    h = mix32(h ^ ((uint32_t)y + 0x9e3779b9u));
-    h = mix32(h ^ ((uint32_t)P.sample + 0x7f4a7c15u));
-    const uint32_t h2 = mix32(h ^ 0x68bc21ebu);
-    const double u1 = (double)(h >> 8) * (1.0 / 16777216.0), u2 = (double)(h2 >> 8) * (1.0 / 16777216.0);
-    const int k = (int)floor(sqrt((double)P.spp) + 0.5);
-    if (k * k == P.spp) {
-        const int sx = P.sample % k, sy = P.sample / k;
-        ox = ((double)sx + u1) / (double)k - 0.5;
-        oy = ((double)sy + u2) / (double)k - 0.5;
-    } else { ox = u1 - 0.5; oy = u2 - 0.5; }
-}
-
-// cast camera x y — Main.hs:528-533
-template <bool MAY_TALK = true>
-__device__ __forceinline__ RayD camera_ray(const RenderParams &P, int x, int y) {
-    double ox, oy;
-    sample_offset(P, x, y, ox, oy);
-    const double posX = P.cam.scaleX * ((double)x + ox) + P.cam.dX;
-    const double posY = P.cam.scaleY * ((double)y + oy) + P.cam.dY;
-    const double n = sqrt(posX * posX + posY * posY + P.cam.d * P.cam.d);
-    if (MAY_TALK && RT_TALK(P)) {                       // Talk.hs:66-67, 152: scalar (recip (norm v)) v
-        const double rn = 1.0 / n;
-        return mkray(posX, posY, 0.0, rn * posX, rn * posY, rn * P.cam.d, P.eps);
-    }
-    return mkray(posX, posY, 0.0, posX / n, posY / n, P.cam.d / n, P.eps);
-}
-
-// Statistics counters: RT_STAT_SLOTS copies of the 8 counters, one 128-byte line each, picked by wave number.  Every
-// wave adds to them once, and atomics on ONE address are serialised by the L2 (12 ns each: 0.4 ms for the 32 400 waves
-// of a 4K frame, which is what a single set of counters cost); rt_get_stats sums the copies.
-constexpr int RT_STAT_SLOTS = 256;
-// Workspace::qcount: [0, 32) shadow jobs per point light; [32, 32 + RT_MAX_LEVELS] rays per bounce level; then the
-// number of hit points waiting for a normal callback
-constexpr int RT_QCOUNT_CB = 32 + RT_MAX_LEVELS + 1, RT_QCOUNT_CLEAR = (RT_QCOUNT_CB + 1 + 3) / 4 * 4;   // (cleared as whole 16-byte units: one fill kernel)
-// ... then, NOT cleared between renders: [RT_QCOUNT_HIST, + 64) per point light of a group {wall-clock ticks, waves} of a
-// sample of its k_shadow_mfma waves, halved at every launch (a moving average); [RT_QCOUNT_ORDER, + 32) the order the
-// lights' waves are dispatched in, costliest light first (k_queue_offsets).
-constexpr size_t RT_COUNTER_BYTES = (size_t)RT_STAT_SLOTS * 16 * sizeof(unsigned long long);
-constexpr int RT_QCOUNT_HIST = RT_QCOUNT_CLEAR, RT_QCOUNT_ORDER = RT_QCOUNT_HIST + 64, RT_QCOUNT_WORDS = RT_QCOUNT_ORDER + 32;
-__device__ __forceinline__ void stat_add(const RenderParams &P, int k, unsigned long long v) {
-    const unsigned wave = (blockIdx.x + blockIdx.y * gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    atomicAdd(&P.counters[(size_t)(wave % RT_STAT_SLOTS) * 16 + k], v);
-}
-#ifdef RT_WAVE_TIMES
-// measurement builds: one record per wave {kernel | light << 8, wave, start, end (100 MHz wall clock), blocks scanned,
-// record tests, exact evaluations, hardware id}; dbg[0] counts the records
-__device__ __forceinline__ void wave_record(const RenderParams &P, unsigned kernel, unsigned wave, unsigned long long t0,
-                                            unsigned nblocks, unsigned nrec, unsigned nexact, const unsigned long long (&ph)[3]) {
-    if (!P.dbg || (threadIdx.x & 63u) != 0u) return;
-    const unsigned long long t1 = wall_clock64();
-    const unsigned long long k = atomicAdd(&P.dbg[0], 1ull);
-    if (k >= (1ull << 20)) return;
-    unsigned long long *r = P.dbg + 8 + 8 * k;
-    r[0] = kernel; r[1] = wave; r[2] = t0; r[3] = t1;
-    r[4] = (unsigned long long)nblocks | ((unsigned long long)nrec << 16) | ((unsigned long long)nexact << 40);
-    r[5] = ph[0]; r[6] = ph[1]; r[7] = ph[2];      // phase boundaries: after the ray set-up, after bound + guard proofs, after the scan
-}
-#define RT_WAVE_T0 const unsigned long long wave_t0 = wall_clock64(); unsigned long long wave_ph[3] = {0, 0, 0};
-#define RT_WAVE_PHASE(k) wave_ph[k] = wall_clock64();
-#else
-#define RT_WAVE_T0
-#define RT_WAVE_PHASE(k)
-#endif
-
-__device__ __forceinline__ unsigned num_slots(const RenderParams &P) {
-    if (!P.count_ptr) return (unsigned)P.qcap;
-    const unsigned c = *P.count_ptr;
-    return c < (unsigned)P.lcap ? c : (unsigned)P.lcap;
-}
-// the ray of a slot: `cast camera x y` at level 0, `mkray (ipos + 1e-5 rdir) rdir` (Main.hs:552) above
-// A level's ray list in memory: runs of 64 slots, structure-of-arrays inside a run (8 fields x 64 x 8 bytes = 4 KiB per
-// run: origin, direction, reflectivity, parent slot), so that a wave reading or writing the rays of a run touches 512
-// contiguous bytes per field.  (As an array of 72-byte structures every field access of a wave scattered over 36 cache
-// lines: k_final spent 0.4 of its 0.47 ms per chunk writing the reflected rays.)  RayRec is the value in registers.
-__device__ __forceinline__ size_t ray_index(unsigned slot, int field) { return ((size_t)(slot >> 6) * 8 + (size_t)field) * 64 + (slot & 63u); }
-__device__ __forceinline__ uint32_t ray_parent(const RayRec *rays, unsigned slot) {
-    return (uint32_t)reinterpret_cast<const unsigned long long *>(rays)[ray_index(slot, 7)];
-}
-__device__ __forceinline__ RayRec load_ray(const RayRec *rays, unsigned slot) {
-    const double *p = reinterpret_cast<const double *>(rays);
-    RayRec R;
-    R.ox = p[ray_index(slot, 0)]; R.oy = p[ray_index(slot, 1)]; R.oz = p[ray_index(slot, 2)];
-    R.dx = p[ray_index(slot, 3)]; R.dy = p[ray_index(slot, 4)]; R.dz = p[ray_index(slot, 5)];
-    R.rho = p[ray_index(slot, 6)];
-    R.parent = ray_parent(rays, slot); R._pad = 0u;
-    return R;
-}
-__device__ __forceinline__ void store_ray(RayRec *rays, unsigned slot, const RayRec &R) {
-    double *p = reinterpret_cast<double *>(rays);
-    p[ray_index(slot, 0)] = R.ox; p[ray_index(slot, 1)] = R.oy; p[ray_index(slot, 2)] = R.oz;
-    p[ray_index(slot, 3)] = R.dx; p[ray_index(slot, 4)] = R.dy; p[ray_index(slot, 5)] = R.dz;
-    p[ray_index(slot, 6)] = R.rho;
-    reinterpret_cast<unsigned long long *>(rays)[ray_index(slot, 7)] = (unsigned long long)R.parent;
-}
-
-__device__ __forceinline__ RayD slot_ray(const RenderParams &P, int slot) {
-    if (P.rays) {
-        const RayRec R = load_ray(P.rays, (unsigned)slot);
-        return mkray(R.ox, R.oy, R.oz, R.dx, R.dy, R.dz, P.eps);
-    }
-    const int ly = slot / P.w;
-    return camera_ray(P, slot - ly * P.w, P.row0 + ly);
-}
-
-// planeRayIsect + the inside test of rectangle (Main.hs:234-242) / triangle (Main.hs:374-383).
-// KIND is the leaf type; L is wave-uniform in the filter loops (scalar loads).
-template <int KIND>
-__device__ __forceinline__ bool leaf_isect(const LeafD &L, const RayD &r, double &ix, double &iy, double &iz, double &t, bool talk) {
-    if (KIND == LEAF_SPHERE) {                                                         // sphere, Main.hs:395-411
-        const double ox = r.px - L.p0x, oy = r.py - L.p0y, oz = r.pz - L.p0z;          // :396
-        const double sb = 2 * (r.dx * ox + r.dy * oy + r.dz * oz);                     // :398
-        const double sc = (ox * ox + oy * oy + oz * oz) - L.c0 * L.c0;                 // :399
-        const double delta = sb * sb - 4 * sc;                                         // :400
-        if (!(delta >= 0)) return false;                                               // :401
-        double ts;
-        if (delta > 0) {
-            const double sq = sqrt(delta);
-            const double t1 = (-sb + sq) / 2, t2 = (-sb - sq) / 2;                     // :404-405
-            const double m1 = t1 <= 0 ? 0.0 : t1, m2 = t2 <= 0 ? 0.0 : t2;             // max t 0
-            ts = m1 <= m2 ? m1 : m2;                                                   // min, :406
-        } else ts = -sb / 2;                                                           // :407
-        if (!(ts > 0)) return false;                                                   // :408
-        t = ts;
-        ix = r.px + ts * r.dx; iy = r.py + ts * r.dy; iz = r.pz + ts * r.dz;           // :409
-        return true;
-    }
-    const double a = L.nx, b = L.ny, c = L.nz;
-    const double frac = (a * r.dx + b * r.dy + c * r.dz) / r.dz;                       // Main.hs:269
-    const double z = (-L.d - a * r.px - b * r.py + (frac - c) * r.pz) / frac;          // :270
-    const double x = (r.dx * (z - r.pz) / r.dz) + r.px;                                // :271
-    const double y = (r.dy * (z - r.pz) / r.dz) + r.py;                                // :272
-    if (fabs(frac) <= 0.00001) return false;                                           // :273
-    if (talk) {                       // Talk.hs:121-122: ray_direction *@ (i - ray_position) >= 0; key = squared distance, :192-193
-        const double vx = x - r.px, vy = y - r.py, vz = z - r.pz;
-        if (!(r.dx * vx + r.dy * vy + r.dz * vz >= 0)) return false;
-        t = vx * vx + vy * vy + vz * vz;
-    } else {
-        t = (z - r.pz) * r.rz;                                                         // :256, 122-126
-        if (!(t >= 0)) return false;                                                   // :257
-    }
-    ix = x; iy = y; iz = z;
-    const double wx = x - L.p0x, wy = y - L.p0y, wz = z - L.p0z;
-    if (KIND == LEAF_RECT) {
-        const double dw = wx * L.e1x + wy * L.e1y + wz * L.e1z;                        // :239
-        const double dh = wx * L.e2x + wy * L.e2y + wz * L.e2z;                        // :240
-        return 0 <= dw && dw <= L.c0 && 0 <= dh && dh <= L.c1;                         // :241
-    } else {
-        const double wv = wx * L.e2x + wy * L.e2y + wz * L.e2z;                        // :377
-        const double wu = wx * L.e1x + wy * L.e1y + wz * L.e1z;                        // :378
-        const double rr = (L.c0 * wv - L.c2 * wu) / L.c3;                              // :379
-        const double ss = (L.c0 * wu - L.c1 * wv) / L.c3;                              // :380
-        return rr >= 0 && ss >= 0 && rr + ss <= 1;                                     // :382
-    }
-}
-
-// intersectBB — Main.hs:152-174 — for every mappend node above the leaf (Main.hs:209).
-// The reference ORs six face tests; the result does not depend on their order.  A ray that meets a box leaves it
-// through one of the three faces it points at, with t >= 0, so those are tried first, and the remaining tests are
-// skipped once every active lane of the wave has found a face (wave-uniform branches): about two face tests per
-// box instead of six, the same six when in doubt.
-#ifndef RT_GUARD_EARLY
-#define RT_GUARD_EARLY 1
-#endif
-__device__ __forceinline__ bool face_xy(const GuardD &B, double zf, const RayD &r) {       // isectXY
-    const double t = (zf - r.pz) * r.rz;
-    const double a = r.px + t * r.dx, c = r.py + t * r.dy;
-    return t >= 0 && B.x0 <= a && a <= B.x1 && B.y0 <= c && c <= B.y1;
-}
-__device__ __forceinline__ bool face_xz(const GuardD &B, double yf, const RayD &r) {       // isectXZ
-    const double t = (yf - r.py) * r.ry;
-    const double a = r.px + t * r.dx, c = r.pz + t * r.dz;
-    return t >= 0 && B.x0 <= a && a <= B.x1 && B.z0 <= c && c <= B.z1;
-}
-__device__ __forceinline__ bool face_yz(const GuardD &B, double xf, const RayD &r) {       // isectYZ
-    const double t = (xf - r.px) * r.rx;
-    const double a = r.py + t * r.dy, c = r.pz + t * r.dz;
-    return t >= 0 && B.y0 <= a && a <= B.y1 && B.z0 <= c && c <= B.z1;
-}
-// `passed`: bit g set = box g (< 64) and every box above it are known to let this ray through (tile_guard_mask)
-template <bool EARLY = (RT_GUARD_EARLY != 0)>
-__device__ __forceinline__ bool guards_ok(const GuardD *__restrict__ G, int g, const RayD &r, unsigned long long passed = 0ull) {
-    // the faces the ray points at: it leaves the box through one of these three
-    const bool nz = r.dz < 0, ny = r.dy < 0, nx = r.dx < 0;
-    (void)nz; (void)ny; (void)nx;
-#ifdef RT_NO_GUARDS
-    return true;        // timing experiments only
-#endif
-    while (g >= 0) {
-        if (g < 64 && ((passed >> g) & 1ull)) return true;
-        const GuardD B = G[g];
-        bool any;
-        if (EARLY) {
-        any = face_xy(B, nz ? B.z0 : B.z1, r);
-        if (__builtin_amdgcn_ballot_w64(!any)) {
-            any |= face_xz(B, ny ? B.y0 : B.y1, r);
-            if (__builtin_amdgcn_ballot_w64(!any)) {
-                any |= face_yz(B, nx ? B.x0 : B.x1, r);
-                if (__builtin_amdgcn_ballot_w64(!any)) {
-                    any |= face_xy(B, nz ? B.z1 : B.z0, r);
-                    any |= face_xz(B, ny ? B.y1 : B.y0, r);
-                    any |= face_yz(B, nx ? B.x1 : B.x0, r);
-                }
-            }
-        }
-        } else {
-            any = face_xy(B, B.z0, r); any |= face_xz(B, B.y0, r); any |= face_yz(B, B.x0, r);
-            any |= face_xy(B, B.z1, r); any |= face_xz(B, B.y1, r); any |= face_yz(B, B.x1, r);
-        }
-        if (!any) return false;
-        g = B.parent;
-    }
-    return true;
-}
-
-// ------------------------------------------------------------------------------------------
-// FP32 filter: 4 rays of one lane against one leaf record (wave-uniform -> SGPR operands)
-
-__device__ __forceinline__ CRecPtr as_const(const FilterRec *p) { return (CRecPtr)(const void *)p; }
-__device__ __forceinline__ CIntPtr as_const(const int32_t *p) { return (CIntPtr)(const void *)p; }
-template <int N = 10>
-__device__ __forceinline__ FilterRec load_rec(CRecPtr p) {
-    FilterRec r;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) r.c[k] = k < N ? p->c[k] : 0.f;
-    return r;
-}
-// p, but not before record r has arrived: orders a prefetch after the wait for the record in use
-__device__ __forceinline__ CRecPtr after(CRecPtr p, const FilterRec &r) {
-    asm volatile("" : "+s"(p) : "s"(r.c[0]));
-    return p;
-}
-__device__ __forceinline__ f2 splat(float v) { f2 r = {v, v}; return r; }
-__device__ __forceinline__ f2 pkfma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
-
-struct Dir4 { f2 x[2], y[2], z[2]; };   // directions of the lane's 4 rays from the apex
-
-#ifdef RT_VALU_FILTER   // the FP32 vector-ALU kernel family: cross-check build only (libraytrace_gpu_valu.so)
-// Returns z[r] for the lane's 4 rays: ray r passes the filter iff z[r] >= R.c[9] (= -margin).
-//   triangle : z = min(q1*N, q2*N, (1-q1-q2)*N [, N - Kq])      q1, q2 = barycentrics r, s
-//   rectangle: z = min(N - max(|a'N|, |b'N|)     [, N - Kq])     a', b' in [-1, 1]
-// CLIP adds the "not beyond the ray origin" test u* = K/N <= 1 used by shadow rays.
-template <int KIND, bool CLIP>
-__device__ __forceinline__ bool filter4(const FilterRec &R, const Dir4 &D, float z[4]) {
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const f2 q1 = pkfma(splat(R.c[0]), D.x[p], pkfma(splat(R.c[1]), D.y[p], splat(R.c[2]) * D.z[p]));
-        const f2 q2 = pkfma(splat(R.c[3]), D.x[p], pkfma(splat(R.c[4]), D.y[p], splat(R.c[5]) * D.z[p]));
-        const f2 n = pkfma(splat(R.c[6]), D.x[p], pkfma(splat(R.c[7]), D.y[p], splat(R.c[8]) * D.z[p]));
-        f2 zz;
-        if (KIND == LEAF_TRI) {
-            const f2 w = CLIP ? n - q1 - q2 : n;      // without the clip the third form already is W
-            zz = f2{__builtin_fminf(__builtin_fminf(q1[0], q2[0]), w[0]), __builtin_fminf(__builtin_fminf(q1[1], q2[1]), w[1])};
-        } else {
-            const f2 m = f2{__builtin_fmaxf(__builtin_fabsf(q1[0]), __builtin_fabsf(q2[0])),
-                            __builtin_fmaxf(__builtin_fabsf(q1[1]), __builtin_fabsf(q2[1]))};
-            zz = n - m;
-        }
-        if (CLIP) {
-            const f2 c = n - splat(R.c[10]);
-            zz = f2{__builtin_fminf(zz[0], c[0]), __builtin_fminf(zz[1], c[1])};
-        }
-        z[2 * p] = zz[0]; z[2 * p + 1] = zz[1];
-    }
-    const float mx = __builtin_fmaxf(__builtin_fmaxf(z[0], z[1]), __builtin_fmaxf(z[2], z[3]));
-    return mx >= R.c[9];
-}
-
-#endif // RT_VALU_FILTER
-// Sphere, apex form: z = (D.oc)^2 - |D|^2 cs; dd = |D|^2 of the lane's rays.
-__device__ __forceinline__ bool filter4_sphere(const FilterRec &R, const Dir4 &D, const f2 dd[2], float z[4]) {
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const f2 b = pkfma(splat(R.c[0]), D.x[p], pkfma(splat(R.c[1]), D.y[p], splat(R.c[2]) * D.z[p]));
-        const f2 zz = pkfma(b, b, -(dd[p] * splat(R.c[3])));
-        z[2 * p] = zz[0]; z[2 * p + 1] = zz[1];
-    }
-    const float mx = __builtin_fmaxf(__builtin_fmaxf(z[0], z[1]), __builtin_fmaxf(z[2], z[3]));
-    return mx >= R.c[9];
-}
-__device__ __forceinline__ void dir_norms(const Dir4 &D, f2 dd[2]) {
-#pragma unroll
-    for (int p = 0; p < 2; ++p) dd[p] = pkfma(D.x[p], D.x[p], pkfma(D.y[p], D.y[p], D.z[p] * D.z[p]));
-}
-
-#ifdef RT_VALU_FILTER   // the FP32 vector-ALU kernel family: cross-check build only (libraytrace_gpu_valu.so)
-// Eye-apex variant: the forms are affine in the pixel's viewport position (posX, posY); the lane's 4
-// pixels share posY (SHARED_Y, spp == 1), so the posY part of a form is computed once per lane.
-//   triangle : z = min(U, V, W)          rectangle: z = N - max(|A|, |B|)
-struct Eye4 { f2 x[2]; f2 y[2]; float ys; };
-
-template <int KIND, bool SHARED_Y>
-__device__ __forceinline__ bool filter4_eye(const FilterRec &R, const Eye4 &E, float z[4]) {
-    f2 q[3][2];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        if (SHARED_Y) {
-            const float b = __builtin_fmaf(R.c[3 * k + 1], E.ys, R.c[3 * k + 2]);
-#pragma unroll
-            for (int p = 0; p < 2; ++p) q[k][p] = pkfma(splat(R.c[3 * k]), E.x[p], splat(b));
-        } else {
-#pragma unroll
-            for (int p = 0; p < 2; ++p) q[k][p] = pkfma(splat(R.c[3 * k]), E.x[p], pkfma(splat(R.c[3 * k + 1]), E.y[p], splat(R.c[3 * k + 2])));
-        }
-    }
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        if (KIND == LEAF_TRI) {
-            z[2 * p] = __builtin_fminf(__builtin_fminf(q[0][p][0], q[1][p][0]), q[2][p][0]);
-            z[2 * p + 1] = __builtin_fminf(__builtin_fminf(q[0][p][1], q[1][p][1]), q[2][p][1]);
-        } else {
-            const f2 m = f2{__builtin_fmaxf(__builtin_fabsf(q[0][p][0]), __builtin_fabsf(q[1][p][0])),
-                            __builtin_fmaxf(__builtin_fabsf(q[0][p][1]), __builtin_fabsf(q[1][p][1]))};
-            const f2 zz = q[2][p] - m;
-            z[2 * p] = zz[0]; z[2 * p + 1] = zz[1];
-        }
-    }
-    const float mx = __builtin_fmaxf(__builtin_fmaxf(z[0], z[1]), __builtin_fmaxf(z[2], z[3]));
-    return mx >= R.c[9];
-}
-
-__device__ __forceinline__ void tile_coords(const RenderParams &P, int &x0, int &y, bool &row_ok) {
-    const int wave = (int)(blockIdx.x * RT_WAVES_PER_BLOCK + (threadIdx.x >> 6));
-    const int lane = (int)(threadIdx.x & 63);
-    const int tx = wave % P.tiles_x, ty = wave / P.tiles_x;
-    x0 = tx * RT_TILE_W + (lane & 7) * 4;
-    const int ly = ty * RT_TILE_H + (lane >> 3);
-    row_ok = ly < P.nrows;
-    y = P.row0 + ly;             // absolute image row
-}
-
-// ------------------------------------------------------------------------------------------
-// Kernel 1: nearest hit of the primary rays -> hit_id
-//   replaces `intersect world (cast camera x y)` of trace (Main.hs:543) for every pixel of the chunk.
-//   One wave = 32 x 8 pixel tile, 4 pixels per lane.  Apex = the eye (all primary rays pass through
-//   (0, 0, -d)), D = (posX, posY, d).
-
-template <int KIND, bool SHARED_Y>
-__device__ __forceinline__ void primary_loop(const RenderParams &P, CRecPtr recs, CIntPtr gids, int n, const Eye4 &D,
-                                             const bool act[4], int x0, int y, double bt[4], int bid[4],
-                                             unsigned &nexact) {
-    if (n <= 0) return;
-    auto body = [&](const FilterRec &cur, int i) {
-        float z[4];
-        if (filter4_eye<KIND, SHARED_Y>(cur, D, z)) {
-            const float negm = cur.c[9];
-            const int gid = gids[i];
-            const LeafD &L = P.leaves[gid];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if ((z[r] >= negm) & act[r]) {
-                    int xr = x0 + r;
-                    asm volatile("" : "+v"(xr));   // keep the exact-path ray set-up inside this rare branch
-                    const RayD ray = camera_ray<false>(P, xr, y);
-                    double ix, iy, iz, t;
-                    ++nexact;
-                    if (leaf_isect<KIND>(L, ray, ix, iy, iz, t, false) && guards_ok<false>(P.guards, L.guard, ray)) {
-                        // nearest wins; equal t -> the left-most leaf of the tree (Main.hs:213-214)
-                        if (t < bt[r] || (t == bt[r] && gid < bid[r]) || bid[r] < 0) { bt[r] = t; bid[r] = gid; }
-                    }
-                }
-            }
-        }
-    };
-#if RT_PREFETCH
-    // Two record buffers in SGPRs, used in turn (no copies).  Scalar loads return out of order, so the only wait
-    // there is waits for ALL of them: the load of record i + 1 is issued right after the wait for record i (the
-    // asm ties its address to a register of record i) and has the whole test of record i to arrive.
-    FilterRec a = load_rec(recs);
-    int i = 0;
-    for (; i + 1 < n; i += 2) {
-        const FilterRec b = load_rec(after(recs + i + 1, a));
-        body(a, i);
-        a = load_rec(after(recs + i + 2, b));             // arrays are padded: i + 2 may be one past the end
-        body(b, i + 1);
-    }
-    if (i < n) body(a, i);
-#else
-    for (int i = 0; i < n; ++i) body(load_rec(recs + i), i);
-#endif
-}
-
-// spheres seen from the eye (few per scene: plain loop, generic apex form)
-__device__ __forceinline__ void primary_sphere_loop(const RenderParams &P, const Eye4 &E, const bool act[4], int x0, int y,
-                                                 double bt[4], int bid[4], unsigned &nexact) {
-    Dir4 D;
-    const float dz = (float)P.cam.d;
-#pragma unroll
-    for (int p = 0; p < 2; ++p) { D.x[p] = E.x[p]; D.y[p] = E.y[p]; D.z[p] = f2{dz, dz}; }
-    f2 dd[2];
-    dir_norms(D, dd);
-    CRecPtr recs = as_const(P.sph_rec);
-    CIntPtr gids = as_const(P.sph_gid);
-    for (int i = 0; i < P.nsph; ++i) {
-        const FilterRec cur = load_rec(recs + i);
-        float z[4];
-        if (filter4_sphere(cur, D, dd, z)) {
-            const int gid = gids[i];
-            const LeafD &L = P.leaves[gid];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if ((z[r] >= cur.c[9]) & act[r]) {
-                    int xr = x0 + r;
-                    asm volatile("" : "+v"(xr));
-                    const RayD ray = camera_ray<false>(P, xr, y);
-                    double ix, iy, iz, t;
-                    ++nexact;
-                    if (leaf_isect<LEAF_SPHERE>(L, ray, ix, iy, iz, t, false) && guards_ok<false>(P.guards, L.guard, ray)) {
-                        if (t < bt[r] || (t == bt[r] && gid < bid[r]) || bid[r] < 0) { bt[r] = t; bid[r] = gid; }
-                    }
-                }
-            }
-        }
-    }
-}
-
-template <bool SHARED_Y>
-__global__ void RT_HOT(RT_WAVES_EU_PRIMARY) k_primary(const RenderParams P) {
-    int x0, y; bool row_ok;
-    tile_coords(P, x0, y, row_ok);
-    bool act[4];
-    Eye4 D;
-    {
-        float dx[4], dy[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            act[r] = row_ok && (x0 + r) < P.w;
-            double ox, oy;
-            sample_offset(P, x0 + r, y, ox, oy);
-            dx[r] = (float)(P.cam.scaleX * ((double)(x0 + r) + ox) + P.cam.dX);
-            dy[r] = (float)(P.cam.scaleY * ((double)y + oy) + P.cam.dY);
-        }
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            D.x[p] = f2{dx[2 * p], dx[2 * p + 1]};
-            D.y[p] = f2{dy[2 * p], dy[2 * p + 1]};
-        }
-        D.ys = dy[0];
-    }
-    double bt[4]; int bid[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { bt[r] = INFINITY; bid[r] = -1; }
-    unsigned nexact = 0;
-    primary_loop<LEAF_TRI, SHARED_Y>(P, as_const(P.tri_rec), as_const(P.tri_gid), P.ntri, D, act, x0, y, bt, bid, nexact);
-    primary_loop<LEAF_RECT, SHARED_Y>(P, as_const(P.rect_rec), as_const(P.rect_gid), P.nrect, D, act, x0, y, bt, bid, nexact);
-    if (P.nsph > 0) primary_sphere_loop(P, D, act, x0, y, bt, bid, nexact);
-    const long long row = P.out_off + (long long)(y - P.row0) * P.w;
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-        if (act[r]) P.hit_id[row + (x0 + r)] = bid[r];
-    for (int o = 32; o > 0; o >>= 1) nexact += __shfl_down(nexact, o);
-    if ((threadIdx.x & 63) == 0 && nexact) stat_add(P, 1, (unsigned long long)nexact);
-}
-
-#endif // RT_VALU_FILTER
 // ------------------------------------------------------------------------------------------
 // Kernel 2: per hit pixel, the exact hit point and shading normal; shadow jobs for every point light
 //   with L.N > 0, compacted into one queue per light (wave-aggregated atomics).
 //   When L.N <= 0 both Phong terms are exactly 0 (Main.hs:480-484), so the shadow ray cannot change
 //   the pixel and is not cast.
 
-__device__ __forceinline__ void to_light(bool talk, const LightD &Lt, double hx, double hy, double hz, double &tx, double &ty, double &tz) {
-    const double lx = Lt.px - hx, ly = Lt.py - hy, lz = Lt.pz - hz;                    // Main.hs:470
-    const double ln = sqrt(lx * lx + ly * ly + lz * lz);
-    if (talk) { const double rn = 1.0 / ln; tx = rn * lx; ty = rn * ly; tz = rn * lz; return; }   // Talk.hs:239, 66-67
-    tx = lx / ln; ty = ly / ln; tz = lz / ln;
-}
-
-// Haskell `round` (half-even) then fromInteger to Word8 (wraps) — Main.hs:451-456
-__device__ __forceinline__ int round8(double v) {
-    const double r = __builtin_rint(v);
-    if (!(fabs(r) < 9.0e18)) return 0;
-    return (int)((long long)r & 0xff);
-}
-__device__ __forceinline__ double hs_max0(double v) { return 0.0 <= v ? v : 0.0; }    // max 0 v
-
-// x ** specularity (Main.hs:483).  A DELIBERATE departure from the reference's expression: materials carry small whole
-// exponents (1, 20, 100, 400 in the reference's scenes) and for whole n <= 512 the power is taken by squaring.  Every
-// squaring doubles the relative error of its operand, so the result is off by up to about n * 2^-53 (4e-14 at n = 400),
-// where libm's pow is within one rounding of the real power: an 8-bit colour differs from the reference's only if
-// f * 255 lies within ~n * 3e-14 of a rounding boundary (never seen: test_whole_and_fractional_specular_exponents, the
-// fuzzers).  Larger and fractional exponents go through pow.
-#ifndef RT_POWI
-#define RT_POWI 1
-#endif
-__device__ __forceinline__ double pow_spec(double x, double sp) {
-#if RT_POWI
-    const int n = (int)sp;
-    if ((double)n == sp && n >= 0 && n <= 512) {
-        double r = 1.0, b = x;
-        for (int k = n; k != 0; k >>= 1) { if (k & 1) r *= b; b *= b; }
-        return r;
-    }
-#endif
-    return pow(x, sp);
-}
-
-// What a point light adds to a pixel it reaches: pointLight (Main.hs:476-487) or Talk.hs's pointLight (Talk.hs:244-248).
-// k_final adds it for the lights that reach the pixel; k_setup evaluates the same function first and casts no shadow
-// ray where it is (0, 0, 0) — a black material, a grazing light: the shadow test could not change the pixel.
-__device__ __forceinline__ void light_terms(const RenderParams &P, const LightD &Lt, const MaterialD &M, const HitRec &H,
-                                            const RayD &ray, int &r, int &g, int &b) {
-    double tx, ty, tz;
-    to_light(RT_TALK(P), Lt, H.px, H.py, H.pz, tx, ty, tz);
-    const double lndot = tx * H.nx + ty * H.ny + tz * H.nz;
-    if (RT_TALK(P)) {                                                                  // Talk.hs:244-248
-        const double v = hs_max0(lndot) * Lt.diffuse;
-        const double f = (1.0 <= v) ? 1.0 : v;                                         // min 1 v
-        r = round8(f * (double)M.diffuse[0]); g = round8(f * (double)M.diffuse[1]); b = round8(f * (double)M.diffuse[2]);
-        return;
-    }
-    const double k2 = 2 * lndot;
-    const double rx = tx - k2 * H.nx, ry = ty - k2 * H.ny, rz = tz - k2 * H.nz;
-    const double fDiffuse = Lt.diffuse * hs_max0(lndot);
-    const double fSpecular = (lndot <= 0) ? 0.0
-        : Lt.specular * pow_spec(hs_max0(rx * ray.dx + ry * ray.dy + rz * ray.dz), M.specularity);
-    r = min(255, round8(fDiffuse * (double)M.diffuse[0]) + round8(fSpecular * (double)M.specular[0]));
-    g = min(255, round8(fDiffuse * (double)M.diffuse[1]) + round8(fSpecular * (double)M.specular[1]));
-    b = min(255, round8(fDiffuse * (double)M.diffuse[2]) + round8(fSpecular * (double)M.specular[2]));
-}
-
-#ifndef RT_SETUP_THREADS
-#define RT_SETUP_THREADS 512
-#endif
 #ifndef RT_WAVES_EU_SETUP
 #define RT_WAVES_EU_SETUP 4
 #endif
@@ -855,9 +184,6 @@ __global__ void __launch_bounds__(1024) k_queue_offsets(const RenderParams P) {
 }
 
 // Moves every k_setup block's run of jobs to its place in the light's dense queue.
-#ifndef RT_COMPACT_THREADS
-#define RT_COMPACT_THREADS 128
-#endif
 __global__ void __launch_bounds__(RT_COMPACT_THREADS) k_queue_compact(const RenderParams P) {
     const int pl = (int)blockIdx.y;
     const size_t slot = (size_t)pl * (size_t)P.setup_blocks + blockIdx.x;
@@ -868,169 +194,6 @@ __global__ void __launch_bounds__(RT_COMPACT_THREADS) k_queue_compact(const Rend
         P.queue[(size_t)pl * (size_t)P.qcap + off + i] = P.qsparse[slot * RT_SETUP_THREADS + i];
 }
 
-// ------------------------------------------------------------------------------------------
-// Kernel 3: shadow rays of one point light (blockIdx.y), 4 jobs per lane, brute force over all leaves.
-//   replaces `intersect world ray_to_light` + the t <= distance test of pointLight (Main.hs:472-474).
-//   Apex = the light, D = shadow-ray origin - light; the filter's clip keeps leaves between them.
-
-#ifdef RT_VALU_FILTER   // the FP32 vector-ALU kernel family: cross-check build only (libraytrace_gpu_valu.so)
-template <int KIND>
-__device__ __forceinline__ void shadow_loop(const RenderParams &P, CRecPtr recs, CIntPtr gids, int n, const Dir4 &D,
-                                            const uint32_t pix[4], const int own[4], const LightD &Lt, bool need[4],
-                                            unsigned &nexact) {
-    constexpr int NLOAD = RT_SHADOW_CLIP ? 11 : 10;   // the hot test reads c[0..9]; Kq and N stay in memory
-    if (n <= 0) return;
-    auto body = [&](const FilterRec &cur, int i) {
-        float z[4];
-        if (filter4<KIND, RT_SHADOW_CLIP != 0>(cur, D, z)) {
-            const float negm = cur.c[9];
-#ifdef RT_COUNT_EVENTS
-            if ((threadIdx.x & 63) == __builtin_amdgcn_readfirstlane(threadIdx.x & 63)) stat_add(P, 3, 1ull);
-#endif
-            bool cand[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) cand[r] = (z[r] >= negm) & need[r];
-#if !RT_SHADOW_CLIP
-            // The fast filter tests the whole line from the light through the shadow-ray origin.  Keep only the
-            // rays whose SEGMENT light..origin can meet the plane: N.D >= Kq (Main.hs:474 needs t <= distance).
-            // Kq and N are fetched here, on the rare path, so the loop carries 10 SGPRs per record, not 14.
-            const float kq = recs[i].c[10], nx = recs[i].c[11], ny = recs[i].c[12], nz = recs[i].c[13];
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                const f2 nd = pkfma(splat(nx), D.x[p], pkfma(splat(ny), D.y[p], splat(nz) * D.z[p]));
-                cand[2 * p] &= nd[0] >= kq;
-                cand[2 * p + 1] &= nd[1] >= kq;
-            }
-#endif
-            if (cand[0] | cand[1] | cand[2] | cand[3]) {
-                const int gid = gids[i];
-                const LeafD &L = P.leaves[gid];
-#ifdef RT_COUNT_EVENTS
-                if ((threadIdx.x & 63) == __builtin_amdgcn_readfirstlane(threadIdx.x & 63)) stat_add(P, 4, 1ull);
-#endif
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    // the hit leaf itself lies 1e-5 behind the shadow-ray origin (Main.hs:472): t < 0
-                    if (cand[r] & (own[r] != gid)) {
-                        uint32_t pr = pix[r];
-                        asm volatile("" : "+v"(pr));   // keep the exact-path ray set-up inside this rare branch
-                        const HitRec H = P.hitrec[pr];
-                        double tx, ty, tz;
-                        to_light(false, Lt, H.px, H.py, H.pz, tx, ty, tz);
-                        const RayD ray = mkray(H.px + 0.00001 * tx, H.py + 0.00001 * ty, H.pz + 0.00001 * tz,
-                                               tx, ty, tz, P.eps);                     // Main.hs:472
-                        double ix, iy, iz, t;
-                        ++nexact;
-                        if (leaf_isect<KIND>(L, ray, ix, iy, iz, t, false) && guards_ok<false>(P.guards, L.guard, ray)) {
-                            const double tl = (Lt.pz - ray.pz) * ray.rz;               // rayDistance ray lpos
-                            const bool occ = false ? ((Lt.px - ix) * tx + (Lt.py - iy) * ty + (Lt.pz - iz) * tz >= 0)   // Talk.hs:242
-                                                    : (t <= tl);                        // Main.hs:474
-                            if (occ) need[r] = false;                                  // -> black
-                        }
-                    }
-                }
-            }
-        }
-    };
-#if RT_PREFETCH
-    FilterRec a = load_rec<NLOAD>(recs);                   // two SGPR buffers used in turn, see primary_loop
-    int i = 0;
-    for (; i + 1 < n; i += 2) {
-        const FilterRec b = load_rec<NLOAD>(after(recs + i + 1, a));
-        body(a, i);
-        a = load_rec<NLOAD>(after(recs + i + 2, b));
-        body(b, i + 1);
-    }
-    if (i < n) body(a, i);
-#else
-    for (int i = 0; i < n; ++i) body(load_rec<NLOAD>(recs + i), i);
-#endif
-}
-
-#endif // RT_VALU_FILTER
-// spheres between a light and the shadow-ray origins (no own-leaf exclusion: a sphere is not planar)
-__device__ __forceinline__ void shadow_sphere_loop(const RenderParams &P, CRecPtr recs, const Dir4 &D, const uint32_t pix[4],
-                                                const LightD &Lt, bool need[4], unsigned &nexact) {
-    f2 dd[2];
-    dir_norms(D, dd);
-    CIntPtr gids = as_const(P.sph_gid);
-    for (int i = 0; i < P.nsph; ++i) {
-        const FilterRec cur = load_rec(recs + i);
-        float z[4];
-        if (filter4_sphere(cur, D, dd, z)) {
-            const int gid = gids[i];
-            const LeafD &L = P.leaves[gid];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if ((z[r] >= cur.c[9]) & need[r]) {
-                    uint32_t pr = pix[r];
-                    asm volatile("" : "+v"(pr));
-                    const HitRec H = P.hitrec[pr];
-                    double tx, ty, tz;
-                    to_light(false, Lt, H.px, H.py, H.pz, tx, ty, tz);
-                    const RayD ray = mkray(H.px + 0.00001 * tx, H.py + 0.00001 * ty, H.pz + 0.00001 * tz, tx, ty, tz, P.eps);
-                    double ix, iy, iz, t;
-                    ++nexact;
-                    if (leaf_isect<LEAF_SPHERE>(L, ray, ix, iy, iz, t, false) && guards_ok<false>(P.guards, L.guard, ray)) {
-                        const double tl = (Lt.pz - ray.pz) * ray.rz;
-                        if (t <= tl) need[r] = false;
-                    }
-                }
-            }
-        }
-    }
-}
-
-#ifdef RT_VALU_FILTER   // the FP32 vector-ALU kernel family: cross-check build only (libraytrace_gpu_valu.so)
-__global__ void RT_HOT(RT_WAVES_EU_SHADOW) k_shadow(const RenderParams P) {
-    const int pl = (int)blockIdx.y;
-    const unsigned count = P.qcount[pl];
-    const unsigned wave = blockIdx.x * RT_WAVES_PER_BLOCK + (threadIdx.x >> 6);
-    if (wave * 256u >= count) return;
-    const int lane = (int)(threadIdx.x & 63);
-    // the pl-th point light
-    const int li = P.point_light[pl];
-    const LightD &Lt = P.lights[li];
-    const uint32_t *q = P.queue + (size_t)pl * (size_t)P.qcap;
-    uint32_t pix[4]; bool need[4]; int own[4];
-    float ddx[4], ddy[4], ddz[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const unsigned j = wave * 256u + (unsigned)(r * 64 + lane);
-        need[r] = j < count;
-        pix[r] = need[r] ? q[j] : 0u;
-        own[r] = need[r] ? P.hit_id[P.out_off + pix[r]] : -1;
-        ddx[r] = ddy[r] = ddz[r] = 0.f;
-        if (need[r]) {
-            const HitRec H = P.hitrec[pix[r]];
-            double tx, ty, tz;
-            to_light(false, Lt, H.px, H.py, H.pz, tx, ty, tz);
-            ddx[r] = (float)((H.px + 0.00001 * tx) - Lt.px);
-            ddy[r] = (float)((H.py + 0.00001 * ty) - Lt.py);
-            ddz[r] = (float)((H.pz + 0.00001 * tz) - Lt.pz);
-        }
-    }
-    Dir4 D;
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        D.x[p] = f2{ddx[2 * p], ddx[2 * p + 1]};
-        D.y[p] = f2{ddy[2 * p], ddy[2 * p + 1]};
-        D.z[p] = f2{ddz[2 * p], ddz[2 * p + 1]};
-    }
-    unsigned nexact = 0;
-    // wave-uniform by construction; say so, or the record loads become per-lane vector loads
-    const size_t ro = (size_t)__builtin_amdgcn_readfirstlane(Lt.rec_offset);
-    shadow_loop<LEAF_TRI>(P, as_const(P.tri_rec + ro * (size_t)P.ntri), as_const(P.tri_gid), P.ntri, D, pix, own, Lt, need, nexact);
-    shadow_loop<LEAF_RECT>(P, as_const(P.rect_rec + ro * (size_t)P.nrect), as_const(P.rect_gid), P.nrect, D, pix, own, Lt, need, nexact);
-    if (P.nsph > 0) shadow_sphere_loop(P, as_const(P.sph_rec + ro * (size_t)P.nsph), D, pix, Lt, need, nexact);
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-        if (need[r]) atomicOr(&P.lit_w[pix[r]], 1u << pl);
-    for (int o = 32; o > 0; o >>= 1) nexact += __shfl_down(nexact, o);
-    if (lane == 0 && nexact) stat_add(P, 2, (unsigned long long)nexact);
-}
-
-#endif // RT_VALU_FILTER
 // ------------------------------------------------------------------------------------------
 // Matrix-core versions of kernels 1 and 3.
 //
@@ -2454,1065 +1617,49 @@ __global__ void __launch_bounds__(256) k_cb_gather(const RenderParams P) {
 
 } // namespace
 
-// Scratch of rt_render_device_noalloc (for callers that cannot allocate: HIP graph capture, tight serving loops):
-// every buffer a render needs beyond its inputs and outputs is carved out of this array instead of hipMalloc'ed.
-// Each GPU the library runs on holds its own copy, at its own address, until the process ends.  On the host the name
-// is only a stand-in for HIP_SYMBOL(): the device address comes from hipGetSymbolAddress (device_init), once per device.
-constexpr size_t RT_STATIC_SCRATCH_BYTES = 64u << 20;
-static __device__ __align__(256) unsigned char scratch[RT_STATIC_SCRATCH_BYTES];
-
-namespace {
-
-// ------------------------------------------------------------------------------------------
-// Host side
-
-// Library state per device and per thread.  Everything else lives in the (scene, device) pair: streams, events,
-// uploaded records, work buffers — so distinct scenes can be rendered from different threads.
-struct DeviceCtx {
-    bool ready = false;
-    unsigned char *scratch = nullptr;    // this device's copy of `scratch` (hipGetSymbolAddress, with the device current)
-};
-DeviceCtx g_ctx[RT_MAX_DEVICES];
-std::mutex g_ctx_mutex;
-thread_local int t_device = -1;          // the device this thread renders on (rt_init)
-
-bool hip_ok(hipError_t e, const char *what) {
-    if (e == hipSuccess) return true;
-    set_error(std::string(what) + ": " + hipGetErrorString(e));
-    return false;
+namespace rt {
+void launch_primary_mfma(const RenderParams &P, unsigned tblocks, hipStream_t st) { hipLaunchKernelGGL(k_primary_mfma, dim3(tblocks), dim3(RT_WAVES_PER_BLOCK * 64), 0, st, P); }
+void launch_shadow_mfma(const RenderParams &P, unsigned sblocks, unsigned nlights, hipStream_t st) { hipLaunchKernelGGL(k_shadow_mfma, dim3(sblocks, nlights), dim3(RT_WAVES_PER_BLOCK * 64), 0, st, P); }
+void launch_setup(const RenderParams &P, unsigned ublocks, hipStream_t st) { hipLaunchKernelGGL(k_setup, dim3(ublocks), dim3(RT_SETUP_THREADS), 0, st, P); }
+void launch_queue_offsets(const RenderParams &P, unsigned nlights, hipStream_t st) { hipLaunchKernelGGL(k_queue_offsets, dim3(nlights), dim3(1024), 0, st, P); }
+void launch_queue_compact(const RenderParams &P, unsigned ublocks, unsigned nlights, hipStream_t st) { hipLaunchKernelGGL(k_queue_compact, dim3(ublocks, nlights), dim3(RT_COMPACT_THREADS), 0, st, P); }
+void launch_final(const RenderParams &P, unsigned blocks, unsigned threads, hipStream_t st) { hipLaunchKernelGGL(k_final, dim3(blocks), dim3(threads), 0, st, P); }
+void launch_general(const RenderParams &P, unsigned runs, hipStream_t st) { hipLaunchKernelGGL(k_general, dim3(runs), dim3(64), 0, st, P); }
+void launch_combine(const RayRec *rays, const uint32_t *col, const unsigned *count, unsigned cap, uint32_t *parent_col, unsigned blocks, hipStream_t st) {
+    hipLaunchKernelGGL(k_combine, dim3(blocks), dim3(256), 0, st, rays, col, count, cap, parent_col);
 }
-#define HIP_TRY(expr) do { if (!hip_ok((expr), #expr)) return RT_ERR_HIP; } while (0)
+void launch_store(const RenderParams &P, unsigned blocks, hipStream_t st) { hipLaunchKernelGGL(k_store, dim3(blocks), dim3(256), 0, st, P); }
+void launch_resolve(const uint32_t *accum, uint8_t *rgba, size_t npix, uint32_t spp, hipStream_t st) {
+    hipLaunchKernelGGL(k_resolve, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, accum, rgba, npix, spp);
+}
+void launch_cb_gather(const RenderParams &P, unsigned blocks, hipStream_t st) { hipLaunchKernelGGL(k_cb_gather, dim3(blocks), dim3(256), 0, st, P); }
 
+const char *kernel_build_flags() {
+    return ""
+#ifdef RT_MEASUREMENT_BUILD
+        " MEASUREMENT BUILD (results may differ from the reference's):"
+#ifdef RT_NO_GUARDS
+        " RT_NO_GUARDS"
+#endif
+#ifdef RT_X_NOSCAN
+        " RT_X_NOSCAN"
+#endif
+#ifdef RT_X_SCANONLY
+        " RT_X_SCANONLY"
+#endif
+#ifdef RT_MF_NOSLOW
+        " RT_MF_NOSLOW"
+#endif
+#ifdef RT_NO_DEPTH_SKIP
+        " RT_NO_DEPTH_SKIP"
+#endif
+#ifdef RT_NO_TALK
+        " RT_NO_TALK"
+#endif
+#endif
 #ifdef RT_WAVE_TIMES
-unsigned long long *g_wave_dbg = nullptr;
+        " RT_WAVE_TIMES"
 #endif
-
-double now_ms() {
-    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+        ;
 }
-
-// Sets the library up on `device` and makes it the calling thread's device.
-int device_init(int device) {
-    int n = 0;
-    if (!hip_ok(hipGetDeviceCount(&n), "hipGetDeviceCount") || n <= 0) {
-        set_error("rt_init: no HIP device available (this library has no CPU fallback)");
-        return RT_ERR_HIP;
-    }
-    if (device < 0 || device >= n || device >= RT_MAX_DEVICES) { set_error("rt_init: device index out of range"); return RT_ERR_ARG; }
-    HIP_TRY(hipSetDevice(device));
-    {
-        std::lock_guard<std::mutex> lock(g_ctx_mutex);
-        DeviceCtx &C = g_ctx[device];
-        if (!C.ready) {
-            unsigned char *ptr = nullptr;
-            if (!hip_ok(hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch)), "hipGetSymbolAddress(scratch)") || !ptr) return RT_ERR_HIP;
-            C.scratch = ptr;
-            C.ready = true;
-        }
-    }
-    t_device = device;
-    return RT_OK;
-}
-// Every entry point that touches the device starts here: the thread's device is made current again (the caller may
-// have switched it, e.g. through another library).
-int enter() {
-    if (t_device < 0) return device_init(0);
-    HIP_TRY(hipSetDevice(t_device));
-    return RT_OK;
-}
-
-// The resident copy of a scene is ONE allocation (DeviceScene::arena) that the arrays are views of: a first upload is one
-// hipMalloc and a run of copies on the scene's stream instead of ~25 allocations and blocking copies (a one-shot caller
-// pays for it: examples/cold_start.cpp).  plan(): size of the views, 256-byte aligned; place(): view + copy.
-struct UploadPlan {
-    size_t total = 0;
-    template <typename T> void add(const std::vector<T> &src) { total = ((total + 255) & ~(size_t)255) + sizeof(T) * (src.empty() ? 1 : src.size()); }
-};
-template <typename T>
-int place(DeviceScene &D, size_t &off, DevBuf &dst, const std::vector<T> &src, unsigned char *staging) {
-    off = (off + 255) & ~(size_t)255;
-    const size_t bytes = sizeof(T) * (src.empty() ? 1 : src.size());
-    dst.p = (char *)D.arena.p + off; dst.cap = bytes;
-    if (!src.empty()) std::memcpy(staging + off, src.data(), sizeof(T) * src.size());
-    off += bytes;
-    return RT_OK;
-}
-// elements [first, first + count) of an array that is already resident
-template <typename T>
-int upload_slice(DevBuf &dst, const std::vector<T> &src, size_t first, size_t count) {
-    if (count == 0) return RT_OK;
-    if (!dst.p || dst.cap < sizeof(T) * (first + count) || src.size() < first + count) { set_error("upload_slice: array not resident"); return RT_ERR_ARG; }
-    HIP_TRY(hipMemcpy((char *)dst.p + sizeof(T) * first, src.data() + first, sizeof(T) * count, hipMemcpyHostToDevice));
-    return RT_OK;
-}
-
-template <typename T>
-int ensure(T *&buf, size_t &cap, size_t need) {
-    if (cap >= need && buf) return RT_OK;
-    if (buf) { HIP_TRY(hipFree(buf)); buf = nullptr; cap = 0; }
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&buf), sizeof(T) * (need ? need : 1)));
-    cap = need;
-    return RT_OK;
-}
-
-// Makes the scene resident on the thread's device for w x h renders (rt_scene_prepare_device).
-// What the runtime sets up when streams are first made costs a one-shot caller milliseconds (a stream = a hardware queue:
-// 8 ms for the first of a process, 4.6 ms for the two copy streams and their events; examples/cold_start.cpp): a helper
-// thread makes them while the calling thread builds the host index and uploads.  The render stream is waited for in
-// device_prepare; the copy tools by the first call that needs them (copy_tools), or by rt_scene_destroy.
-struct Helper { std::thread th; std::mutex m; std::condition_variable cv; bool stream_ready = false; hipError_t err = hipSuccess; };
-void helper_join(DeviceScene &D) {
-    Helper *H = static_cast<Helper *>(D.helper);
-    if (!H) return;
-    if (H->th.joinable()) H->th.join();
-    delete H;
-    D.helper = nullptr;
-}
-int make_copy_tools(DeviceScene &D) {
-    if (!D.copy_stream) { hipStream_t st; HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); D.copy_stream = st; }
-    if (!D.copy_stream2) { hipStream_t st; HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); D.copy_stream2 = st; }
-    for (void *&e : D.band_done) if (!e) { hipEvent_t ev; HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); e = ev; }
-    for (void *&e : D.hits_done) if (!e) { hipEvent_t ev; HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); e = ev; }
-    return RT_OK;
-}
-
-int device_prepare(rt_scene &s, DeviceScene &D, int device, int w, int h) {
-    if (!D.stream && !D.helper && !host_ready(s, w, h)) {
-        Helper *H = new Helper;
-        D.helper = H;
-        H->th = std::thread([&D, H, device] {
-            hipStream_t st = nullptr;
-            hipError_t e = hipSetDevice(device);
-            if (e == hipSuccess) e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
-            {
-                std::lock_guard<std::mutex> lock(H->m);
-                if (e == hipSuccess) D.stream = st;
-                H->err = e; H->stream_ready = true;
-            }
-            H->cv.notify_all();
-            if (e == hipSuccess && make_copy_tools(D) != RT_OK) (void)hipGetLastError();     // (copy_tools() makes what is missing, and reports)
-        });
-    }
-    D.device = device;              // (from here on rt_scene_destroy looks at this entry)
-    const bool host_ok = prepare_host(s, w, h);
-    if (Helper *H = static_cast<Helper *>(D.helper)) {
-        std::unique_lock<std::mutex> lock(H->m);
-        H->cv.wait(lock, [H] { return H->stream_ready; });
-        if (H->err != hipSuccess) { const hipError_t e = H->err; lock.unlock(); helper_join(D); HIP_TRY(e); }
-    }
-    if (!host_ok) return RT_ERR_ARG;
-    if (s.mf_groups + 2 > 65535) { set_error("rt_render: more than 2 million planar leaves are not supported (16-bit block indices)"); return RT_ERR_UNSUPPORTED; }
-    if (!D.stream) { hipStream_t st; HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); D.stream = st; }
-    if (D.version == s.version && D.eye_version == s.eye_version) return RT_OK;
-    const double t0 = now_ms();
-    int rc;
-    // a render of the stale copy may still be in flight on some stream: the arrays are overwritten in place
-    if (D.version != 0) HIP_TRY(hipDeviceSynchronize());
-    const size_t nsph = s.sph_gid.size();
-#ifdef RT_VALU_FILTER
-    const size_t ntri = s.tri_gid.size(), nrect = s.rect_gid.size();
-#endif
-    const size_t gstride = (size_t)s.mf_groups + 2;
-    if (D.version != s.version) {
-        // every array of the scene, in one arena (grown with a quarter of slack so that a slightly bigger scene fits again)
-        auto each = [&](auto &&f) -> int {
-            int r;
-            if ((r = f(D.leaves, s.leaves)) || (r = f(D.aux, s.aux)) || (r = f(D.guards, s.guards)) || (r = f(D.mats, s.mats)) ||
-                (r = f(D.lights, s.lights)) || (r = f(D.tri_rec, s.tri_rec)) || (r = f(D.rect_rec, s.rect_rec)) ||
-                (r = f(D.sph_rec, s.sph_rec)) || (r = f(D.sph_gid, s.sph_gid)) || (r = f(D.mf_rows, s.mf_rows)) ||
-                (r = f(D.mf_gid, s.mf_gid)) || (r = f(D.mf_cone, s.mf_cone)) || (r = f(D.mf_rec, s.mf_rec)) ||
-                (r = f(D.tri_gid, s.tri_gid)) || (r = f(D.rect_gid, s.rect_gid))) return r;
-            if (s.reflective) {
-                if ((r = f(D.gen_sph, s.gen_sph)) || (r = f(D.gen_tri, s.gen_tri)) || (r = f(D.gen_rect, s.gen_rect)) ||
-                    (r = f(D.gen_tri_gid, s.gen_tri_gid)) || (r = f(D.gen_rect_gid, s.gen_rect_gid)) ||
-                    (r = f(D.gen_tri_sph, s.gen_tri_sph)) || (r = f(D.gen_rect_sph, s.gen_rect_sph)) ||
-                    (r = f(D.gen_tri_rows, s.gen_tri_rows)) || (r = f(D.gen_rect_rows, s.gen_rect_rows)) ||
-                    (r = f(D.gen_tri_ssph, s.gen_tri_ssph)) || (r = f(D.gen_rect_ssph, s.gen_rect_ssph))) return r;
-            }
-            return RT_OK;
-        };
-        UploadPlan plan;
-        (void)each([&](DevBuf &, const auto &src) { plan.add(src); return (int)RT_OK; });
-        if (!D.arena.p || D.arena.cap < plan.total) {
-            if (D.arena.p) { HIP_TRY(hipFree(D.arena.p)); D.arena.p = nullptr; D.arena.cap = 0; }
-            const size_t cap = plan.total + plan.total / 4 + 4096;
-            HIP_TRY(hipMalloc(&D.arena.p, cap));
-            D.arena.cap = cap;
-        }
-        // the arrays are laid out in a host image of the arena and travel in ONE copy (25 copies out of pageable vectors
-        // cost 8.7 ms for 10 MB: each one is staged and waited for on its own)
-        size_t off = 0;
-        unsigned char *image = nullptr;                   // page-locked: one DMA, no staging inside the runtime
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&image), plan.total, hipHostMallocDefault));
-        rc = each([&](DevBuf &dst, const auto &src) { return place(D, off, dst, src, image); });
-        if (rc == RT_OK && (!hip_ok(hipMemcpyAsync(D.arena.p, image, off, hipMemcpyHostToDevice, (hipStream_t)D.stream), "hipMemcpyAsync") ||
-                            !hip_ok(hipStreamSynchronize((hipStream_t)D.stream), "hipStreamSynchronize"))) rc = RT_ERR_HIP;   // complete on return
-        (void)hipHostFree(image);
-        if (rc) return rc;
-    } else {
-        // only the camera bound grew: apex 0 (the eye) of every per-apex array
-#ifdef RT_VALU_FILTER
-        if ((rc = upload_slice(D.tri_rec, s.tri_rec, 0, ntri))) return rc;
-        if ((rc = upload_slice(D.rect_rec, s.rect_rec, 0, nrect))) return rc;
-#endif
-        if ((rc = upload_slice(D.sph_rec, s.sph_rec, 0, nsph))) return rc;
-        if ((rc = upload_slice(D.mf_rows, s.mf_rows, 0, gstride * 32 * 8))) return rc;
-        if ((rc = upload_slice(D.mf_gid, s.mf_gid, 0, gstride * MF_LEAVES))) return rc;
-        if ((rc = upload_slice(D.mf_cone, s.mf_cone, 0, gstride * 8))) return rc;
-        if ((rc = upload_slice(D.mf_rec, s.mf_rec, 0, gstride * MF_LEAVES))) return rc;
-    }
-    D.version = s.version;
-    D.eye_version = s.eye_version;
-    D.stats.upload_ms = now_ms() - t0;
-    return RT_OK;
-}
-
-// The streams and events of the copies to host memory (rt_render) and between devices (rt_render_multi).
-int copy_tools(DeviceScene &D) {
-    helper_join(D);                 // (it may be making them right now)
-    return make_copy_tools(D);
-}
-
-// event pool: one event per kernel boundary, so that rt_get_stats can attribute time to each kernel
-int next_event(DeviceScene &D, hipStream_t st, int kind) {
-    if (D.ev_used == (int)D.evpool.size()) {
-        hipEvent_t e;
-        HIP_TRY(hipEventCreate(&e));
-        D.evpool.push_back(e);
-        D.evkind.push_back(0);
-    }
-    D.evkind[D.ev_used] = kind;
-    HIP_TRY(hipEventRecord((hipEvent_t)D.evpool[D.ev_used], st));
-    ++D.ev_used;
-    return RT_OK;
-}
-
-constexpr size_t RT_CHUNK_PIXELS = 16u << 20;   // rows are processed in chunks of about 16 Mi pixels
-
-int render_levels(const rt_scene *s, int depth) {
-    return (s->reflective && depth > 1 && !s->talk) ? (depth < RT_MAX_LEVELS ? depth : RT_MAX_LEVELS) : 1;
-}
-bool levels_supported(const rt_scene *s, int depth) {
-    if (s->reflective && !s->talk && depth > RT_MAX_LEVELS) {
-        set_error("rt_render: trace depth > 64 with reflective materials is not supported"); return false;
-    }
-    return true;
-}
-
-// What one render needs beyond its inputs and outputs, in elements of each buffer.
-struct WsNeeds {
-    size_t hit_id = 0, accum = 0, hitrec = 0, queue = 0, qsparse = 0, tcount = 0, lit = 0, lvl = 0, cb = 0;
-    int levels = 1;
-};
-// slots of a bounce level: k_final hands every wave of 8 x 8 pixels that reflects anything a run of 64 slots, so a level
-// can hold the chunk's pixels padded to whole 32 x 8 tiles (and no more: deeper levels never grow)
-size_t level_capacity(int w, size_t rows) {
-    return (size_t)((w + 31) / 32) * 32 * ((rows + 7) / 8) * 8;
-}
-size_t setup_blocks_bound(int w, size_t crow, bool levels) {   // k_setup blocks of a chunk: 32 x 16 pixel tiles at level 0, runs of slots above
-    const size_t slots = levels ? level_capacity(w, crow) : crow * (size_t)w;
-    return std::max((size_t)((w + 31) / 32) * ((crow + RT_SETUP_THREADS / 32 - 1) / (RT_SETUP_THREADS / 32)),
-                    (slots + RT_SETUP_THREADS - 1) / RT_SETUP_THREADS);
-}
-WsNeeds ws_needs(int w, int nrows, size_t crow, int npoint, int levels, int spp, bool own_hit, bool shade, bool callbacks) {
-    WsNeeds n;
-    const size_t npix = (size_t)w * (size_t)nrows, np = (size_t)(npoint > 0 ? std::min(npoint, 32) : 1);
-    const size_t groups = (size_t)std::max(1, (npoint + 31) / 32);
-    const size_t cpix = levels > 1 ? level_capacity(w, crow) : crow * (size_t)w;      // slots of a chunk (bounce levels: padded)
-    n.levels = levels;
-    if (own_hit || spp > 1) n.hit_id = npix;
-    if (!shade) return n;
-    if (spp > 1) n.accum = 3 * npix;
-    n.hitrec = cpix * sizeof(HitRec);
-    n.lit = cpix * groups;
-    n.queue = cpix * np;
-    const size_t ub = setup_blocks_bound(w, crow, levels > 1);
-    n.qsparse = ub * RT_SETUP_THREADS * np;
-    n.tcount = (ub + 1) * np;
-    if (levels > 1) n.lvl = cpix;
-    if (callbacks) n.cb = cpix;
-    return n;
-}
-// Carves the buffers of `n` out of [base, base + cap); returns the bytes used, or 0 if they do not fit.  base == nullptr:
-// sizing only (W is left empty).
-size_t ws_carve(unsigned char *base, size_t cap, const WsNeeds &n, Workspace &W) {
-    size_t used = 0;
-    bool fits = true;
-    auto take = [&](auto *&ptr, size_t count) {
-        using T = std::remove_reference_t<decltype(*ptr)>;
-        used = (used + 255) & ~(size_t)255;
-        if (used + count * sizeof(T) > cap) { fits = false; return; }
-        if (base) ptr = reinterpret_cast<T *>(base + used);
-        used += count * sizeof(T);
-    };
-    W = Workspace{};
-    // the queue counters sit right behind the statistics counters, at the start: a render clears both with one fill, and
-    // the part of them that lives across renders (the lights' cost history) keeps its place whatever else is carved
-    take(W.counters, (size_t)RT_STAT_SLOTS * 16 + ((size_t)RT_QCOUNT_WORDS + 1) / 2);
-    if (fits && base) W.qcount = reinterpret_cast<unsigned *>(reinterpret_cast<unsigned char *>(W.counters) + RT_COUNTER_BYTES);
-    if (n.hit_id) take(W.hit_id, n.hit_id);
-    if (n.accum) take(W.accum, n.accum);
-    if (n.hitrec) take(W.hitrec, n.hitrec);
-    if (n.lit) take(W.lit, n.lit);
-    if (n.queue) take(W.queue, n.queue);
-    if (n.qsparse) take(W.qsparse, n.qsparse);
-    if (n.tcount) take(W.tcount, n.tcount);
-    if (n.lvl) {
-        take(W.lvl_col[0], n.lvl);
-        for (int k = 1; k < n.levels && k < RT_MAX_LEVELS; ++k) { take(W.lvl_rays[k], n.lvl); take(W.lvl_hit[k], n.lvl); take(W.lvl_col[k], n.lvl); }
-    }
-    if (n.cb) { take(W.cb_slot, n.cb); take(W.cb_xy, 2 * n.cb); take(W.cb_group, n.cb); take(W.cb_normal, 3 * n.cb); }
-    return fits ? used : 0;
-}
-
-// rt_render / rt_render_device: the work buffers of the (scene, device) pair are views of ONE allocation
-// (DeviceScene::ws_arena), grown when a render needs more than it holds: a first render is one hipMalloc, not a dozen.
-int ws_grow(DeviceScene &D, const WsNeeds &n) {
-    Workspace sizing;
-    const size_t total = ws_carve(nullptr, ~(size_t)0 >> 1, n, sizing);
-    if (!D.ws_arena.p || D.ws_arena.cap < total) {
-        if (D.ws_arena.p) { HIP_TRY(hipFree(D.ws_arena.p)); D.ws_arena.p = nullptr; D.ws_arena.cap = 0; }     // (hipFree waits for what is in flight)
-        HIP_TRY(hipMalloc(&D.ws_arena.p, total));
-        D.ws_arena.cap = total;
-        // the counters that live across renders start at zero
-        HIP_TRY(hipMemsetAsync((unsigned char *)D.ws_arena.p + RT_COUNTER_BYTES, 0, RT_QCOUNT_WORDS * sizeof(unsigned), (hipStream_t)D.stream));
-        HIP_TRY(hipStreamSynchronize((hipStream_t)D.stream));
-    }
-    if (!ws_carve((unsigned char *)D.ws_arena.p, D.ws_arena.cap, n, D.ws)) { set_error("ws_grow: internal sizing error"); return RT_ERR_NOMEM; }
-    return RT_OK;
-}
-
-// RT_NORMAL_CALLBACK: between the nearest-hit kernel and k_setup, the hit points that lie on callback leaves go to the
-// host, the caller's fnorm is evaluated there (per callback group), and the normals come back.
-int run_normal_callbacks(rt_scene &s, const RenderParams &P, hipStream_t st, unsigned pblocks) {
-    HIP_TRY(hipMemsetAsync(P.cb_count, 0, sizeof(unsigned), st));
-    hipLaunchKernelGGL(k_cb_gather, dim3(pblocks), dim3(256), 0, st, P);
-    unsigned count = 0;
-    HIP_TRY(hipMemcpyAsync(&count, P.cb_count, sizeof(unsigned), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    if (count == 0) return RT_OK;
-    std::vector<double> xy(2 * (size_t)count), nrm(3 * (size_t)count);
-    std::vector<int32_t> grp(count);
-    HIP_TRY(hipMemcpy(xy.data(), P.cb_xy, xy.size() * sizeof(double), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(grp.data(), P.cb_group, grp.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
-    // the hit points sorted by callback group in one counting pass (a scene may register one group per interpolation cell:
-    // a scan of all points per group was O(groups x points)), then one call per group that has any
-    const size_t ngroups = s.normal_fn.size();
-    std::vector<unsigned> start(ngroups + 1, 0u), idx(count);
-    for (unsigned k = 0; k < count; ++k) if (grp[k] >= 0 && (size_t)grp[k] < ngroups) ++start[(size_t)grp[k] + 1];
-    for (size_t g = 0; g < ngroups; ++g) start[g + 1] += start[g];
-    {
-        std::vector<unsigned> fill(start.begin(), start.end() - 1);
-        for (unsigned k = 0; k < count; ++k) if (grp[k] >= 0 && (size_t)grp[k] < ngroups) idx[fill[(size_t)grp[k]]++] = k;
-    }
-    std::vector<double> gxy, gn;
-    for (size_t g = 0; g < ngroups; ++g) {
-        const size_t n = start[g + 1] - start[g];
-        if (n == 0) continue;
-        gxy.resize(2 * n); gn.assign(3 * n, 0.0);
-        for (size_t j = 0; j < n; ++j) { const size_t k = idx[start[g] + j]; gxy[2 * j] = xy[2 * k]; gxy[2 * j + 1] = xy[2 * k + 1]; }
-        s.normal_fn[g]((int)n, gxy.data(), gn.data(), s.normal_user[g]);
-        for (size_t j = 0; j < n; ++j)
-            for (int c = 0; c < 3; ++c) nrm[3 * (size_t)idx[start[g] + j] + c] = gn[3 * j + c];
-    }
-    HIP_TRY(hipMemcpy(const_cast<double *>(P.cb_normal), nrm.data(), nrm.size() * sizeof(double), hipMemcpyHostToDevice));
-    return RT_OK;
-}
-
-// Enqueues the kernels of one row band on `st`.  `more` = this band continues a frame whose earlier bands were
-// enqueued by the previous call(s): events, counters and ray counts then accumulate, so rt_get_stats describes the
-// whole frame.  `W` holds buffers of at least ws_needs(...) elements for chunks of `crow` rows; `timed` records an
-// event per kernel boundary (creates events on first use).
-int render_rows(rt_scene *s, DeviceScene &D, const Workspace &W, size_t crow, int w, int h, int depth, int spp, uint64_t seed,
-                int row0, int nrows, void *d_rgba, void *d_hit_id, hipStream_t st, bool more, bool timed, hipEvent_t hits_done = nullptr) {
-    // hits_done: recorded on `st` as soon as the caller's hit-ID buffer is complete (after the nearest-hit kernel of
-    // sample 0's last chunk: everything later only reads it), so that a copy of it can run beside the shading kernels
-    int rc;
-    const size_t npix = (size_t)w * (size_t)nrows;
-    if (!more) { D.last_primary = 0; D.ev_used = 0; }
-    D.last_primary += (uint64_t)npix * (uint64_t)spp;
-    D.stats_pending = false;
-    D.last_counters = W.counters;
-    s->last_device = D.device;
-    s->multi_stats = false;
-    if (npix == 0) return RT_OK;
-    (void)hipGetLastError();       // kernel launches report through the sticky error: start from a clean one
-    // bounce levels: trace n reflects at most n - 1 times (trace 0 = black, Main.hs:542); only scenes with a
-    // reflective material ever spawn a reflected ray (Main.hs:553)
-    const int levels = render_levels(s, depth);
-    int32_t *hit = (int32_t *)d_hit_id;
-    if (!hit) hit = W.hit_id;
-    if (spp > 1 && d_rgba) HIP_TRY(hipMemsetAsync(W.accum, 0, 3 * npix * sizeof(uint32_t), st));
-    // (a render's first chunk finds its queue counters cleared by the same fill as the statistics counters)
-    if (!more) HIP_TRY(hipMemsetAsync(W.counters, 0, RT_COUNTER_BYTES + RT_QCOUNT_CLEAR * sizeof(unsigned), st));
-    bool queues_clear = !more;
-
-#ifdef RT_VALU_FILTER
-    // the vector-ALU kernels are compiled for Main.hs only: a Talk.hs scene always takes the matrix-core kernels
-    const bool use_mfma = s->opt_filter == 0 || s->talk;
-#else
-    const bool use_mfma = true;
-#endif
-    RenderParams P{};
-    P.leaves = (const LeafD *)D.leaves.p; P.aux = (const AuxD *)D.aux.p; P.guards = (const GuardD *)D.guards.p;
-    P.mats = (const MaterialD *)D.mats.p; P.lights = (const LightD *)D.lights.p;
-    P.tri_rec = (const FilterRec *)D.tri_rec.p; P.rect_rec = (const FilterRec *)D.rect_rec.p;
-    P.tri_gid = (const int32_t *)D.tri_gid.p; P.rect_gid = (const int32_t *)D.rect_gid.p;
-    P.counters = W.counters;
-    P.hitrec = reinterpret_cast<HitRec *>(W.hitrec); P.queue = W.queue; P.qcount = W.qcount; P.lit = W.lit;
-    P.qsparse = W.qsparse; P.tcount = W.tcount;
-    P.cb_slot = W.cb_slot; P.cb_xy = W.cb_xy; P.cb_group = W.cb_group; P.cb_normal = W.cb_normal; P.cb_count = W.qcount + RT_QCOUNT_CB;
-    P.gen_tri = (const GenRec *)D.gen_tri.p; P.gen_rect = (const GenRec *)D.gen_rect.p;
-    P.gen_tri_gid = (const int32_t *)D.gen_tri_gid.p; P.gen_rect_gid = (const int32_t *)D.gen_rect_gid.p;
-    P.gen_tri_sph = (const float *)D.gen_tri_sph.p; P.gen_rect_sph = (const float *)D.gen_rect_sph.p;
-    P.gen_tri_rows = (const uint16_t *)D.gen_tri_rows.p; P.gen_rect_rows = (const uint16_t *)D.gen_rect_rows.p;
-    P.gen_tri_ssph = (const float *)D.gen_tri_ssph.p; P.gen_rect_ssph = (const float *)D.gen_rect_ssph.p;
-    P.sph_rec = (const FilterRec *)D.sph_rec.p; P.gen_sph = (const GenRec *)D.gen_sph.p; P.sph_gid = (const int32_t *)D.sph_gid.p;
-    P.nsph = (int)s->sph_gid.size();
-    P.mf_rows = (const uint16_t *)D.mf_rows.p; P.mf_gid = (const int32_t *)D.mf_gid.p; P.mf_rec = (const FilterRec *)D.mf_rec.p;
-    P.mf_groups = s->mf_groups;
-    P.mf_cone = (const float *)D.mf_cone.p; P.cull = s->opt_cull ? 1 : 0;
-    P.nguard_cached = (s->opt_cull && !s->talk) ? s->guard_cached : 0;
-    // point lights are worked off 32 at a time (one bit each in a word of `lit`); the reference's Light monoid has no limit
-    std::vector<uint16_t> point_lights;
-    for (size_t li = 0; li < s->lights.size(); ++li) if (s->lights[li].kind == 0) point_lights.push_back((uint16_t)li);
-    const int ngroups = std::max(1, (int)((point_lights.size() + 31) / 32));
-    P.cam = fixed_camera(w, h);
-    P.eps = ray_eps();
-    P.ntri = (int)s->tri_gid.size(); P.nrect = (int)s->rect_gid.size();
-    P.nlights = (int)s->lights.size(); P.nleaves = (int)s->leaves.size(); P.npoint = std::min(32, s->npoint);
-    P.w = w; P.h = h;
-    P.talk = s->talk ? 1 : 0;
-    P.spp = spp; P.seed_lo = (uint32_t)seed; P.seed_hi = (uint32_t)(seed >> 32);
-    const bool callbacks = !s->normal_fn.empty();
-#ifdef RT_WAVE_TIMES
-    {
-        static unsigned long long *dbg = nullptr;
-        if (!dbg) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dbg), (8 + 8 * (1ull << 20)) * sizeof(unsigned long long)));
-        HIP_TRY(hipMemsetAsync(dbg, 0, 64, st));
-        P.dbg = dbg;
-        g_wave_dbg = dbg;
-    }
-#endif
-
-    if (timed && (rc = next_event(D, st, 0))) return rc;
-    for (int sample = 0; sample < spp; ++sample) {
-        P.sample = sample;
-        // sample 0 writes the caller's hit-ID buffer; later samples use the scratch one
-        P.hit_id = (sample == 0) ? hit : W.hit_id;
-        P.rgba = (spp == 1) ? (uint8_t *)d_rgba : nullptr;
-        P.accum = (spp == 1) ? nullptr : W.accum;
-        for (size_t r = 0; r < (size_t)nrows; r += crow) {
-            const int rows = (int)((size_t)nrows - r < crow ? (size_t)nrows - r : crow);
-            P.row0 = row0 + (int)r; P.nrows = rows;
-            P.out_off = (long long)r * w;
-            P.qcap = rows * w;
-            P.lcap = (int)level_capacity(w, (size_t)rows);
-            P.tiles_x = (w + RT_TILE_W - 1) / RT_TILE_W;
-            P.tiles_y = (rows + RT_TILE_H - 1) / RT_TILE_H;
-            const long long tiles = (long long)P.tiles_x * P.tiles_y;
-            const unsigned tblocks = (unsigned)((tiles + RT_WAVES_PER_BLOCK - 1) / RT_WAVES_PER_BLOCK);
-            const unsigned pblocks = (unsigned)(((size_t)P.qcap + 255) / 256);
-            if (depth == 0) {      // trace 0 = black (Main.hs:542): every pixel misses
-                HIP_TRY(hipMemsetAsync(P.hit_id + P.out_off, 0xff, (size_t)P.qcap * sizeof(int32_t), st));
-            } else {
-                if (use_mfma) hipLaunchKernelGGL(k_primary_mfma, dim3(tblocks), dim3(RT_WAVES_PER_BLOCK * 64), 0, st, P);
-#ifdef RT_VALU_FILTER
-                else if (spp == 1) hipLaunchKernelGGL(k_primary<true>, dim3(tblocks), dim3(RT_WAVES_PER_BLOCK * 64), 0, st, P);
-                else hipLaunchKernelGGL(k_primary<false>, dim3(tblocks), dim3(RT_WAVES_PER_BLOCK * 64), 0, st, P);
-#endif
-            }
-            if (timed && (rc = next_event(D, st, 1))) return rc;
-            if (hits_done && sample == 0 && r + crow >= (size_t)nrows) HIP_TRY(hipEventRecord(hits_done, st));
-            if (!d_rgba) continue;
-            // grids: shadow waves of 256 jobs, one thread per slot; bounce levels have up to lcap slots
-            const size_t slots_max = levels > 1 ? (size_t)P.lcap : (size_t)P.qcap;
-            const unsigned sblocks = (unsigned)((slots_max + 256 * RT_WAVES_PER_BLOCK - 1) / (256 * RT_WAVES_PER_BLOCK));
-            const unsigned lblocks = (unsigned)((slots_max + 255) / 256);
-            int32_t *const hit0 = P.hit_id;
-            const long long off0 = P.out_off;
-            uint8_t *const rgba0 = P.rgba;
-            uint32_t *const accum0 = P.accum;
-            unsigned *const lvl_count = W.qcount + 32;
-            if (!queues_clear) HIP_TRY(hipMemsetAsync(W.qcount, 0, RT_QCOUNT_CLEAR * sizeof(unsigned), st));
-            queues_clear = false;
-            for (int lvl = 0; lvl < levels; ++lvl) {
-                if (lvl > 0) {      // trace (n-1) lights world reflected, Main.hs:554
-                    HIP_TRY(hipMemsetAsync(W.qcount, 0, 32 * sizeof(unsigned), st));
-                    P.rays = W.lvl_rays[lvl]; P.count_ptr = lvl_count + lvl;
-                    P.hit_id = W.lvl_hit[lvl]; P.out_off = 0;
-                    hipLaunchKernelGGL(k_general, dim3((unsigned)((slots_max + 63) / 64)), dim3(64), 0, st, P);
-                    if (timed && (rc = next_event(D, st, 1))) return rc;
-                }
-                P.next_rays = (lvl + 1 < levels) ? W.lvl_rays[lvl + 1] : nullptr;
-                P.next_count = lvl_count + lvl + 1;
-                P.colour = (levels > 1) ? W.lvl_col[lvl] : nullptr;
-                if (callbacks && (rc = run_normal_callbacks(*s, P, st, lvl == 0 ? pblocks : lblocks))) return rc;
-                const unsigned ublocks = lvl == 0 ? (unsigned)P.tiles_x * (unsigned)((rows + RT_SETUP_THREADS / 32 - 1) / (RT_SETUP_THREADS / 32))
-                                                  : (unsigned)((slots_max + RT_SETUP_THREADS - 1) / RT_SETUP_THREADS);
-                P.setup_blocks = (int)ublocks;
-                P.lit_stride = (long long)slots_max;
-                for (int grp = 0; grp < ngroups; ++grp) {
-                    const int first = 32 * grp, np = std::max(0, std::min(32, (int)point_lights.size() - first));
-                    P.npoint = np;
-                    for (int k = 0; k < np; ++k) P.point_light[k] = point_lights[(size_t)first + k];
-                    P.lit_w = W.lit + (size_t)grp * slots_max;
-                    if (grp > 0) HIP_TRY(hipMemsetAsync(W.qcount, 0, 32 * sizeof(unsigned), st));
-                    hipLaunchKernelGGL(k_setup, dim3(ublocks), dim3(RT_SETUP_THREADS), 0, st, P);
-                    if (np > 0) {
-                        hipLaunchKernelGGL(k_queue_offsets, dim3((unsigned)np), dim3(1024), 0, st, P);
-                        hipLaunchKernelGGL(k_queue_compact, dim3(ublocks, (unsigned)np), dim3(RT_COMPACT_THREADS), 0, st, P);
-                    }
-                    if (timed && (rc = next_event(D, st, 2))) return rc;
-                    if (np > 0) {
-                        if (use_mfma) hipLaunchKernelGGL(k_shadow_mfma, dim3(sblocks, (unsigned)np), dim3(RT_WAVES_PER_BLOCK * 64), 0, st, P);
-#ifdef RT_VALU_FILTER
-                        else hipLaunchKernelGGL(k_shadow, dim3(sblocks, (unsigned)np), dim3(RT_WAVES_PER_BLOCK * 64), 0, st, P);
-#endif
-                    }
-                    if (timed && (rc = next_event(D, st, 3))) return rc;
-                }
-                if (P.next_rays)
-                    hipLaunchKernelGGL(k_final, dim3(lvl == 0 ? (unsigned)P.tiles_x * (unsigned)((rows + 31) / 32) : (lblocks + 3) / 4), dim3(1024), 0, st, P);
-                else
-                    hipLaunchKernelGGL(k_final, dim3(lvl == 0 ? (unsigned)P.tiles_x * (unsigned)((rows + 7) / 8) : lblocks), dim3(256), 0, st, P);
-                if (timed && (rc = next_event(D, st, 4))) return rc;
-            }
-            P.rays = nullptr; P.count_ptr = nullptr; P.next_rays = nullptr; P.hit_id = hit0; P.out_off = off0;
-            if (levels > 1) {       // fold the levels back: direct `addPixelRGB8` scaled reflection, deepest first
-                for (int lvl = levels - 1; lvl >= 1; --lvl)
-                    hipLaunchKernelGGL(k_combine, dim3(lblocks), dim3(256), 0, st, W.lvl_rays[lvl], W.lvl_col[lvl],
-                                       lvl_count + lvl, (unsigned)P.lcap, W.lvl_col[lvl - 1]);
-                P.colour = W.lvl_col[0]; P.rgba = rgba0; P.accum = accum0;
-                hipLaunchKernelGGL(k_store, dim3(pblocks), dim3(256), 0, st, P);
-                P.colour = nullptr;
-                if (timed && (rc = next_event(D, st, 4))) return rc;
-            }
-        }
-    }
-    if (d_rgba && spp > 1) {
-        hipLaunchKernelGGL(k_resolve, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st,
-                           W.accum, (uint8_t *)d_rgba, npix, (uint32_t)spp);
-        if (timed && (rc = next_event(D, st, 4))) return rc;
-    }
-    HIP_TRY(hipGetLastError());
-    D.stats_pending = true;
-    return RT_OK;
-}
-
-int check_render_args(const rt_scene *s, int w, int h, int depth, int spp, int row0, int nrows) {
-    if (!s) { set_error("rt_render: scene is NULL"); return RT_ERR_ARG; }
-    if (w <= 0 || h <= 0 || spp < 1 || row0 < 0 || nrows < 0 || row0 + nrows > h) {
-        set_error("rt_render: bad image size or row band"); return RT_ERR_ARG;
-    }
-    if (depth < 0) { set_error("rt_render: depth must be >= 0"); return RT_ERR_ARG; }
-    if (s->lights.size() > 65535) { set_error("rt_render: more than 65535 lights are not supported"); return RT_ERR_UNSUPPORTED; }
-    return RT_OK;
-}
-// chunk rows of the growing-workspace renders: a multiple of the tile height
-size_t chunk_rows(int w, int nrows, int levels) {
-    // a bounce level keeps 72 bytes per slot: a quarter of the pixels for up to 8 levels, fewer beyond
-    const size_t pixels = levels > 1 ? std::min<size_t>(RT_CHUNK_PIXELS / 4, 2 * RT_CHUNK_PIXELS / (size_t)levels) : RT_CHUNK_PIXELS;
-    size_t crow = pixels / (size_t)w;
-    crow = crow < RT_TILE_H ? RT_TILE_H : crow - crow % RT_TILE_H;
-    if (crow > (size_t)nrows) crow = (size_t)nrows;
-    return crow ? crow : 1;
-}
-
-// rt_render_device on the growing workspace of the (scene, device) pair
-int render_band(rt_scene *s, int device, int w, int h, int depth, int spp, uint64_t seed, int row0, int nrows,
-                void *d_rgba, void *d_hit_id, hipStream_t st, bool more, hipEvent_t hits_done = nullptr) {
-    int rc;
-    DeviceScene &D = s->dev[device];
-    if ((rc = device_prepare(*s, D, device, w, h))) return rc;
-    if (!levels_supported(s, depth)) return RT_ERR_UNSUPPORTED;
-    const int levels = render_levels(s, depth);
-    const size_t crow = chunk_rows(w, nrows, levels);
-    const WsNeeds need = ws_needs(w, nrows, crow, s->npoint, levels, spp, d_hit_id == nullptr, d_rgba != nullptr, !s->normal_fn.empty());
-    if ((rc = ws_grow(D, need))) return rc;
-    return render_rows(s, D, D.ws, crow, w, h, depth, spp, seed, row0, nrows, d_rgba, d_hit_id, st ? st : (hipStream_t)D.stream, more, true, hits_done);
-}
-
-} // namespace
-
-extern "C" {
-
-int rt_init(int device) { return device_init(device); }
-
-int rt_scene_prepare_device(rt_scene *s, int w, int h) {
-    if (!s || w <= 0 || h <= 0) { set_error("rt_scene_prepare_device: bad argument"); return RT_ERR_ARG; }
-    int rc;
-    if ((rc = enter())) return rc;
-    return device_prepare(*s, s->dev[t_device], t_device, w, h);
-}
-
-void rt_scene_destroy(rt_scene *s) {
-    if (!s) return;
-    int cur = -1;
-    (void)hipGetDevice(&cur);
-    for (DeviceScene &d : s->dev) {
-        helper_join(d);
-        if (d.device < 0) continue;
-        if (hipSetDevice(d.device) != hipSuccess) continue;
-        if (d.stream) (void)hipStreamSynchronize((hipStream_t)d.stream);
-        if (d.copy_stream) (void)hipStreamSynchronize((hipStream_t)d.copy_stream);
-        if (d.copy_stream2) (void)hipStreamSynchronize((hipStream_t)d.copy_stream2);
-        // the scene's arrays and the work buffers are views of the two arenas
-        void *ptrs[] = {d.arena.p, d.ws_arena.p, d.rgba, d.hit_out, d.stage_rgba, d.stage_hit};
-        for (void *p : ptrs) if (p) (void)hipFree(p);
-        for (void *e : d.evpool) if (e) (void)hipEventDestroy((hipEvent_t)e);
-        for (void *e : d.band_done) if (e) (void)hipEventDestroy((hipEvent_t)e);
-        for (void *e : d.hits_done) if (e) (void)hipEventDestroy((hipEvent_t)e);
-        if (d.stream) (void)hipStreamDestroy((hipStream_t)d.stream);
-        if (d.copy_stream) (void)hipStreamDestroy((hipStream_t)d.copy_stream);
-        if (d.copy_stream2) (void)hipStreamDestroy((hipStream_t)d.copy_stream2);
-    }
-    if (cur >= 0) (void)hipSetDevice(cur);
-    delete s;
-}
-
-int rt_render_device(rt_scene *s, int w, int h, int depth, int spp, uint64_t seed, int row0, int nrows,
-                     void *d_rgba, void *d_hit_id, void *stream) {
-    int rc;
-    if ((rc = check_render_args(s, w, h, depth, spp, row0, nrows))) return rc;
-    if ((rc = enter())) return rc;
-    return render_band(s, t_device, w, h, depth, spp, seed, row0, nrows, d_rgba, d_hit_id, (hipStream_t)stream, false);
-}
-
-int rt_render(rt_scene *s, int w, int h, int depth, int spp, uint64_t seed, int row0, int nrows,
-              uint8_t *rgba_out, int32_t *hit_id_out) {
-    int rc;
-    if ((rc = check_render_args(s, w, h, depth, spp, row0, nrows))) return rc;
-    if ((rc = enter())) return rc;
-    DeviceScene &D = s->dev[t_device];
-    const size_t npix = (size_t)w * (size_t)nrows;
-    if (npix == 0) return RT_OK;
-    if ((rc = device_prepare(*s, D, t_device, w, h))) return rc;
-    if ((rc = copy_tools(D))) return rc;
-    // Colours into page-locked memory that this device can address (rt_host_alloc): k_final stores its coalesced 256-byte
-    // lines straight through PCIe into the caller's buffer, so no copy of the colours is left exposed behind the last
-    // kernel (33 MB at 4K: 0.6 ms).  Hit IDs still go through device memory: the shading kernels read them back.
-    uint8_t *direct = nullptr;
-#ifndef RT_NO_DIRECT_RGBA
-    if (rgba_out && s->opt_host_bands <= 1) {
-        hipPointerAttribute_t attr{};
-        if (hipPointerGetAttributes(&attr, rgba_out) == hipSuccess && attr.type == hipMemoryTypeHost && attr.devicePointer) {
-            hipPointerAttribute_t last{};
-            uint8_t *end = rgba_out + 4 * npix - 1;
-            if (hipPointerGetAttributes(&last, end) == hipSuccess && last.type == hipMemoryTypeHost && last.devicePointer == (uint8_t *)attr.devicePointer + (4 * npix - 1))
-                direct = (uint8_t *)attr.devicePointer;
-        } else (void)hipGetLastError();                     // (an ordinary pointer: not an error)
-    }
-#endif
-    if (!direct && (rc = ensure(D.rgba, D.rgba_cap, 4 * npix))) return rc;
-    if ((rc = ensure(D.hit_out, D.hit_out_cap, npix))) return rc;
-    hipStream_t st = (hipStream_t)D.stream, cst = (hipStream_t)D.copy_stream, hst = (hipStream_t)D.copy_stream2;
-    // The frame is enqueued as row bands; band k's copies to the caller's memory run on their own streams beside the
-    // kernels that follow: the hit IDs as soon as the band's nearest-hit kernel has ended (the shading kernels only read
-    // them), the colours behind the band's last kernel, i.e. beside band k + 1.  Only the last band's colours are
-    // exposed.  Bands cost kernel time (every band has its own tails), so there are few: one per ~4 Mi pixels.
-    // Into rt_host_alloc'ed (page-locked) memory the copies are DMA at PCIe rate; into pageable memory they stage
-    // through the runtime's bounce buffers and block this thread, which is why every band is enqueued first.
-    int nb = s->opt_host_bands > 0 ? s->opt_host_bands : (int)(npix >> 22);
-    nb = nb < 1 ? 1 : (nb > RT_HOST_BANDS_MAX ? RT_HOST_BANDS_MAX : nb);
-    if (direct) nb = 1;
-    int brows = (nrows + nb - 1) / nb;
-    brows = (brows + RT_TILE_H - 1) / RT_TILE_H * RT_TILE_H;
-    int used = 0;
-    for (int r = 0; r < nrows && rc == RT_OK; r += brows, ++used) {
-        const int rows = nrows - r < brows ? nrows - r : brows;
-        const size_t off = (size_t)r * (size_t)w;
-        rc = render_band(s, t_device, w, h, depth, spp, seed, row0 + r, rows, rgba_out ? (direct ? direct : D.rgba) + 4 * off : nullptr,
-                         D.hit_out + off, st, r > 0, hit_id_out ? (hipEvent_t)D.hits_done[used] : nullptr);
-        if (rc == RT_OK && !hip_ok(hipEventRecord((hipEvent_t)D.band_done[used], st), "hipEventRecord")) rc = RT_ERR_HIP;
-    }
-    int band = 0;
-    for (int r = 0; r < nrows && rc == RT_OK; r += brows, ++band) {
-        const int rows = nrows - r < brows ? nrows - r : brows;
-        const size_t off = (size_t)r * (size_t)w, n = (size_t)rows * (size_t)w;
-        if (hit_id_out) {
-            if (!hip_ok(hipStreamWaitEvent(hst, (hipEvent_t)D.hits_done[band], 0), "hipStreamWaitEvent")) { rc = RT_ERR_HIP; break; }
-            if (!hip_ok(hipMemcpyAsync(hit_id_out + off, D.hit_out + off, n * sizeof(int32_t), hipMemcpyDeviceToHost, hst), "hipMemcpyAsync")) { rc = RT_ERR_HIP; break; }
-        }
-        if (rgba_out && !direct) {
-            if (!hip_ok(hipStreamWaitEvent(cst, (hipEvent_t)D.band_done[band], 0), "hipStreamWaitEvent")) { rc = RT_ERR_HIP; break; }
-            if (!hip_ok(hipMemcpyAsync(rgba_out + 4 * off, D.rgba + 4 * off, 4 * n, hipMemcpyDeviceToHost, cst), "hipMemcpyAsync")) rc = RT_ERR_HIP;
-        }
-    }
-    // always drain both streams, also after an error: nothing may still be writing the caller's buffers on return
-    if (!hip_ok(hipStreamSynchronize(cst), "hipStreamSynchronize") && rc == RT_OK) rc = RT_ERR_HIP;
-    if (!hip_ok(hipStreamSynchronize(hst), "hipStreamSynchronize") && rc == RT_OK) rc = RT_ERR_HIP;
-    if (!hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize") && rc == RT_OK) rc = RT_ERR_HIP;
-    return rc;
-}
-
-void *rt_host_alloc(size_t bytes) {
-    if (enter() != RT_OK) return nullptr;
-    void *p = nullptr;
-    if (!hip_ok(hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable), "hipHostMalloc")) return nullptr;
-    return p;
-}
-
-void rt_host_free(void *p) {
-    if (p) (void)hipHostFree(p);
-}
-
-int rt_synchronize(void) {
-    if (t_device < 0) return RT_OK;
-    int rc;
-    if ((rc = enter())) return rc;
-    HIP_TRY(hipDeviceSynchronize());
-    return RT_OK;
-}
-
-} // extern "C"
-
-namespace {
-// statistics of the last render of the (scene, device) pair; synchronises with it
-int device_stats(rt_scene *s, DeviceScene &D, rt_stats *out) {
-    if (D.stats_pending) {
-        static thread_local std::vector<unsigned long long> all(RT_STAT_SLOTS * 16);
-        if (D.ev_used > 0) HIP_TRY(hipEventSynchronize((hipEvent_t)D.evpool[D.ev_used - 1]));
-        else HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(hipMemcpy(all.data(), D.last_counters, all.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-        unsigned long long c[16] = {0};
-        for (int slot = 0; slot < RT_STAT_SLOTS; ++slot) for (int k = 0; k < 16; ++k) c[k] += all[(size_t)slot * 16 + k];
-        double ms[5] = {0, 0, 0, 0, 0};
-        for (int i = 1; i < D.ev_used; ++i) {
-            float t = 0;
-            HIP_TRY(hipEventElapsedTime(&t, (hipEvent_t)D.evpool[i - 1], (hipEvent_t)D.evpool[i]));
-            ms[D.evkind[i]] += t;
-        }
-        float tot = 0;
-        if (D.ev_used > 1) HIP_TRY(hipEventElapsedTime(&tot, (hipEvent_t)D.evpool[0], (hipEvent_t)D.evpool[D.ev_used - 1]));
-        rt_stats st{};
-        st.primary_rays = D.last_primary;
-        st.shadow_rays = c[0];
-        st.bounce_rays = c[5];
-        st.bounce_blocks = c[8];
-        const uint64_t rays = st.primary_rays + st.shadow_rays + st.bounce_rays;
-        st.tri_pairs = rays * (uint64_t)s->tri_gid.size();
-        st.rect_pairs = rays * (uint64_t)s->rect_gid.size();
-        st.exact_evals = c[1] + c[2];
-        st.record_tests = c[4];
-        st.mfma_blocks_primary = c[6];
-        st.mfma_blocks_shadow = c[7];
-#ifdef RT_COUNT_EVENTS
-        fprintf(stderr, "[rt] primary: true hits among the exact evaluations %llu; exact evals primary %llu shadow %llu\n", c[3], c[1], c[2]);
-#endif
-        st.ms_primary = ms[1]; st.ms_setup = ms[2]; st.ms_shadow = ms[3]; st.ms_final = ms[4]; st.ms_total = tot;
-        st.upload_ms = D.stats.upload_ms;
-        D.stats = st;
-        D.stats_pending = false;
-#ifdef RT_WAVE_TIMES
-        if (const char *path = getenv("RT_WAVE_TIMES_FILE")) {
-            std::vector<unsigned long long> rec(8 + 8 * (1ull << 20));
-            HIP_TRY(hipMemcpy(rec.data(), g_wave_dbg, rec.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-            if (FILE *f = fopen(path, "wb")) { fwrite(rec.data(), 8, 8 + 8 * (size_t)std::min<unsigned long long>(rec[0], 1ull << 20), f); fclose(f); }
-        }
-#endif
-    }
-    *out = D.stats;
-    out->prepare_ms = s->prepare_ms;
-    return RT_OK;
-}
-} // namespace
-
-extern "C" int rt_get_stats(rt_scene *s, rt_stats *out) {
-    if (!s || !out) { set_error("rt_get_stats: NULL argument"); return RT_ERR_ARG; }
-    if (s->multi_stats) { *out = s->stats_multi; return RT_OK; }
-    int rc;
-    if ((rc = enter())) return rc;
-    const int dev = s->last_device >= 0 ? s->last_device : t_device;
-    if (dev != t_device) HIP_TRY(hipSetDevice(dev));
-    rc = device_stats(s, s->dev[dev], out);
-    if (dev != t_device) (void)hipSetDevice(t_device);
-    return rc;
-}
-
-namespace {
-
-// Relative cost of `ncost` equal horizontal strips of the w x h frame, measured: the strips are rendered one by one at
-// a reduced scale (a quarter or half the width and height while a strip keeps >= 256 Ki pixels, else full scale) and
-// timed with HIP events, the better of two passes.  The bands of a multi-GPU render are cut from this (split_rows).
-int row_costs(rt_scene *s, int device, int w, int h, int depth, int spp, int ncost, double *cost) {
-    int q = 4;
-    while (q > 1 && ((size_t)(w / q) * (size_t)(h / q)) / (size_t)ncost < (256u << 10)) q >>= 1;
-    const int sw = std::max(1, w / q), sh = std::max(ncost, h / q);
-    int rc;
-    DeviceScene &D = s->dev[device];
-    if ((rc = device_prepare(*s, D, device, sw, sh))) return rc;
-    const int maxrows = (sh + ncost - 1) / ncost + 1;
-    if ((rc = ensure(D.stage_rgba, D.stage_rgba_cap, 4 * (size_t)sw * (size_t)maxrows))) return rc;
-    for (int k = 0; k < ncost; ++k) cost[k] = 1e300;
-    for (int pass = 0; pass < 2; ++pass)
-        for (int k = 0; k < ncost; ++k) {
-            const int r0 = (int)((long long)sh * k / ncost), r1 = (int)((long long)sh * (k + 1) / ncost);
-            if (r1 <= r0) { cost[k] = 0; continue; }
-            if ((rc = render_band(s, device, sw, sh, depth, spp, 0, r0, r1 - r0, D.stage_rgba, nullptr, (hipStream_t)D.stream, false))) return rc;
-            rt_stats st;
-            if ((rc = device_stats(s, D, &st))) return rc;
-            cost[k] = std::min(cost[k], st.ms_total);
-        }
-    return RT_OK;
-}
-
-// port of raytrace_amd/distributed.py: sub_bands with the piece sizes of piece_fractions (1 : 2 : ... : 2 : 1 — a small
-// first piece puts data on the link early, a small last one leaves little travelling when the render has ended)
-void sub_bands(int r0, int nr, int parts, int align, int *p0, int *pn) {
-    const int units = (nr + align - 1) / align;
-    double total = 0, run = 0;
-    for (int k = 0; k < parts; ++k) total += (parts <= 2 || (k > 0 && k + 1 < parts)) ? 2.0 : 1.0;
-    int done = 0;
-    for (int k = 0; k < parts; ++k) {
-        run += (parts <= 2 || (k > 0 && k + 1 < parts)) ? 2.0 : 1.0;
-        const int upto = k + 1 < parts ? std::min(nr, std::max(done, (int)((double)units * (run / total) + 0.5) * align)) : nr;
-        p0[k] = r0 + done; pn[k] = upto - done;
-        done = upto;
-    }
-}
-
-} // namespace
-
-extern "C" int rt_scene_row_costs(rt_scene *s, int w, int h, int depth, int spp, int ncost, double *cost) {
-    int rc;
-    if ((rc = check_render_args(s, w, h, depth, spp, 0, h))) return rc;
-    if (!cost || ncost < 1 || ncost > h) { set_error("rt_scene_row_costs: bad argument"); return RT_ERR_ARG; }
-    if ((rc = enter())) return rc;
-    return row_costs(s, t_device, w, h, depth, spp, ncost, cost);
-}
-
-extern "C" int rt_render_multi(rt_scene *s, int w, int h, int depth, int spp, uint64_t seed, int ngpus, const int *devices,
-                               uint8_t *rgba_out, int32_t *hit_id_out) {
-    int rc;
-    if ((rc = check_render_args(s, w, h, depth, spp, 0, h))) return rc;
-    if (ngpus < 1 || ngpus > RT_MAX_DEVICES) { set_error("rt_render_multi: ngpus must be between 1 and 16"); return RT_ERR_ARG; }
-    int ndev = 0;
-    if (!hip_ok(hipGetDeviceCount(&ndev), "hipGetDeviceCount") || ndev <= 0) {
-        set_error("rt_render_multi: no HIP device available (this library has no CPU fallback)"); return RT_ERR_HIP;
-    }
-    int devs[RT_MAX_DEVICES];
-    for (int k = 0; k < ngpus; ++k) {
-        devs[k] = devices ? devices[k] : k;
-        if (devs[k] < 0 || devs[k] >= ndev || devs[k] >= RT_MAX_DEVICES) { set_error("rt_render_multi: device index out of range"); return RT_ERR_ARG; }
-    }
-    const int caller = t_device, home = devs[0];
-    const size_t npix = (size_t)w * (size_t)h;
-    constexpr int PIECES = 4;
-    struct Band { int dev, row0, nrows; size_t stage_off; bool staged; int p0[PIECES], pn[PIECES]; };
-    Band band[RT_MAX_DEVICES];
-    std::vector<hipEvent_t> ev;            // per (band, piece): rendered, arrived on the home device
-    bool first_on[RT_MAX_DEVICES], peer_ok[RT_MAX_DEVICES];
-    for (bool &f : first_on) f = true;
-    for (bool &f : peer_ok) f = false;
-    auto finish = [&](int code) {          // drain every stream that was used, restore the caller's device
-        for (int k = 0; k < ngpus; ++k) {
-            DeviceScene &D = s->dev[devs[k]];
-            if (hipSetDevice(devs[k]) != hipSuccess) continue;
-            if (D.stream && !hip_ok(hipStreamSynchronize((hipStream_t)D.stream), "hipStreamSynchronize") && code == RT_OK) code = RT_ERR_HIP;
-            if (D.copy_stream && !hip_ok(hipStreamSynchronize((hipStream_t)D.copy_stream), "hipStreamSynchronize") && code == RT_OK) code = RT_ERR_HIP;
-            // (the home device's copies into the caller's buffers: nothing may still be writing them after an error return)
-            if (D.copy_stream2 && !hip_ok(hipStreamSynchronize((hipStream_t)D.copy_stream2), "hipStreamSynchronize") && code == RT_OK) code = RT_ERR_HIP;
-        }
-        for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
-        if (caller >= 0) (void)hipSetDevice(caller);
-        t_device = caller;
-        return code;
-    };
-    if ((rc = device_init(home))) return finish(rc);
-    DeviceScene &H = s->dev[home];
-    if ((rc = device_prepare(*s, H, home, w, h))) return finish(rc);
-    if ((rc = copy_tools(H))) return finish(rc);
-    // 1. bands of about equal measured cost
-    int b0[RT_MAX_DEVICES] = {0}, bn[RT_MAX_DEVICES] = {h};
-    if (ngpus > 1) {
-        const int ncost = std::min(32, std::max(1, h / 8));
-        if (s->multi_cost.size() != (size_t)ncost || s->multi_cost_key[0] != s->version || s->multi_cost_key[1] != (uint64_t)w ||
-            s->multi_cost_key[2] != (uint64_t)h || s->multi_cost_key[3] != (uint64_t)depth || s->multi_cost_key[4] != (uint64_t)spp) {
-            s->multi_cost.assign(ncost, 1.0);
-            if ((rc = row_costs(s, home, w, h, depth, spp, ncost, s->multi_cost.data()))) return finish(rc);
-            if ((rc = device_prepare(*s, H, home, w, h))) return finish(rc);
-            const uint64_t key[5] = {s->version, (uint64_t)w, (uint64_t)h, (uint64_t)depth, (uint64_t)spp};
-            std::copy(key, key + 5, s->multi_cost_key);
-        }
-        // devices[0] collects: it sends nothing, so it may render while the others' last pieces travel — one more of
-        // the PIECES * 3/2 - 1 units a band's pieces are made of (distributed.py: plan_frame has the long form)
-        double weight[RT_MAX_DEVICES];
-        for (int k = 0; k < ngpus; ++k) weight[k] = 1.0;
-        if (devs[0] != devs[ngpus - 1] || ngpus > 1) weight[0] = 1.0 + 1.0 / (2.0 * (PIECES - 1));
-        split_rows(s->multi_cost.data(), ncost, h, ngpus, RT_TILE_H, b0, bn, weight);
-    }
-    // 2. buffers: the whole frame on the home device, a staging buffer per other device
-    if (rgba_out && (rc = ensure(H.rgba, H.rgba_cap, 4 * npix))) return finish(rc);
-    if ((rc = ensure(H.hit_out, H.hit_out_cap, npix))) return finish(rc);
-    size_t stage_pix[RT_MAX_DEVICES] = {0};
-    for (int k = 0; k < ngpus; ++k) {
-        Band &B = band[k];
-        B.dev = devs[k]; B.row0 = b0[k]; B.nrows = bn[k];
-        B.staged = B.dev != home || s->opt_multi_stage;
-        B.stage_off = stage_pix[B.dev];
-        if (B.staged) stage_pix[B.dev] += (size_t)w * (size_t)B.nrows;
-        sub_bands(B.row0, B.nrows, PIECES, RT_TILE_H, B.p0, B.pn);
-    }
-    for (int k = 0; k < ngpus; ++k) {
-        const int d = devs[k];
-        if (!stage_pix[d]) continue;
-        if ((rc = device_init(d))) return finish(rc);
-        DeviceScene &D = s->dev[d];
-        if ((rc = device_prepare(*s, D, d, w, h))) return finish(rc);
-        if ((rc = copy_tools(D))) return finish(rc);
-        if (rgba_out && (rc = ensure(D.stage_rgba, D.stage_rgba_cap, 4 * stage_pix[d]))) return finish(rc);
-        if ((rc = ensure(D.stage_hit, D.stage_hit_cap, stage_pix[d]))) return finish(rc);
-        if (d != home) {                  // direct xGMI copies into the home device's memory
-            const hipError_t e = hipDeviceEnablePeerAccess(home, 0);
-            peer_ok[d] = e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled;   // else hipMemcpyPeerAsync stages through the host
-            (void)hipGetLastError();
-        }
-    }
-    // 3. every device is driven by a host thread of its own (enqueueing 6 kernels per piece costs the host ~0.1 ms: from
-    // one thread, 8 devices x 4 pieces would take as long as a device needs for its whole band); a device's pieces are
-    // enqueued in order, and a piece travels to the home device (peer-to-peer over xGMI, on the band's copy stream) while
-    // the next one renders.  Scenes with fnorm callbacks stay on this thread (the caller's closure is not ours to run
-    // concurrently).
-    ev.assign((size_t)ngpus * PIECES * 2, nullptr);
-    for (size_t i = 0; i < ev.size(); ++i)
-        if (!hip_ok(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming), "hipEventCreate")) return finish(RT_ERR_HIP);
-    auto drive = [&](int dev, std::string &err) -> int {        // all bands of one device, piece by piece
-        int rc2;
-        if ((rc2 = device_init(dev))) { err = rt_last_error(); return rc2; }
-        DeviceScene &D = s->dev[dev];
-        bool first = true;
-        for (int p = 0; p < PIECES; ++p)
-            for (int k = 0; k < ngpus; ++k) {
-                Band &B = band[k];
-                if (B.dev != dev || B.pn[p] <= 0) continue;
-                const size_t foff = (size_t)B.p0[p] * (size_t)w, n = (size_t)B.pn[p] * (size_t)w;
-                const size_t soff = B.stage_off + (size_t)(B.p0[p] - B.row0) * (size_t)w;
-                uint8_t *dst = !rgba_out ? nullptr : (B.staged ? D.stage_rgba + 4 * soff : H.rgba + 4 * foff);
-                int32_t *dhit = B.staged ? D.stage_hit + soff : H.hit_out + foff;
-                if ((rc2 = render_band(s, dev, w, h, depth, spp, seed, B.p0[p], B.pn[p], dst, dhit, (hipStream_t)D.stream, !first))) { err = rt_last_error(); return rc2; }
-                first = false;
-                first_on[dev] = false;
-                hipEvent_t er = ev[((size_t)k * PIECES + p) * 2], ea = ev[((size_t)k * PIECES + p) * 2 + 1];
-                bool ok = hip_ok(hipEventRecord(er, (hipStream_t)D.stream), "hipEventRecord");
-                if (ok && B.staged) {
-                    hipStream_t cs = (hipStream_t)D.copy_stream;
-                    ok = hip_ok(hipStreamWaitEvent(cs, er, 0), "hipStreamWaitEvent") &&
-                         (!rgba_out || hip_ok(hipMemcpyPeerAsync(H.rgba + 4 * foff, home, dst, dev, 4 * n, cs), "hipMemcpyPeerAsync")) &&
-                         hip_ok(hipMemcpyPeerAsync(H.hit_out + foff, home, dhit, dev, n * sizeof(int32_t), cs), "hipMemcpyPeerAsync") &&
-                         hip_ok(hipEventRecord(ea, cs), "hipEventRecord");
-                }
-                if (!ok) { err = rt_last_error(); return RT_ERR_HIP; }
-            }
-        return RT_OK;
-    };
-    {
-        int distinct[RT_MAX_DEVICES], nd = 0;
-        for (int k = 0; k < ngpus; ++k) { bool seen = false; for (int j = 0; j < nd; ++j) seen |= distinct[j] == devs[k]; if (!seen) distinct[nd++] = devs[k]; }
-        int rcs[RT_MAX_DEVICES] = {0};
-        std::string errs[RT_MAX_DEVICES];
-        if (nd > 1 && s->normal_fn.empty()) {
-            std::vector<std::thread> workers;
-            for (int j = 1; j < nd; ++j) workers.emplace_back([&, j] { rcs[j] = drive(distinct[j], errs[j]); });
-            rcs[0] = drive(distinct[0], errs[0]);
-            for (std::thread &t : workers) t.join();
-        } else {
-            for (int j = 0; j < nd && (j == 0 || rcs[j - 1] == RT_OK); ++j) rcs[j] = drive(distinct[j], errs[j]);
-        }
-        for (int j = 0; j < nd; ++j) if (rcs[j] != RT_OK) { set_error(errs[j]); return finish(rcs[j]); }
-    }
-    // 4. from the home device to the caller's memory, piece by piece as they arrive
-    if ((rc = device_init(home))) return finish(rc);
-    for (int p = 0; p < PIECES; ++p)
-        for (int k = 0; k < ngpus; ++k) {
-            const Band &B = band[k];
-            if (B.pn[p] <= 0) continue;
-            const size_t foff = (size_t)B.p0[p] * (size_t)w, n = (size_t)B.pn[p] * (size_t)w;
-            hipEvent_t arrived = ev[((size_t)k * PIECES + p) * 2 + (B.staged ? 1 : 0)];
-            hipStream_t cs = (hipStream_t)H.copy_stream2;
-            if (!hip_ok(hipStreamWaitEvent(cs, arrived, 0), "hipStreamWaitEvent")) return finish(RT_ERR_HIP);
-            if (rgba_out && !hip_ok(hipMemcpyAsync(rgba_out + 4 * foff, H.rgba + 4 * foff, 4 * n, hipMemcpyDeviceToHost, cs), "hipMemcpyAsync")) return finish(RT_ERR_HIP);
-            if (hit_id_out && !hip_ok(hipMemcpyAsync(hit_id_out + foff, H.hit_out + foff, n * sizeof(int32_t), hipMemcpyDeviceToHost, cs), "hipMemcpyAsync")) return finish(RT_ERR_HIP);
-        }
-    if (!hip_ok(hipStreamSynchronize((hipStream_t)H.copy_stream2), "hipStreamSynchronize")) return finish(RT_ERR_HIP);
-    if ((rc = finish(RT_OK))) return rc;
-    // 5. statistics of the whole frame: counts summed over the devices, times = the slowest device
-    rt_stats tot{};
-    bool seen[RT_MAX_DEVICES] = {false};
-    for (int k = 0; k < ngpus; ++k) {
-        const int d = devs[k];
-        if (seen[d] || first_on[d]) continue;
-        seen[d] = true;
-        rt_stats st;
-        if (hipSetDevice(d) != hipSuccess || device_stats(s, s->dev[d], &st) != RT_OK) continue;
-        tot.primary_rays += st.primary_rays; tot.shadow_rays += st.shadow_rays; tot.bounce_rays += st.bounce_rays;
-        tot.tri_pairs += st.tri_pairs; tot.rect_pairs += st.rect_pairs; tot.exact_evals += st.exact_evals;
-        tot.record_tests += st.record_tests; tot.mfma_blocks_primary += st.mfma_blocks_primary; tot.mfma_blocks_shadow += st.mfma_blocks_shadow;
-        tot.ms_primary = std::max(tot.ms_primary, st.ms_primary); tot.ms_setup = std::max(tot.ms_setup, st.ms_setup);
-        tot.ms_shadow = std::max(tot.ms_shadow, st.ms_shadow); tot.ms_final = std::max(tot.ms_final, st.ms_final);
-        tot.ms_total = std::max(tot.ms_total, st.ms_total); tot.upload_ms = std::max(tot.upload_ms, st.upload_ms);
-    }
-    tot.prepare_ms = s->prepare_ms;
-    for (int k = 0; k < ngpus; ++k) {          // how the bands reached devices[0]
-        if (devs[k] == home) continue;
-        if (peer_ok[devs[k]]) ++tot.multi_bands_direct; else ++tot.multi_bands_staged;
-    }
-    s->stats_multi = tot;
-    s->multi_stats = true;
-    if (caller >= 0) (void)hipSetDevice(caller);
-    return RT_OK;
-}
-
-// rt_render_device without a single allocation: no hipMalloc / hipFree, no event or stream creation.  The scene must be
-// resident already (rt_scene_prepare_device); work buffers come from the static device array `scratch` (64 MiB per GPU).
-// A band that needs more than that is rendered as consecutive sub-bands that each fit; only a frame so wide that 16 rows
-// do not fit is refused.  All calls on one GPU share the array: calls that overlap in time race.
-extern "C" int rt_render_device_noalloc(rt_scene *s, int w, int h, int depth, int spp, uint64_t seed, int row0, int nrows,
-                                        void *d_rgba, void *d_hit_id, void *stream) {
-    int rc;
-    if ((rc = check_render_args(s, w, h, depth, spp, row0, nrows))) return rc;
-    if (t_device < 0) { set_error("rt_render_device_noalloc: call rt_init(device) on this thread first"); return RT_ERR_ARG; }
-    HIP_TRY(hipSetDevice(t_device));
-    DeviceScene &D = s->dev[t_device];
-    if (!host_ready(*s, w, h) || !D.stream || D.version != s->version || D.eye_version != s->eye_version) {
-        set_error("rt_render_device_noalloc: the scene is not resident on this device for this image size: call rt_scene_prepare_device(scene, w, h) first");
-        return RT_ERR_ARG;
-    }
-    if (!s->normal_fn.empty()) { set_error("rt_render_device_noalloc: scenes with fnorm callbacks need host staging and are not supported here"); return RT_ERR_UNSUPPORTED; }
-    if (!levels_supported(s, depth)) return RT_ERR_UNSUPPORTED;
-    if (!d_rgba && !d_hit_id) { set_error("rt_render_device_noalloc: no output buffer"); return RT_ERR_ARG; }
-    const int levels = render_levels(s, depth);
-    unsigned char *base = g_ctx[t_device].scratch;       // the device address, never the array's name
-    // the most rows (all of them, or a multiple of the 16-row set-up tiles) whose buffers fit
-    Workspace W;
-    auto fits = [&](int rows) {
-        return ws_carve(base, RT_STATIC_SCRATCH_BYTES, ws_needs(w, rows, (size_t)rows, s->npoint, levels, spp, d_hit_id == nullptr, d_rgba != nullptr, false), W) != 0;
-    };
-    int rows_fit = nrows;
-    if (nrows > 0 && !fits(nrows)) {
-        int lo = 0, hi = nrows / 16;                       // in units of 16 rows: lo fits (0 = nothing), hi may not
-        while (lo < hi) { const int mid = (lo + hi + 1) / 2; if (fits(mid * 16)) lo = mid; else hi = mid - 1; }
-        rows_fit = lo * 16;
-        if (rows_fit == 0) {                               // not even 16 rows (or the band has fewer): single rows, if one fits
-            if (!fits(1)) {
-                set_error("rt_render_device_noalloc: the image is too wide: one row of it needs more than the 64 MiB of static scratch");
-                return RT_ERR_UNSUPPORTED;
-            }
-            rows_fit = 1;
-            while (rows_fit < 15 && rows_fit < nrows && fits(rows_fit + 1)) ++rows_fit;
-        }
-        (void)fits(rows_fit);                              // W = the layout that is used
-    }
-    hipStream_t st = stream ? (hipStream_t)stream : (hipStream_t)D.stream;
-    // (the array keeps whatever the last call left: no history of the lights' costs here, they are taken in their own order)
-    if (nrows > 0) HIP_TRY(hipMemsetAsync(W.qcount + RT_QCOUNT_HIST, 0, (RT_QCOUNT_WORDS - RT_QCOUNT_HIST) * sizeof(unsigned), st));
-    for (int r = 0; r < nrows; r += rows_fit) {
-        const int rows = nrows - r < rows_fit ? nrows - r : rows_fit;
-        const size_t off = (size_t)r * (size_t)w;
-        if ((rc = render_rows(s, D, W, (size_t)rows, w, h, depth, spp, seed, row0 + r, rows,
-                              d_rgba ? (uint8_t *)d_rgba + 4 * off : nullptr, d_hit_id ? (int32_t *)d_hit_id + off : nullptr,
-                              st, r > 0, false))) return rc;
-    }
-    if (nrows == 0) { D.last_primary = 0; D.ev_used = 0; D.stats_pending = false; }
-    return RT_OK;
-}
+} // namespace rt

@@ -1065,7 +1065,14 @@ using namespace rt;
 extern "C" {
 
 const char *rt_last_error(void) { return g_err.c_str(); }
-const char *rt_version(void) { return "raytrace_amd 0.1 (gfx950)"; }
+const char *rt_version(void) {
+    static const std::string v = std::string("raytrace_amd 0.3 (gfx950)")
+#ifdef RT_VALU_FILTER
+        + " cross-check build (also holds the FP32 vector-ALU kernels)"
+#endif
+        + rt::kernel_build_flags();
+    return v.c_str();
+}
 
 int rt_scene_create(rt_scene **out) {
     if (!out) { set_error("rt_scene_create: out is NULL"); return RT_ERR_ARG; }

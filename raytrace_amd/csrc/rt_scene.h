@@ -140,6 +140,7 @@ struct rt_scene {
 namespace rt {
 
 void set_error(const std::string &msg);
+const char *kernel_build_flags();                         // rt_kernels.hip: the measurement switches the kernels were compiled with ("" for a product build)
 CameraD fixed_camera(int w, int h);                       // Main.hs:506-527
 double ray_eps();                                         // Main.hs:114
 // (Re)build what a w x h render uploads: guard chains and every apex's records when the scene changed, the eye

@@ -72,7 +72,7 @@ def predict_step_ms(render_ms: float, transfer_ms: float, fractions: Sequence[fl
     return t_link
 
 
-def plan_frame(frame_ms_one_gpu: float, n: int, band_bytes: float, link_gbps: float, overhead_ms: float = 0.05, max_parts: int = 8):
+def plan_frame(frame_ms_one_gpu: float, n: int, band_bytes: float, link_gbps: float, overhead_ms: float = 0.1, max_parts: int = 8):
     """The N-rank frame on paper: pieces per band, rank 0's share, predicted step time.
 
     frame_ms_one_gpu: the whole frame on one GPU (measured); band_bytes: what one sender puts on its link per frame;

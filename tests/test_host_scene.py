@@ -322,3 +322,12 @@ def test_host_index_is_the_same_every_time_it_is_built():
         snaps.append(snap)
         sc.close()
     assert snaps[0] == snaps[1]
+
+
+def test_product_libraries_are_not_measurement_builds():
+    """Result-changing measurement switches (RT_NO_GUARDS, RT_X_SCANONLY, ...) compile only with -DRT_MEASUREMENT_BUILD, and
+    rt_version() names them: the libraries the tests load must be clean."""
+    for L in (_lib.lib(), _lib.valu_lib()):
+        v = L.rt_version().decode()
+        assert v.startswith("raytrace_amd") and "MEASUREMENT" not in v and "RT_" not in v, v
+    assert "cross-check" in _lib.valu_lib().rt_version().decode() and "cross-check" not in _lib.lib().rt_version().decode()

@@ -38,7 +38,7 @@ for which, r0 in (("middle band", (n // 2) * rows), ("top band", 0)):
     print(f"{which} (rows {r0}..{r0 + rows - 1} of the {w}x{h} frame): " +
           ", ".join(f"{p} piece(s) {res[(which, p)]:.3f} ms" for p in (1, 2, 3, 4, 6, 8)))
     print("   overhead per extra piece: " + ", ".join(f"{p}: {(res[(which, p)] - base) / (p - 1):.3f} ms" for p in (2, 3, 4, 6, 8)))
-full = sum(res[(k, 1)] for k in res if k[1] == 1) / 2 * n
+full = sum(v for k, v in res.items() if k[1] == 1) / 2 * n
 for o in (0.03, 0.05, 0.1, 0.15):
     for bw in (48.0, 64.0, 76.8):
         parts, fr, wts, t, d = plan_frame(full, n, w * h * 4 / n, bw, o)
