@@ -230,8 +230,9 @@ def main():
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank renders on GPU 0 (gloo only)")
     ap.add_argument("--pieces", type=int, default=0, help="N > 1: pieces per band (0 = what the pipeline model picks: raytrace_amd/distributed.py plan_frame)")
     ap.add_argument("--link-gbps", type=float, default=48.0, help="N > 1: what the model assumes one xGMI link carries in one direction under ncclSend/ncclRecv (GB/s)")
-    ap.add_argument("--piece-overhead-ms", type=float, default=0.1, help="N > 1: what the model charges per piece for its launches and kernel tails "
-                    "(measured on one MI355X: 0.06-0.14 ms per extra piece of a 2048-row band of the 16384-wide frame, profiles/r03_piece_overhead.txt)")
+    ap.add_argument("--piece-overhead-ms", type=float, default=0.02, help="N > 1: what the model charges per piece for its launches and kernel tails "
+                    "(measured on one MI355X for a 2048-row band of the 16384-wide frame, profiles/r03_piece_overhead.txt: 0.06-0.14 ms per extra piece on one "
+                    "lane; -0.08 to +0.01 ms with the pieces alternating between the scene's two lanes, which is how they are rendered)")
     ap.add_argument("--verify", action="store_true", help="rank 0 re-renders the whole frame alone and compares it with the gathered one")
     args = ap.parse_args()
 
@@ -333,6 +334,10 @@ def main():
     # own stream behind the current stream, so piece k's send waits for piece k's render and for nothing later.  (With the
     # library's private stream, or the legacy default stream, the send would not be ordered behind the render at all.)
     rs = torch.cuda.Stream(dev)
+    # N > 1: the pieces of a band alternate between the scene's two lanes (RT_OPT_LANE), each lane on a stream of its own:
+    # piece k + 1's kernels fill the tails of piece k's, which takes the cost of cutting a band into pieces to ~0
+    # (profiles/r03_piece_overhead.txt).  Piece k's send is enqueued with ITS lane's stream current.
+    lanes = [rs, torch.cuda.Stream(dev)]
 
     # every band is rendered in `pieces` consecutive pieces; piece k of all peers travels to GPU 0 in one group
     # of send/recv while piece k+1 renders, so only the last piece's exchange is exposed.  A piece should take about
@@ -340,7 +345,8 @@ def main():
     pieces = plan_parts if n > 1 else 1
     subs = [sub_bands(b, pieces, fractions=plan_fr if n > 1 else None) for b in bands]
     # (the three events of a step are made once and recorded again every step: the last step's are the ones read)
-    marks = {k: torch.cuda.Event(enable_timing=True) for k in ("start", "rendered", "end")}
+    marks = {k: torch.cuda.Event(enable_timing=True) for k in ("start", "rendered", "rendered_b", "end")}
+    lane_done = torch.cuda.Event()
     frame_ptr, hit_ptr = mine.data_ptr(), hit.data_ptr()
 
     def step(seed=20260355):
@@ -350,24 +356,29 @@ def main():
             return
         pending, host = [], []
         host_frame = torch.empty((h, w, 4), dtype=torch.uint8) if staged and rank == 0 else None
-        with torch.cuda.stream(rs):
-            rs.record_event(marks["start"])
-            for k in range(pieces):
+        rs.record_event(marks["start"])
+        lanes[1].wait_event(marks["start"])            # (the previous step ended with lane 1 joined to lane 0)
+        for k in range(pieces):
+            ln = k & 1
+            with torch.cuda.stream(lanes[ln]):
                 r0, nr = subs[rank][k]
                 piece = mine[r0 - row0:r0 - row0 + nr]
                 if nr > 0:
                     scene.render_device(w, h, piece.data_ptr(), hit[r0 - row0:].data_ptr(), depth=args.depth, spp=args.spp,
-                                        seed=seed, row0=r0, nrows=nr, stream=rs.cuda_stream)
-                if k == pieces - 1:
-                    rs.record_event(marks["rendered"])
+                                        seed=seed, row0=r0, nrows=nr, stream=lanes[ln].cuda_stream, lane=ln, cont=k > 0)
+                if k >= pieces - 2:    # the last piece of each lane
+                    lanes[ln].record_event(marks["rendered" if k == pieces - 1 else "rendered_b"])
                 group = [s[k] for s in subs]
                 if not staged:     # ncclSend/ncclRecv in one group: every peer has a direct xGMI link to GPU 0
                     pending += gather_bands(dist, frame, piece, group, rank, wait=False)
                 else:              # gloo rehearsal: the same groups, through host memory
-                    rs.synchronize()
+                    lanes[ln].synchronize()
                     host_piece = piece.cpu()
                     host.append((r0, nr, host_piece))
                     pending += gather_bands(dist, host_frame, host_piece, group, rank, wait=False)
+        with torch.cuda.stream(rs):
+            lanes[1].record_event(lane_done)
+            rs.wait_event(lane_done)
             for req in pending:
                 req.wait()
             if staged and rank == 0:
@@ -407,7 +418,11 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     # the last step of this rank: render of its band, and what followed until the frame was complete (exposed exchange)
-    rank_render_ms = marks["start"].elapsed_time(marks["rendered"]) if n > 1 else dt / args.steps * 1e3
+    rank_render_ms = dt / args.steps * 1e3
+    if n > 1:
+        rank_render_ms = marks["start"].elapsed_time(marks["rendered"])
+        if pieces > 1:
+            rank_render_ms = max(rank_render_ms, marks["start"].elapsed_time(marks["rendered_b"]))
     rank_total_ms = marks["start"].elapsed_time(marks["end"]) if n > 1 else dt / args.steps * 1e3
     if n > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -423,7 +438,7 @@ def main():
         for r0, nr in subs[rank]:
             if nr > 0:
                 scene.render_device(w, h, mine[r0 - row0:].data_ptr(), hit[r0 - row0:].data_ptr(), depth=args.depth, spp=args.spp,
-                                    seed=20260355, row0=r0, nrows=nr, stream=rs.cuda_stream)
+                                    seed=20260355, row0=r0, nrows=nr, stream=rs.cuda_stream, lane=0, cont=False)
                 st = scene.stats()
                 for key in keys:
                     total[key] += st[key]
@@ -448,7 +463,8 @@ def main():
         sync()
         if rank == 0:
             alone = torch.empty((h, w, 4), dtype=torch.uint8, device=dev)
-            scene.render_device(w, h, alone.data_ptr(), None, depth=args.depth, spp=args.spp, seed=20260355, stream=rs.cuda_stream)
+            scene.render_device(w, h, alone.data_ptr(), None, depth=args.depth, spp=args.spp, seed=20260355, stream=rs.cuda_stream,
+                                lane=0, cont=False)
             torch.cuda.synchronize()
             verified = bool(torch.equal(alone, frame))
             del alone
@@ -604,11 +620,19 @@ def main():
                                         stream=rs.cuda_stream)
                     rs.synchronize()
                     ts.append(time.perf_counter() - t0)
+                # the kernels' own times from one more frame on ONE lane (in the timed frames the two halves overlap, and the
+                # intervals between a lane's events then hold the other lane's kernels too)
+                scene.render_device(MULTI_W, MULTI_H, big.data_ptr(), bhit.data_ptr(), depth=args.depth, spp=args.spp, seed=20260355,
+                                    stream=rs.cuda_stream, lane=0, cont=False)
                 bst = scene.stats()
+                scene.set_option(_lib.RT_OPT_LANE, -1)
                 out["same_frame_as_multi_gpu"] = {"width": MULTI_W, "height": MULTI_H, "ms": min(ts[1:]) * 1e3,
                                                   "mrays": MULTI_W * MULTI_H * args.spp / min(ts[1:]) / 1e6,
-                                                  "kernel_ms": {"k_primary": bst["ms_primary"], "k_setup": bst["ms_setup"], "k_shadow": bst["ms_shadow"], "k_final": bst["ms_final"]},
-                                                  "note": "the frame `bench.py --gpus N` (N > 1) splits across ranks, on this one GPU: divide by it, not by `value`, for a scaling ratio"}
+                                                  "ms_on_one_lane": bst["ms_total"],
+                                                  "kernel_ms_on_one_lane": {"k_primary": bst["ms_primary"], "k_setup": bst["ms_setup"], "k_shadow": bst["ms_shadow"], "k_final": bst["ms_final"]},
+                                                  "note": "the frame `bench.py --gpus N` (N > 1) splits across ranks, on this one GPU: divide by it, not by `value`, for a scaling ratio.  "
+                                                          "`ms`: as rt_render_device renders it by default, two halves on the scene's two lanes whose kernels fill each other's tails; "
+                                                          "`*_on_one_lane`: one more frame with RT_OPT_LANE 0 (kernel after kernel), for the per-kernel times"}
                 del big, bhit
         if n == 1 and mfma and not args.no_extra_legs and args.spp == 1:
             cs = cold_start_leg(args.workload, w, h, args.depth)

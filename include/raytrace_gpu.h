@@ -107,11 +107,22 @@ int  rt_scene_set_dialect(rt_scene *, int dialect);
  *                      256 rays; 0: every wave scans every block (the plain all-pairs scan).  Same pixels either way.
  *   RT_OPT_FILTER      0 (default): first stage on the matrix cores; 1: the FP32 vector-ALU kernels, which exist only
  *                      in the cross-check build libraytrace_gpu_valu.so (RT_ERR_UNSUPPORTED in the product library).
- *   RT_OPT_HOST_BANDS  copy bands of rt_render, 1..8 (0 = default: one per 4 Mi pixels; a band's hit IDs travel to the
- *                      host as soon as its nearest-hit kernel has ended, its colours beside the next band's kernels).
+ *   RT_OPT_HOST_BANDS  bands of rt_render, 1..8 (0 = default: 2, one per 8 Mi pixels beyond 24 Mi).  Consecutive bands run on
+ *                      the scene's two lanes, so band k + 1's kernels fill the tails of band k's; a band's hit IDs
+ *                      travel to the host as soon as its nearest-hit kernel has ended, its colours beside the next band.
  *   RT_OPT_MULTI_STAGE 1: rt_render_multi sends the bands of devices[0] through a staging buffer and a peer copy too,
- *                      like those of the other devices (default 0: they are rendered in place; tests use 1). */
-enum { RT_OPT_CULL = 0, RT_OPT_FILTER = 1, RT_OPT_HOST_BANDS = 2, RT_OPT_MULTI_STAGE = 3 };
+ *                      like those of the other devices (default 0: they are rendered in place; tests use 1).
+ *   RT_OPT_LANE        A scene has two lanes per device: a set of work buffers and a stream each.  Kernels of two lanes run
+ *                      beside each other and fill each other's tails.  -1 (default): rt_render_device renders a band of
+ *                      12 Mi pixels or more as two halves, one per lane (on the lanes' own streams, forked from and joined
+ *                      to the stream it is given; same pixels, ~7 % faster).  0 or 1: the following rt_render_device calls use that lane and are not
+ *                      split: a caller who cuts a frame into pieces renders them alternately on lane 0 and lane 1
+ *                      (stream = NULL: the lane's own stream, or two streams of the caller's) and they overlap on the
+ *                      device.  Two calls in flight on the SAME lane must be on the same stream (they share work buffers).
+ *   RT_OPT_CONTINUE    1: the following rt_render_device calls add to the frame in progress as far as rt_get_stats is
+ *                      concerned (counts and times of all its pieces, both lanes); 0 (default): a call on lane 0 begins a
+ *                      new frame, a call on lane 1 adds to it. */
+enum { RT_OPT_CULL = 0, RT_OPT_FILTER = 1, RT_OPT_HOST_BANDS = 2, RT_OPT_MULTI_STAGE = 3, RT_OPT_LANE = 4, RT_OPT_CONTINUE = 5 };
 int  rt_scene_set_option(rt_scene *, int option, int value);
 
 /* ---- scene construction (replaces the closure-building constructors) -------------------- */

@@ -459,7 +459,8 @@ class Scene:
         return rgba, hit
 
     def set_option(self, option, value):
-        """rt_scene_set_option: _lib.RT_OPT_CULL / RT_OPT_FILTER / RT_OPT_HOST_BANDS / RT_OPT_MULTI_STAGE."""
+        """rt_scene_set_option: _lib.RT_OPT_CULL / RT_OPT_FILTER / RT_OPT_HOST_BANDS / RT_OPT_MULTI_STAGE / RT_OPT_LANE /
+        RT_OPT_CONTINUE."""
         self._check(self._L.rt_scene_set_option(self._h, option, value), "rt_scene_set_option")
         return self
 
@@ -485,9 +486,13 @@ class Scene:
         self._raise_callback_error()
         return rgba, hit
 
-    def render_device(self, w, h, d_rgba, d_hit, depth=4, spp=1, seed=0, row0=0, nrows=None, stream=None):
-        """Device-buffer render (rt_render_device); d_rgba/d_hit are device addresses (int) or None."""
+    def render_device(self, w, h, d_rgba, d_hit, depth=4, spp=1, seed=0, row0=0, nrows=None, stream=None, lane=None, cont=False):
+        """Device-buffer render (rt_render_device); d_rgba/d_hit are device addresses (int) or None.  lane = 0 / 1: the
+        call uses that lane of the scene (RT_OPT_LANE; cont: it adds to the frame in progress, RT_OPT_CONTINUE) and the
+        options are left that way; None: whatever the options say (default: the library splits big bands itself)."""
         nrows = h - row0 if nrows is None else nrows
+        if lane is not None:
+            self.set_option(_lib.RT_OPT_LANE, lane).set_option(_lib.RT_OPT_CONTINUE, int(bool(cont)))
         self._check(self._L.rt_render_device(self._h, w, h, depth, spp, seed, row0, nrows, d_rgba, d_hit, stream), "rt_render_device")
 
     def render_device_noalloc(self, w, h, d_rgba, d_hit, depth=4, spp=1, seed=0, row0=0, nrows=None, stream=None):

@@ -140,6 +140,7 @@ void helper_join(DeviceScene &D) {
 int make_copy_tools(DeviceScene &D) {
     if (!D.copy_stream) { hipStream_t st; HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); D.copy_stream = st; }
     if (!D.copy_stream2) { hipStream_t st; HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); D.copy_stream2 = st; }
+    for (int k = 1; k < RT_LANES; ++k) if (!D.xstream[k]) { hipStream_t st; HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); D.xstream[k] = st; }
     for (void *&e : D.band_done) if (!e) { hipEvent_t ev; HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); e = ev; }
     for (void *&e : D.hits_done) if (!e) { hipEvent_t ev; HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); e = ev; }
     return RT_OK;
@@ -243,7 +244,7 @@ int copy_tools(DeviceScene &D) {
 }
 
 // event pool: one event per kernel boundary, so that rt_get_stats can attribute time to each kernel
-int next_event(DeviceScene &D, hipStream_t st, int kind) {
+int next_event(Lane &D, hipStream_t st, int kind) {
     if (D.ev_used == (int)D.evpool.size()) {
         hipEvent_t e;
         HIP_TRY(hipEventCreate(&e));
@@ -255,7 +256,16 @@ int next_event(DeviceScene &D, hipStream_t st, int kind) {
     ++D.ev_used;
     return RT_OK;
 }
+// the stream of a lane (lane 1's is made on first use)
+int lane_stream(DeviceScene &D, int lane, hipStream_t &out) {
+    if (lane == 0) { out = (hipStream_t)D.stream; return RT_OK; }
+    helper_join(D);                 // (the helper thread of rt_scene_prepare_device may be making it right now)
+    if (!D.xstream[lane]) { hipStream_t st; HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); D.xstream[lane] = st; }
+    out = (hipStream_t)D.xstream[lane];
+    return RT_OK;
+}
 
+constexpr size_t RT_SPLIT_PIXELS = 12u << 20;    // rt_render_device splits bands of this many pixels over the two lanes
 constexpr size_t RT_CHUNK_PIXELS = 16u << 20;   // rows are processed in chunks of about 16 Mi pixels
 
 int render_levels(const rt_scene *s, int depth) {
@@ -334,20 +344,26 @@ size_t ws_carve(unsigned char *base, size_t cap, const WsNeeds &n, Workspace &W)
     return fits ? used : 0;
 }
 
-// rt_render / rt_render_device: the work buffers of the (scene, device) pair are views of ONE allocation
-// (DeviceScene::ws_arena), grown when a render needs more than it holds: a first render is one hipMalloc, not a dozen.
-int ws_grow(DeviceScene &D, const WsNeeds &n) {
+// rt_render / rt_render_device: the work buffers of a lane of the (scene, device) pair are views of ONE allocation
+// (Lane::ws_arena), grown when a render needs more than it holds: a first render is one hipMalloc, not a dozen.
+int ws_grow(DeviceScene &D, Lane &LN, const WsNeeds &n) {
     Workspace sizing;
     const size_t total = ws_carve(nullptr, ~(size_t)0 >> 1, n, sizing);
-    if (!D.ws_arena.p || D.ws_arena.cap < total) {
-        if (D.ws_arena.p) { HIP_TRY(hipFree(D.ws_arena.p)); D.ws_arena.p = nullptr; D.ws_arena.cap = 0; }     // (hipFree waits for what is in flight)
-        HIP_TRY(hipMalloc(&D.ws_arena.p, total));
-        D.ws_arena.cap = total;
-        // the counters that live across renders start at zero
-        HIP_TRY(hipMemsetAsync((unsigned char *)D.ws_arena.p + RT_COUNTER_BYTES, 0, RT_QCOUNT_WORDS * sizeof(unsigned), (hipStream_t)D.stream));
-        HIP_TRY(hipStreamSynchronize((hipStream_t)D.stream));
+    if (!LN.ws_arena.p || LN.ws_arena.cap < total) {
+        // The head of the arena (statistics counters, queue counters) lives across the bands of a frame and across
+        // renders: a lane that grows in the middle of a frame (a later piece is bigger than the first) takes it along.
+        const size_t head = RT_COUNTER_BYTES + RT_QCOUNT_WORDS * sizeof(unsigned);
+        void *fresh = nullptr;
+        HIP_TRY(hipDeviceSynchronize());                    // what is in flight still uses the old buffers
+        HIP_TRY(hipMalloc(&fresh, total));
+        hipError_t e = LN.ws_arena.p ? hipMemcpy(fresh, LN.ws_arena.p, head, hipMemcpyDeviceToDevice) : hipMemset(fresh, 0, head);
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e != hipSuccess) { (void)hipFree(fresh); HIP_TRY(e); }
+        if (LN.ws_arena.p) HIP_TRY(hipFree(LN.ws_arena.p));
+        LN.ws_arena.p = fresh;
+        LN.ws_arena.cap = total;
     }
-    if (!ws_carve((unsigned char *)D.ws_arena.p, D.ws_arena.cap, n, D.ws)) { set_error("ws_grow: internal sizing error"); return RT_ERR_NOMEM; }
+    if (!ws_carve((unsigned char *)LN.ws_arena.p, LN.ws_arena.cap, n, LN.ws)) { set_error("ws_grow: internal sizing error"); return RT_ERR_NOMEM; }
     return RT_OK;
 }
 
@@ -390,18 +406,24 @@ int run_normal_callbacks(rt_scene &s, const RenderParams &P, hipStream_t st, uns
 
 // Enqueues the kernels of one row band on `st`.  `more` = this band continues a frame whose earlier bands were
 // enqueued by the previous call(s): events, counters and ray counts then accumulate, so rt_get_stats describes the
-// whole frame.  `W` holds buffers of at least ws_needs(...) elements for chunks of `crow` rows; `timed` records an
-// event per kernel boundary (creates events on first use).
-int render_rows(rt_scene *s, DeviceScene &D, const Workspace &W, size_t crow, int w, int h, int depth, int spp, uint64_t seed,
+// whole frame (per lane: a lane's first band of a frame starts its events and counters afresh).  `W` holds buffers of at
+// least ws_needs(...) elements for chunks of `crow` rows; `timed` records an event per kernel boundary (creates events on
+// first use).
+int render_rows(rt_scene *s, DeviceScene &D, Lane &LN, const Workspace &W, size_t crow, int w, int h, int depth, int spp, uint64_t seed,
                 int row0, int nrows, void *d_rgba, void *d_hit_id, hipStream_t st, bool more, bool timed, hipEvent_t hits_done = nullptr) {
     // hits_done: recorded on `st` as soon as the caller's hit-ID buffer is complete (after the nearest-hit kernel of
     // sample 0's last chunk: everything later only reads it), so that a copy of it can run beside the shading kernels
     int rc;
     const size_t npix = (size_t)w * (size_t)nrows;
-    if (!more) { D.last_primary = 0; D.ev_used = 0; }
+    if (!more) {                   // a new frame
+        D.last_primary = 0;
+        for (Lane &l : D.lane) { l.used = false; l.ev_used = 0; }
+    }
+    more = more && LN.used;        // ... and this lane's first band of it
+    LN.used = true;
     D.last_primary += (uint64_t)npix * (uint64_t)spp;
     D.stats_pending = false;
-    D.last_counters = W.counters;
+    LN.last_counters = W.counters;
     s->last_device = D.device;
     s->multi_stats = false;
     if (npix == 0) return RT_OK;
@@ -464,7 +486,7 @@ int render_rows(rt_scene *s, DeviceScene &D, const Workspace &W, size_t crow, in
     }
 #endif
 
-    if (timed && (rc = next_event(D, st, 0))) return rc;
+    if (timed && (rc = next_event(LN, st, 0))) return rc;
     for (int sample = 0; sample < spp; ++sample) {
         P.sample = sample;
         // sample 0 writes the caller's hit-ID buffer; later samples use the scratch one
@@ -490,7 +512,7 @@ int render_rows(rt_scene *s, DeviceScene &D, const Workspace &W, size_t crow, in
                 else launch_primary_valu(P, spp == 1, tblocks, st);
 #endif
             }
-            if (timed && (rc = next_event(D, st, 1))) return rc;
+            if (timed && (rc = next_event(LN, st, 1))) return rc;
             if (hits_done && sample == 0 && r + crow >= (size_t)nrows) HIP_TRY(hipEventRecord(hits_done, st));
             if (!d_rgba) continue;
             // grids: shadow waves of 256 jobs, one thread per slot; bounce levels have up to lcap slots
@@ -510,7 +532,7 @@ int render_rows(rt_scene *s, DeviceScene &D, const Workspace &W, size_t crow, in
                     P.rays = W.lvl_rays[lvl]; P.count_ptr = lvl_count + lvl;
                     P.hit_id = W.lvl_hit[lvl]; P.out_off = 0;
                     launch_general(P, (unsigned)((slots_max + 63) / 64), st);
-                    if (timed && (rc = next_event(D, st, 1))) return rc;
+                    if (timed && (rc = next_event(LN, st, 1))) return rc;
                 }
                 P.next_rays = (lvl + 1 < levels) ? W.lvl_rays[lvl + 1] : nullptr;
                 P.next_count = lvl_count + lvl + 1;
@@ -531,20 +553,20 @@ int render_rows(rt_scene *s, DeviceScene &D, const Workspace &W, size_t crow, in
                         launch_queue_offsets(P, (unsigned)np, st);
                         launch_queue_compact(P, ublocks, (unsigned)np, st);
                     }
-                    if (timed && (rc = next_event(D, st, 2))) return rc;
+                    if (timed && (rc = next_event(LN, st, 2))) return rc;
                     if (np > 0) {
                         if (use_mfma) launch_shadow_mfma(P, sblocks, (unsigned)np, st);
 #ifdef RT_VALU_FILTER
                         else launch_shadow_valu(P, sblocks, (unsigned)np, st);
 #endif
                     }
-                    if (timed && (rc = next_event(D, st, 3))) return rc;
+                    if (timed && (rc = next_event(LN, st, 3))) return rc;
                 }
                 if (P.next_rays)
                     launch_final(P, lvl == 0 ? (unsigned)P.tiles_x * (unsigned)((rows + 31) / 32) : (lblocks + 3) / 4, 1024u, st);
                 else
                     launch_final(P, lvl == 0 ? (unsigned)P.tiles_x * (unsigned)((rows + 7) / 8) : lblocks, 256u, st);
-                if (timed && (rc = next_event(D, st, 4))) return rc;
+                if (timed && (rc = next_event(LN, st, 4))) return rc;
             }
             P.rays = nullptr; P.count_ptr = nullptr; P.next_rays = nullptr; P.hit_id = hit0; P.out_off = off0;
             if (levels > 1) {       // fold the levels back: direct `addPixelRGB8` scaled reflection, deepest first
@@ -553,13 +575,13 @@ int render_rows(rt_scene *s, DeviceScene &D, const Workspace &W, size_t crow, in
                 P.colour = W.lvl_col[0]; P.rgba = rgba0; P.accum = accum0;
                 launch_store(P, pblocks, st);
                 P.colour = nullptr;
-                if (timed && (rc = next_event(D, st, 4))) return rc;
+                if (timed && (rc = next_event(LN, st, 4))) return rc;
             }
         }
     }
     if (d_rgba && spp > 1) {
         launch_resolve(W.accum, (uint8_t *)d_rgba, npix, (uint32_t)spp, st);
-        if (timed && (rc = next_event(D, st, 4))) return rc;
+        if (timed && (rc = next_event(LN, st, 4))) return rc;
     }
     HIP_TRY(hipGetLastError());
     D.stats_pending = true;
@@ -585,18 +607,20 @@ size_t chunk_rows(int w, int nrows, int levels) {
     return crow ? crow : 1;
 }
 
-// rt_render_device on the growing workspace of the (scene, device) pair
+// rt_render_device on the growing workspace of a lane of the (scene, device) pair; st == nullptr: the lane's own stream
 int render_band(rt_scene *s, int device, int w, int h, int depth, int spp, uint64_t seed, int row0, int nrows,
-                void *d_rgba, void *d_hit_id, hipStream_t st, bool more, hipEvent_t hits_done = nullptr) {
+                void *d_rgba, void *d_hit_id, hipStream_t st, bool more, hipEvent_t hits_done = nullptr, int lane = 0) {
     int rc;
     DeviceScene &D = s->dev[device];
     if ((rc = device_prepare(*s, D, device, w, h))) return rc;
+    Lane &LN = D.lane[lane];
+    if (!st && (rc = lane_stream(D, lane, st))) return rc;
     if (!levels_supported(s, depth)) return RT_ERR_UNSUPPORTED;
     const int levels = render_levels(s, depth);
     const size_t crow = chunk_rows(w, nrows, levels);
     const WsNeeds need = ws_needs(w, nrows, crow, s->npoint, levels, spp, d_hit_id == nullptr, d_rgba != nullptr, !s->normal_fn.empty());
-    if ((rc = ws_grow(D, need))) return rc;
-    return render_rows(s, D, D.ws, crow, w, h, depth, spp, seed, row0, nrows, d_rgba, d_hit_id, st ? st : (hipStream_t)D.stream, more, true, hits_done);
+    if ((rc = ws_grow(D, LN, need))) return rc;
+    return render_rows(s, D, LN, LN.ws, crow, w, h, depth, spp, seed, row0, nrows, d_rgba, d_hit_id, st, more, true, hits_done);
 }
 
 } // namespace
@@ -623,10 +647,14 @@ void scene_destroy_impl(rt_scene *s) {
         if (d.copy_stream) (void)hipStreamSynchronize((hipStream_t)d.copy_stream);
         if (d.copy_stream2) (void)hipStreamSynchronize((hipStream_t)d.copy_stream2);
         // the scene's arrays and the work buffers are views of the two arenas
-        void *ptrs[] = {d.arena.p, d.ws_arena.p, d.rgba, d.hit_out, d.stage_rgba, d.stage_hit};
+        for (void *x : d.xstream) if (x) (void)hipStreamSynchronize((hipStream_t)x);
+        void *ptrs[] = {d.arena.p, d.rgba, d.hit_out, d.stage_rgba, d.stage_hit};
         for (void *p : ptrs) if (p) (void)hipFree(p);
-        for (void *e : d.evpool) if (e) (void)hipEventDestroy((hipEvent_t)e);
+        for (Lane &l : d.lane) if (l.ws_arena.p) (void)hipFree(l.ws_arena.p);
+        for (Lane &l : d.lane) for (void *e : l.evpool) if (e) (void)hipEventDestroy((hipEvent_t)e);
+        for (void *x : d.xstream) if (x) (void)hipStreamDestroy((hipStream_t)x);
         for (void *e : d.band_done) if (e) (void)hipEventDestroy((hipEvent_t)e);
+        for (void *e : {d.fork_ev, d.join_ev, d.join0_ev}) if (e) (void)hipEventDestroy((hipEvent_t)e);
         for (void *e : d.hits_done) if (e) (void)hipEventDestroy((hipEvent_t)e);
         if (d.stream) (void)hipStreamDestroy((hipStream_t)d.stream);
         if (d.copy_stream) (void)hipStreamDestroy((hipStream_t)d.copy_stream);
@@ -641,7 +669,39 @@ int render_device_impl(rt_scene *s, int w, int h, int depth, int spp, uint64_t s
     int rc;
     if ((rc = check_render_args(s, w, h, depth, spp, row0, nrows))) return rc;
     if ((rc = enter())) return rc;
-    return render_band(s, t_device, w, h, depth, spp, seed, row0, nrows, d_rgba, d_hit_id, (hipStream_t)stream, false);
+    // A band of RT_SPLIT_PIXELS or more is rendered as two halves on the two lanes, forked from and joined to the caller's
+    // stream: the kernels of the halves run beside each other and fill each other's tails (tools/lane_split_timing.py:
+    // a 16384 x 2048 band 4.44 -> 4.12 ms, the 8K frame 4.80 -> 4.48; the 4K frame gains 0.03 ms from the overlap and
+    // loses 0.05 to the fork and joins, so it stays whole).  Not for a caller who drives the lanes (RT_OPT_LANE 0 or 1, RT_OPT_CONTINUE), nor for fnorm
+    // callbacks (a band with callbacks waits for the host in the middle: nothing would overlap).
+    const size_t npix = (size_t)w * (size_t)nrows;
+    if (s->opt_lane < 0 && !s->opt_continue && npix >= RT_SPLIT_PIXELS && nrows >= 4 * RT_TILE_H && s->normal_fn.empty()) {
+        DeviceScene &D = s->dev[t_device];
+        if ((rc = device_prepare(*s, D, t_device, w, h))) return rc;
+        // Both halves run on the LANES' OWN streams; the caller's stream carries only the fork and the joins.  (Streams share
+        // few hardware queues, 4 by default: kernels of a caller's stream that happens to sit on lane 1's queue would
+        // run behind lane 1's, not beside them — measured 1.65 ms instead of 1.32 for the 4K frame.)
+        hipStream_t cs = (hipStream_t)stream, st0 = (hipStream_t)D.stream, st1 = nullptr;
+        if (!cs) cs = st0;
+        if ((rc = lane_stream(D, 1, st1))) return rc;
+        for (void **e : {&D.fork_ev, &D.join_ev, &D.join0_ev})
+            if (!*e) { hipEvent_t ev; HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); *e = ev; }
+        const int top = (nrows / 2 + RT_TILE_H - 1) / RT_TILE_H * RT_TILE_H;
+        const size_t off = (size_t)top * (size_t)w;
+        HIP_TRY(hipEventRecord((hipEvent_t)D.fork_ev, cs));
+        if (cs != st0) HIP_TRY(hipStreamWaitEvent(st0, (hipEvent_t)D.fork_ev, 0));
+        HIP_TRY(hipStreamWaitEvent(st1, (hipEvent_t)D.fork_ev, 0));
+        rc = render_band(s, t_device, w, h, depth, spp, seed, row0, top, d_rgba, d_hit_id, st0, false, nullptr, 0);
+        const int rc1 = rc ? rc : render_band(s, t_device, w, h, depth, spp, seed, row0 + top, nrows - top, d_rgba ? (uint8_t *)d_rgba + 4 * off : nullptr,
+                                              d_hit_id ? (int32_t *)d_hit_id + off : nullptr, st1, true, nullptr, 1);
+        // always join: whatever the lanes were given is ordered before what the caller enqueues next
+        bool ok = hip_ok(hipEventRecord((hipEvent_t)D.join_ev, st1), "hipEventRecord") && hip_ok(hipStreamWaitEvent(cs, (hipEvent_t)D.join_ev, 0), "hipStreamWaitEvent");
+        if (cs != st0) ok = hip_ok(hipEventRecord((hipEvent_t)D.join0_ev, st0), "hipEventRecord") && hip_ok(hipStreamWaitEvent(cs, (hipEvent_t)D.join0_ev, 0), "hipStreamWaitEvent") && ok;
+        return rc1 ? rc1 : (ok ? (int)RT_OK : (int)RT_ERR_HIP);
+    }
+    // RT_OPT_LANE picks the work buffers (and, for stream == NULL, the stream): lane 1 continues the frame lane 0 began, RT_OPT_CONTINUE makes lane 0 continue too
+    return render_band(s, t_device, w, h, depth, spp, seed, row0, nrows, d_rgba, d_hit_id, (hipStream_t)stream, s->opt_lane > 0 || s->opt_continue,
+                       nullptr, s->opt_lane > 0 ? s->opt_lane : 0);
 }
 
 int render_impl(rt_scene *s, int w, int h, int depth, int spp, uint64_t seed, int row0, int nrows,
@@ -659,7 +719,7 @@ int render_impl(rt_scene *s, int w, int h, int depth, int spp, uint64_t seed, in
     // kernel (33 MB at 4K: 0.6 ms).  Hit IDs still go through device memory: the shading kernels read them back.
     uint8_t *direct = nullptr;
 #ifndef RT_NO_DIRECT_RGBA
-    if (rgba_out && s->opt_host_bands <= 1) {
+    if (rgba_out) {
         hipPointerAttribute_t attr{};
         if (hipPointerGetAttributes(&attr, rgba_out) == hipSuccess && attr.type == hipMemoryTypeHost && attr.devicePointer) {
             hipPointerAttribute_t last{};
@@ -671,25 +731,29 @@ int render_impl(rt_scene *s, int w, int h, int depth, int spp, uint64_t seed, in
 #endif
     if (!direct && (rc = ensure(D.rgba, D.rgba_cap, 4 * npix))) return rc;
     if ((rc = ensure(D.hit_out, D.hit_out_cap, npix))) return rc;
-    hipStream_t st = (hipStream_t)D.stream, cst = (hipStream_t)D.copy_stream, hst = (hipStream_t)D.copy_stream2;
-    // The frame is enqueued as row bands; band k's copies to the caller's memory run on their own streams beside the
-    // kernels that follow: the hit IDs as soon as the band's nearest-hit kernel has ended (the shading kernels only read
-    // them), the colours behind the band's last kernel, i.e. beside band k + 1.  Only the last band's colours are
-    // exposed.  Bands cost kernel time (every band has its own tails), so there are few: one per ~4 Mi pixels.
-    // Into rt_host_alloc'ed (page-locked) memory the copies are DMA at PCIe rate; into pageable memory they stage
-    // through the runtime's bounce buffers and block this thread, which is why every band is enqueued first.
-    int nb = s->opt_host_bands > 0 ? s->opt_host_bands : (int)(npix >> 22);
+    hipStream_t lst[RT_LANES], cst = (hipStream_t)D.copy_stream, hst = (hipStream_t)D.copy_stream2;
+    for (int k = 0; k < RT_LANES; ++k) if ((rc = lane_stream(D, k, lst[k]))) return rc;
+    // The frame is enqueued as row bands that ALTERNATE between the two lanes (work buffers + stream each): band k + 1's
+    // kernels run beside band k's, filling the tails of its kernels, and band k's colours travel while band k + 1 still
+    // computes — as k_final's own stores over PCIe when the destination is page-locked memory this device can address, as a
+    // copy on a stream of its own otherwise.  The hit IDs of a band are copied as soon as its nearest-hit kernel has ended
+    // (the shading kernels only read them).  Default: 2 bands (one per lane) up to 24 Mi pixels, one per 8 Mi
+    // pixels beyond; measured on the 4K benchmark frame into page-locked memory (tools/host_render_timing.py): 1 band
+    // 1.93 ms, 2 bands 1.86, 3 bands 1.99, 4 bands 2.03 — the bands are short enough for launch gaps to show.  Into pageable memory the copies stage through the runtime's
+    // bounce buffers and block this thread, which is why every band is enqueued first.
+    int nb = s->opt_host_bands > 0 ? s->opt_host_bands : std::max(2, (int)(npix >> 23));
     nb = nb < 1 ? 1 : (nb > RT_HOST_BANDS_MAX ? RT_HOST_BANDS_MAX : nb);
-    if (direct) nb = 1;
+    if (nrows < 2 * RT_TILE_H) nb = 1;
     int brows = (nrows + nb - 1) / nb;
     brows = (brows + RT_TILE_H - 1) / RT_TILE_H * RT_TILE_H;
     int used = 0;
     for (int r = 0; r < nrows && rc == RT_OK; r += brows, ++used) {
         const int rows = nrows - r < brows ? nrows - r : brows;
         const size_t off = (size_t)r * (size_t)w;
+        const int lane = used % RT_LANES;
         rc = render_band(s, t_device, w, h, depth, spp, seed, row0 + r, rows, rgba_out ? (direct ? direct : D.rgba) + 4 * off : nullptr,
-                         D.hit_out + off, st, r > 0, hit_id_out ? (hipEvent_t)D.hits_done[used] : nullptr);
-        if (rc == RT_OK && !hip_ok(hipEventRecord((hipEvent_t)D.band_done[used], st), "hipEventRecord")) rc = RT_ERR_HIP;
+                         D.hit_out + off, lst[lane], r > 0, hit_id_out ? (hipEvent_t)D.hits_done[used] : nullptr, lane);
+        if (rc == RT_OK && !hip_ok(hipEventRecord((hipEvent_t)D.band_done[used], lst[lane]), "hipEventRecord")) rc = RT_ERR_HIP;
     }
     int band = 0;
     for (int r = 0; r < nrows && rc == RT_OK; r += brows, ++band) {
@@ -707,7 +771,7 @@ int render_impl(rt_scene *s, int w, int h, int depth, int spp, uint64_t seed, in
     // always drain both streams, also after an error: nothing may still be writing the caller's buffers on return
     if (!hip_ok(hipStreamSynchronize(cst), "hipStreamSynchronize") && rc == RT_OK) rc = RT_ERR_HIP;
     if (!hip_ok(hipStreamSynchronize(hst), "hipStreamSynchronize") && rc == RT_OK) rc = RT_ERR_HIP;
-    if (!hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize") && rc == RT_OK) rc = RT_ERR_HIP;
+    for (int k = 0; k < RT_LANES; ++k) if (!hip_ok(hipStreamSynchronize(lst[k]), "hipStreamSynchronize") && rc == RT_OK) rc = RT_ERR_HIP;
     return rc;
 }
 
@@ -736,19 +800,33 @@ namespace {
 int device_stats(rt_scene *s, DeviceScene &D, rt_stats *out) {
     if (D.stats_pending) {
         static thread_local std::vector<unsigned long long> all(RT_STAT_SLOTS * 16);
-        if (D.ev_used > 0) HIP_TRY(hipEventSynchronize((hipEvent_t)D.evpool[D.ev_used - 1]));
-        else HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(hipMemcpy(all.data(), D.last_counters, all.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        // the lanes the frame used: wait for each, sum their counters, add their kernel times up; ms_total runs from the
+        // frame's first event to its last, whichever lanes they are on
         unsigned long long c[16] = {0};
-        for (int slot = 0; slot < RT_STAT_SLOTS; ++slot) for (int k = 0; k < 16; ++k) c[k] += all[(size_t)slot * 16 + k];
         double ms[5] = {0, 0, 0, 0, 0};
-        for (int i = 1; i < D.ev_used; ++i) {
-            float t = 0;
-            HIP_TRY(hipEventElapsedTime(&t, (hipEvent_t)D.evpool[i - 1], (hipEvent_t)D.evpool[i]));
-            ms[D.evkind[i]] += t;
-        }
         float tot = 0;
-        if (D.ev_used > 1) HIP_TRY(hipEventElapsedTime(&tot, (hipEvent_t)D.evpool[0], (hipEvent_t)D.evpool[D.ev_used - 1]));
+        bool any_event = false;
+        for (Lane &l : D.lane) if (l.used && l.ev_used > 0) { HIP_TRY(hipEventSynchronize((hipEvent_t)l.evpool[l.ev_used - 1])); any_event = true; }
+        if (!any_event) HIP_TRY(hipDeviceSynchronize());
+        const Lane *first = nullptr;
+        for (Lane &l : D.lane) {
+            if (!l.used || !l.last_counters) continue;
+            HIP_TRY(hipMemcpy(all.data(), l.last_counters, all.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+            for (int slot = 0; slot < RT_STAT_SLOTS; ++slot) for (int k = 0; k < 16; ++k) c[k] += all[(size_t)slot * 16 + k];
+            for (int i = 1; i < l.ev_used; ++i) {
+                float t = 0;
+                HIP_TRY(hipEventElapsedTime(&t, (hipEvent_t)l.evpool[i - 1], (hipEvent_t)l.evpool[i]));
+                ms[l.evkind[i]] += t;
+            }
+            if (l.ev_used > 0 && !first) first = &l;
+        }
+        if (first)
+            for (Lane &l : D.lane) {
+                if (!l.used || l.ev_used == 0) continue;
+                float t = 0;
+                HIP_TRY(hipEventElapsedTime(&t, (hipEvent_t)first->evpool[0], (hipEvent_t)l.evpool[l.ev_used - 1]));
+                tot = std::max(tot, t);
+            }
         rt_stats st{};
         st.primary_rays = D.last_primary;
         st.shadow_rays = c[0];
@@ -874,6 +952,7 @@ int render_multi_impl(rt_scene *s, int w, int h, int depth, int spp, uint64_t se
             DeviceScene &D = s->dev[devs[k]];
             if (hipSetDevice(devs[k]) != hipSuccess) continue;
             if (D.stream && !hip_ok(hipStreamSynchronize((hipStream_t)D.stream), "hipStreamSynchronize") && code == RT_OK) code = RT_ERR_HIP;
+            for (void *x : D.xstream) if (x && !hip_ok(hipStreamSynchronize((hipStream_t)x), "hipStreamSynchronize") && code == RT_OK) code = RT_ERR_HIP;
             if (D.copy_stream && !hip_ok(hipStreamSynchronize((hipStream_t)D.copy_stream), "hipStreamSynchronize") && code == RT_OK) code = RT_ERR_HIP;
             // (the home device's copies into the caller's buffers: nothing may still be writing them after an error return)
             if (D.copy_stream2 && !hip_ok(hipStreamSynchronize((hipStream_t)D.copy_stream2), "hipStreamSynchronize") && code == RT_OK) code = RT_ERR_HIP;
@@ -946,6 +1025,7 @@ int render_multi_impl(rt_scene *s, int w, int h, int depth, int spp, uint64_t se
         if ((rc2 = device_init(dev))) { err = rt_last_error(); return rc2; }
         DeviceScene &D = s->dev[dev];
         bool first = true;
+        int npiece = 0;
         for (int p = 0; p < PIECES; ++p)
             for (int k = 0; k < ngpus; ++k) {
                 Band &B = band[k];
@@ -954,11 +1034,15 @@ int render_multi_impl(rt_scene *s, int w, int h, int depth, int spp, uint64_t se
                 const size_t soff = B.stage_off + (size_t)(B.p0[p] - B.row0) * (size_t)w;
                 uint8_t *dst = !rgba_out ? nullptr : (B.staged ? D.stage_rgba + 4 * soff : H.rgba + 4 * foff);
                 int32_t *dhit = B.staged ? D.stage_hit + soff : H.hit_out + foff;
-                if ((rc2 = render_band(s, dev, w, h, depth, spp, seed, B.p0[p], B.pn[p], dst, dhit, (hipStream_t)D.stream, !first))) { err = rt_last_error(); return rc2; }
+                // consecutive pieces alternate between the device's two lanes: the next piece's kernels fill the tails of this one's
+                const int lane = npiece++ % RT_LANES;
+                hipStream_t ls = nullptr;
+                if ((rc2 = lane_stream(D, lane, ls))) { err = rt_last_error(); return rc2; }
+                if ((rc2 = render_band(s, dev, w, h, depth, spp, seed, B.p0[p], B.pn[p], dst, dhit, ls, !first, nullptr, lane))) { err = rt_last_error(); return rc2; }
                 first = false;
                 first_on[dev] = false;
                 hipEvent_t er = ev[((size_t)k * PIECES + p) * 2], ea = ev[((size_t)k * PIECES + p) * 2 + 1];
-                bool ok = hip_ok(hipEventRecord(er, (hipStream_t)D.stream), "hipEventRecord");
+                bool ok = hip_ok(hipEventRecord(er, ls), "hipEventRecord");
                 if (ok && B.staged) {
                     hipStream_t cs = (hipStream_t)D.copy_stream;
                     ok = hip_ok(hipStreamWaitEvent(cs, er, 0), "hipStreamWaitEvent") &&
@@ -1073,11 +1157,11 @@ int render_device_noalloc_impl(rt_scene *s, int w, int h, int depth, int spp, ui
     for (int r = 0; r < nrows; r += rows_fit) {
         const int rows = nrows - r < rows_fit ? nrows - r : rows_fit;
         const size_t off = (size_t)r * (size_t)w;
-        if ((rc = render_rows(s, D, W, (size_t)rows, w, h, depth, spp, seed, row0 + r, rows,
+        if ((rc = render_rows(s, D, D.lane[0], W, (size_t)rows, w, h, depth, spp, seed, row0 + r, rows,
                               d_rgba ? (uint8_t *)d_rgba + 4 * off : nullptr, d_hit_id ? (int32_t *)d_hit_id + off : nullptr,
                               st, r > 0, false))) return rc;
     }
-    if (nrows == 0) { D.last_primary = 0; D.ev_used = 0; D.stats_pending = false; }
+    if (nrows == 0) { D.last_primary = 0; for (Lane &l : D.lane) { l.used = false; l.ev_used = 0; } D.stats_pending = false; }
     return RT_OK;
 }
 

@@ -42,12 +42,29 @@ struct Workspace {
     double *cb_normal = nullptr;             // per list entry: fnorm x y (from the host)
 };
 
+// One set of work buffers and the stream the renders that use it go to.  A (scene, device) pair has two: consecutive row
+// bands of a frame (rt_render's copy bands, rt_render_multi's pieces, a caller's own pieces: RT_OPT_LANE) alternate
+// between them, so that a band's kernels fill the tails of the other's and its copy to the host or to a peer device
+// runs beside the other band's kernels.
+struct Lane {
+    Workspace ws;                    // views of ws_arena (ws_grow)
+    DevBuf ws_arena;                 // ONE allocation
+    const unsigned long long *last_counters = nullptr;     // where the counters of this lane's part of the last frame live
+    std::vector<void *> evpool;      // hipEvent_t, one per kernel boundary of this lane's part of the last frame
+    std::vector<int> evkind;         // which kernel ended at that event (1 primary .. 4 final)
+    int ev_used = 0;
+    bool used = false;               // by the last frame
+};
+#ifndef RT_LANES_N
+#define RT_LANES_N 2
+#endif
+constexpr int RT_LANES = RT_LANES_N;
+
 struct DeviceScene {          // the scene on ONE device (HBM), owned by the rt_scene
     int device = -1;
     uint64_t version = 0;            // rt_scene::version of the uploaded copy (0: nothing uploaded)
     uint64_t eye_version = 0;        // rt_scene::eye_version of the uploaded eye-apex records
     DevBuf arena;                    // ONE allocation: every array below is a view of it (device_prepare)
-    DevBuf ws_arena;                 // ONE allocation: the work buffers `ws` are views of it (ws_grow)
     DevBuf leaves, aux, guards, mats, lights;
     DevBuf tri_rec, rect_rec;        // (1 + npoint) blocks of ntri / nrect records: eye, then each point light (VALU filter build)
     DevBuf tri_gid, rect_gid;        // per-type slot -> leaf index
@@ -58,22 +75,20 @@ struct DeviceScene {          // the scene on ONE device (HBM), owned by the rt_
     DevBuf gen_tri_rows, gen_rect_rows;                            // the blocks' matrix-core rows (leaf bounding spheres as linear forms)
     DevBuf gen_tri_ssph, gen_rect_ssph;                            // super-blocks of 32 blocks: bounding sphere = the frame of their rows
     void *helper = nullptr;          // rt_kernels.hip: Helper — the thread that makes the streams beside the first host index build
-    void *stream = nullptr;          // hipStream_t: renders of this scene on this device (when the caller passes none)
+    void *stream = nullptr;          // hipStream_t: renders of this scene on this device (when the caller passes none), lane 0
+    void *fork_ev = nullptr, *join_ev = nullptr, *join0_ev = nullptr;   // hipEvent_t: rt_render_device's own split of a big band over lanes 0 and 1
+    void *xstream[RT_LANES] = {};    // hipStream_t: the same for lanes 1.. (entry 0 stays empty: lane 0 runs on `stream`)
     void *copy_stream = nullptr;     // hipStream_t: rt_render's copies to host memory, band by band; rt_render_multi's peer copies
     void *copy_stream2 = nullptr;    // hipStream_t: rt_render_multi's copies from the home device to host memory
     void *band_done[RT_HOST_BANDS_MAX] = {};   // hipEvent_t
     void *hits_done[RT_HOST_BANDS_MAX] = {};   // hipEvent_t: the band's hit-ID buffer is complete (rt_render copies it early)
     // work buffers of rt_render / rt_render_device, grown on demand
-    Workspace ws;
+    Lane lane[RT_LANES];
     uint8_t *rgba = nullptr;    size_t rgba_cap = 0;       // rt_render (host buffers) staging
     int32_t *hit_out = nullptr; size_t hit_out_cap = 0;
     uint8_t *stage_rgba = nullptr; size_t stage_rgba_cap = 0;   // rt_render_multi: this device's bands before the peer copy
     int32_t *stage_hit = nullptr;  size_t stage_hit_cap = 0;
     // statistics of the last render on this device
-    const unsigned long long *last_counters = nullptr;     // where that render's counters live
-    std::vector<void *> evpool;      // hipEvent_t, one per kernel boundary of the last render
-    std::vector<int> evkind;         // which kernel ended at that event (1 primary .. 4 final)
-    int ev_used = 0;
     bool stats_pending = false;
     uint64_t last_primary = 0;
     rt_stats stats{};
@@ -124,8 +139,10 @@ struct rt_scene {
     // per-scene options (rt_scene_set_option)
     int opt_cull = 1;                     // 0: every wave scans every block of the leaf stream
     int opt_filter = 0;                   // 0: matrix-core first stage; 1: FP32 vector-ALU kernels (test build only)
-    int opt_host_bands = 0;               // copy bands of rt_render (0: one per 2 Mi pixels)
+    int opt_host_bands = 0;               // copy bands of rt_render (0: 2, one per 8 Mi pixels beyond 24 Mi)
     int opt_multi_stage = 0;              // rt_render_multi: also the home device's bands go through a staging buffer + peer copy
+    bool opt_continue = false;            // rt_render_device calls add to the statistics of the frame in progress
+    int opt_lane = -1;                    // -1: rt_render_device splits big bands over both lanes itself; 0, 1: the lane its calls use
     // arbitrary `fnorm` closures (Main.hs:956-965): per callback group, the caller's function
     std::vector<rt_normal_fn> normal_fn;
     std::vector<void *> normal_user;

@@ -292,6 +292,12 @@ def test_render_multi_equals_single_render(gpu_lib):
             assert st["primary_rays"] == w * h and st["shadow_rays"] == one["shadow_rays"]
     rgba, none = sc.render_multi(w, h, [0, 0], want_hit=False)
     assert none is None and (rgba == ref_rgba).all()
+    fresh = api.Scene(world, lights)            # first call of a scene: the lanes' work buffers grow between the pieces of the frame
+    rgba, hit = fresh.render_multi(w, h, [0, 0])
+    st = fresh.stats()
+    assert (rgba == ref_rgba).all() and (hit == ref_hit).all()
+    assert st["primary_rays"] == w * h and st["shadow_rays"] == one["shadow_rays"]
+    fresh.close()
     ref4 = sc.render(w, h, spp=4, seed=3)
     got4 = sc.render_multi(w, h, [0, 0, 0], spp=4, seed=3)
     assert (ref4[0] == got4[0]).all() and (ref4[1] == got4[1]).all()
@@ -568,6 +574,54 @@ def test_host_render_copy_bands_and_page_locked_buffers(gpu_lib):
     sc.close()
     with pytest.raises(ValueError):
         api.Scene(*scenes.stacked_cubes()).render(64, 64, out_rgba=np.zeros((64, 64, 3), np.uint8))
+
+
+def test_pieces_on_alternating_lanes(gpu_lib):
+    """RT_OPT_LANE: a frame rendered as pieces that alternate between the scene's two lanes (work buffers + stream each, so
+    the pieces overlap on the device) has the bytes of the one-call frame, its statistics cover every piece, and the
+    lanes go on working across frames of different sizes; a reflective scene (bounce levels in both lanes) too."""
+    from raytrace_amd import _lib
+    from hip_buffers import DeviceBuffer, hip
+    for (world, lights), (w, h), depth in ((scenes.synthetic(ntri=600, ncuboid=60), (1000, 531), 4), (scenes.mirror_room(), (300, 200), 4),
+                                           (scenes.synthetic(ntri=600, ncuboid=60), (640, 96), 4)):
+        sc = api.Scene(world, lights)
+        ref_rgba, ref_hit = sc.render(w, h, depth=depth)
+        one = sc.stats()
+        rgba = DeviceBuffer((h, w, 4), np.uint8, fill=0x5a)
+        hit = DeviceBuffer((h, w), np.int32, fill=0x5a)
+        for cuts in ((0, 200, h), (0, 8, 16, 24, 120, h), (0, h)):
+            cuts = sorted(set(min(c, h) for c in cuts))
+            for i, (r0, r1) in enumerate(zip(cuts[:-1], cuts[1:])):
+                sc.set_option(_lib.RT_OPT_LANE, i & 1).set_option(_lib.RT_OPT_CONTINUE, int(i > 0))
+                sc.render_device(w, h, rgba.ptr + 4 * w * r0, hit.ptr + 4 * w * r0, depth=depth, row0=r0, nrows=r1 - r0)
+            sc.set_option(_lib.RT_OPT_LANE, -1).set_option(_lib.RT_OPT_CONTINUE, 0)
+            st = sc.stats()                                  # (waits for both lanes)
+            assert hip().hipDeviceSynchronize() == 0
+            assert (rgba.numpy() == ref_rgba).all() and (hit.numpy() == ref_hit).all(), cuts
+            assert st["primary_rays"] == w * h and st["shadow_rays"] == one["shadow_rays"] and st["bounce_rays"] == one["bounce_rays"], cuts
+        with pytest.raises(RuntimeError, match="RT_OPT_LANE"):
+            sc.set_option(_lib.RT_OPT_LANE, 2)
+        sc.close()
+    # left to itself (RT_OPT_LANE -1) rt_render_device splits a band of 12 Mi pixels or more over the two lanes: same bytes
+    # and the same counts as the unsplit call, on the library's stream and on a stream of the caller's, full frame and band
+    world, lights = scenes.synthetic(ntri=600, ncuboid=60)
+    sc = api.Scene(world, lights)
+    w, h = 4096, 3200
+    rgba, hit = DeviceBuffer((h, w, 4), np.uint8, fill=0x5a), DeviceBuffer((h, w), np.int32, fill=0x5a)
+    sc.set_option(_lib.RT_OPT_LANE, 0)
+    sc.render_device(w, h, rgba.ptr, hit.ptr)
+    one = sc.stats()
+    ref_rgba, ref_hit = rgba.numpy(), hit.numpy()
+    sc.set_option(_lib.RT_OPT_LANE, -1)
+    for row0, nrows in ((0, h), (24, 3171)):
+        rgba2, hit2 = DeviceBuffer((nrows, w, 4), np.uint8, fill=0x5a), DeviceBuffer((nrows, w), np.int32, fill=0x5a)
+        sc.render_device(w, h, rgba2.ptr, hit2.ptr, row0=row0, nrows=nrows)
+        st = sc.stats()
+        assert (rgba2.numpy() == ref_rgba[row0:row0 + nrows]).all() and (hit2.numpy() == ref_hit[row0:row0 + nrows]).all()
+        assert st["primary_rays"] == w * nrows and (nrows < h or st["shadow_rays"] == one["shadow_rays"])
+        sc.render_device(w, h, None, hit2.ptr, row0=row0, nrows=nrows)                 # hit IDs only, split too
+        assert (hit2.numpy() == ref_hit[row0:row0 + nrows]).all()
+    sc.close()
 
 
 @pytest.mark.parametrize("name", sorted(__import__("known_answers").CASES))

@@ -245,6 +245,9 @@ def test_scene_options_and_the_cross_check_build():
         sc.set_option(99, 1)
     with pytest.raises(RuntimeError, match=">= 0"):
         sc.set_option(_lib.RT_OPT_HOST_BANDS, -1)
+    sc.set_option(_lib.RT_OPT_LANE, 1).set_option(_lib.RT_OPT_LANE, 0).set_option(_lib.RT_OPT_LANE, -1)
+    with pytest.raises(RuntimeError, match="RT_OPT_LANE"):
+        sc.set_option(_lib.RT_OPT_LANE, 2)
     sc.close()
     V = _lib.valu_lib()
     sv = api.Scene(*scenes.planes(), lib=V)

@@ -24,5 +24,11 @@ for bands in (sys.argv[1:] or [""]):
             t0 = time.perf_counter(); sc.render(w, h, out_rgba=rgba, out_hit=hit); ts.append(time.perf_counter() - t0)
         st = sc.stats()
         same = bool((rgba == ref_rgba).all() and (hit == ref_hit).all())
+        if name == "page-locked":                       # colours only (hit_id_out = NULL): what a caller that wants the image asks for
+            tc = []
+            for _ in range(6):
+                t0 = time.perf_counter(); sc.render(w, h, out_rgba=rgba, want_hit=False); tc.append(time.perf_counter() - t0)
+            print(f"rt_render {w}x{h} -> {name:11s} bands={bands or 'auto'}, colours only: min {min(tc)*1e3:.2f} ms, median {sorted(tc)[3]*1e3:.2f} ms; "
+                  f"kernels {sc.stats()['ms_total']:.2f} ms; same: {bool((rgba == ref_rgba).all())}", flush=True)
         print(f"rt_render {w}x{h} -> {name:11s} bands={bands or 'auto'}: min {min(ts)*1e3:.2f} ms, median {sorted(ts)[3]*1e3:.2f} ms "
               f"({w*h/min(ts)/1e6:.0f} Mrays/s); kernels {st['ms_total']:.2f} ms; primary rays {st['primary_rays']}; same as first render: {same}", flush=True)

@@ -17,28 +17,31 @@ sc = api.Scene(*scenes.synthetic())
 sc.prepare(w, h)
 dev = torch.device("cuda", 0)
 rows = h // n
-st = torch.cuda.Stream(dev)
+sts = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
 res = {}
-for which, r0 in (("middle band", (n // 2) * rows), ("top band", 0)):
-    frame = torch.empty((rows, w, 4), dtype=torch.uint8, device=dev)
-    hit = torch.empty((rows, w), dtype=torch.int32, device=dev)
-    for parts in (1, 2, 3, 4, 6, 8):
-        subs = sub_bands((r0, rows), parts, fractions=piece_fractions(parts))
-        ts = []
-        for rep in range(6):
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for p0, pn in subs:
-                if pn > 0:
-                    sc.render_device(w, h, frame[p0 - r0:].data_ptr(), hit[p0 - r0:].data_ptr(), row0=p0, nrows=pn, stream=st.cuda_stream)
-            st.synchronize()
-            ts.append((time.perf_counter() - t0) * 1e3)
-        res[(which, parts)] = min(ts[1:])
-    base = res[(which, 1)]
-    print(f"{which} (rows {r0}..{r0 + rows - 1} of the {w}x{h} frame): " +
-          ", ".join(f"{p} piece(s) {res[(which, p)]:.3f} ms" for p in (1, 2, 3, 4, 6, 8)))
-    print("   overhead per extra piece: " + ", ".join(f"{p}: {(res[(which, p)] - base) / (p - 1):.3f} ms" for p in (2, 3, 4, 6, 8)))
-full = sum(v for k, v in res.items() if k[1] == 1) / 2 * n
+for lanes in (1, 2):              # 1: every piece on lane 0; 2: pieces alternate between the scene's two lanes (RT_OPT_LANE)
+    for which, r0 in (("middle band", (n // 2) * rows), ("top band", 0)):
+        frame = torch.empty((rows, w, 4), dtype=torch.uint8, device=dev)
+        hit = torch.empty((rows, w), dtype=torch.int32, device=dev)
+        for parts in (1, 2, 3, 4, 6, 8):
+            subs = [sb for sb in sub_bands((r0, rows), parts, fractions=piece_fractions(parts)) if sb[1] > 0]
+            ts = []
+            for rep in range(6):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i, (p0, pn) in enumerate(subs):
+                    lane = i % lanes
+                    sc.set_option(_lib.RT_OPT_LANE, lane)
+                    sc.render_device(w, h, frame[p0 - r0:].data_ptr(), hit[p0 - r0:].data_ptr(), row0=p0, nrows=pn, stream=sts[lane].cuda_stream)
+                sts[0].synchronize(); sts[1].synchronize()
+                ts.append((time.perf_counter() - t0) * 1e3)
+            res[(lanes, which, parts)] = min(ts[1:])
+        sc.set_option(_lib.RT_OPT_LANE, -1)
+        base = res[(lanes, which, 1)]
+        print(f"{lanes} lane(s), {which} (rows {r0}..{r0 + rows - 1} of the {w}x{h} frame): " +
+              ", ".join(f"{p} piece(s) {res[(lanes, which, p)]:.3f} ms" for p in (1, 2, 3, 4, 6, 8)))
+        print("   overhead per extra piece: " + ", ".join(f"{p}: {(res[(lanes, which, p)] - base) / (p - 1):.3f} ms" for p in (2, 3, 4, 6, 8)), flush=True)
+full = sum(v for k, v in res.items() if k[0] == 1 and k[2] == 1) / 2 * n
 for o in (0.03, 0.05, 0.1, 0.15):
     for bw in (48.0, 64.0, 76.8):
         parts, fr, wts, t, d = plan_frame(full, n, w * h * 4 / n, bw, o)
