@@ -121,8 +121,12 @@ int  rt_scene_set_dialect(rt_scene *, int dialect);
  *                      device.  Two calls in flight on the SAME lane must be on the same stream (they share work buffers).
  *   RT_OPT_CONTINUE    1: the following rt_render_device calls add to the frame in progress as far as rt_get_stats is
  *                      concerned (counts and times of all its pieces, both lanes); 0 (default): a call on lane 0 begins a
- *                      new frame, a call on lane 1 adds to it. */
-enum { RT_OPT_CULL = 0, RT_OPT_FILTER = 1, RT_OPT_HOST_BANDS = 2, RT_OPT_MULTI_STAGE = 3, RT_OPT_LANE = 4, RT_OPT_CONTINUE = 5 };
+ *                      new frame, a call on lane 1 adds to it.
+ *   RT_OPT_HISTORY     1 (default): every wave of the two big kernels leaves its duration behind, and the next render of
+ *                      the same band of the same scene dispatches the waves longest first, which shortens the kernels'
+ *                      tails (a few hundred KB of device memory per band; the no-alloc entry point keeps none).  The order
+ *                      decides when a wave runs, never what it computes.  0: launch order. */
+enum { RT_OPT_CULL = 0, RT_OPT_FILTER = 1, RT_OPT_HOST_BANDS = 2, RT_OPT_MULTI_STAGE = 3, RT_OPT_LANE = 4, RT_OPT_CONTINUE = 5, RT_OPT_HISTORY = 6 };
 int  rt_scene_set_option(rt_scene *, int option, int value);
 
 /* ---- scene construction (replaces the closure-building constructors) -------------------- */

@@ -27,19 +27,65 @@ namespace {
 //   When L.N <= 0 both Phong terms are exactly 0 (Main.hs:480-484), so the shadow ray cannot change
 //   the pixel and is not cast.
 
+// Wave history (RenderParams::wcost_p ...): one work-group sorts n waves by the duration they had, longest first — a
+// counting sort on the duration in units of 0.64 us (512 bins, one thread per bin; the order inside a bin is whatever
+// the atomics give).  Every index 0 .. n - 1 is written to exactly one place: the result is a permutation whatever the
+// durations were.  `have` = 0: no durations yet, the identity.  Durations are consumed (zeroed): a wave that does not run
+// next time (fewer shadow jobs) then counts as free.  These are the FIRST work-groups of k_setup's grid (1 + lights of
+// them, only when a history is kept): they run beside the thousands of work-groups that do k_setup's own work, off the
+// critical path (as extra work-groups of k_queue_offsets they cost 0.038 ms per frame, mostly serialised LDS atomics).
+// Measured against it and no better (profiles/r03_wave_history.txt): only the longest 5 - 30 % first and the shortest
+// 10 - 30 % last with the middle left in launch order; two tiles per work-group, a long one and a short one.
+constexpr int RT_WBINS = 512;
+__device__ __forceinline__ unsigned wave_bin(unsigned ticks) { return (unsigned)(RT_WBINS - 1) - min(ticks >> 6, (unsigned)(RT_WBINS - 1)); }
+__device__ void wave_order_block(uint32_t *cost, uint32_t *order, int n, bool have) {
+    __shared__ unsigned s_bin[RT_WBINS], s_scan[RT_WBINS];
+    const int t = (int)threadIdx.x;
+    static_assert(RT_SETUP_THREADS == RT_WBINS, "one thread per bin");
+    if (!have) {
+        for (int i = t; i < n; i += RT_SETUP_THREADS) { order[i] = (uint32_t)i; cost[i] = 0u; }
+        return;
+    }
+    s_bin[t] = 0u;
+    __syncthreads();
+    for (int i = t; i < n; i += RT_SETUP_THREADS) atomicAdd(&s_bin[wave_bin(cost[i])], 1u);
+    __syncthreads();
+    s_scan[t] = s_bin[t];
+    __syncthreads();
+    for (int o = 1; o < RT_WBINS; o <<= 1) {             // inclusive scan over the bins
+        const unsigned v = t >= o ? s_scan[t - o] : 0u;
+        __syncthreads();
+        s_scan[t] += v;
+        __syncthreads();
+    }
+    s_bin[t] = s_scan[t] - s_bin[t];                     // exclusive: where the bin starts
+    __syncthreads();
+    for (int i = t; i < n; i += RT_SETUP_THREADS) {
+        order[atomicAdd(&s_bin[wave_bin(cost[i])], 1u)] = (uint32_t)i;
+        cost[i] = 0u;
+    }
+}
+
 #ifndef RT_WAVES_EU_SETUP
 #define RT_WAVES_EU_SETUP 4
 #endif
 __global__ void __attribute__((amdgpu_waves_per_eu(RT_WAVES_EU_SETUP, 8))) __launch_bounds__(RT_SETUP_THREADS) k_setup(const RenderParams P) {
     // shadow jobs of the block per light: per-wave counts -> offsets inside the block's run
     __shared__ unsigned s_cnt[32][RT_SETUP_THREADS / 64];
+    if ((int)blockIdx.x < P.wsort_blocks) {               // wave history: the sorting work-groups come first (0 of them: none kept)
+        const int b = (int)blockIdx.x;
+        if (b == 0) wave_order_block(P.wcost_p, P.worder_p_out, P.tiles_x * P.tiles_y, true);
+        else wave_order_block(P.wcost_s + (size_t)(b - 1) * (size_t)P.wstride_s, P.worder_s + (size_t)(b - 1) * (size_t)P.wstride_s, P.wstride_s, P.whave != 0);
+        return;
+    }
+    const unsigned block = blockIdx.x - (unsigned)P.wsort_blocks;
     // level 0: a block takes a 32 x 16 pixel tile, so that the shadow rays it queues (256 consecutive entries make one
     // wave of k_shadow_mfma) leave from neighbouring pixels and form a narrow bundle; bounce levels: slots in order
-    int pix = (int)(blockIdx.x * RT_SETUP_THREADS + threadIdx.x);
+    int pix = (int)(block * RT_SETUP_THREADS + threadIdx.x);
     bool act = (unsigned)pix < num_slots(P);
     if (!P.rays) {
         // a wave takes 8 x 8 pixels of the tile (objects are blobs: fewer waves straddle an outline than with 32 x 2 strips)
-        const int tx = (int)blockIdx.x % P.tiles_x, ty = (int)blockIdx.x / P.tiles_x;
+        const int tx = (int)block % P.tiles_x, ty = (int)block / P.tiles_x;
         const int wq = (int)(threadIdx.x >> 6), lq = (int)(threadIdx.x & 63);
         const int x = tx * 32 + (wq & 3) * 8 + (lq & 7), y = ty * (RT_SETUP_THREADS / 32) + (wq >> 2) * 8 + (lq >> 3);
         act = x < P.w && y < P.nrows;
@@ -122,7 +168,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(RT_WAVES_EU_SETUP, 8))) __lau
     if ((int)threadIdx.x < P.npoint) {
         unsigned run = 0;
         for (int k = 0; k < RT_SETUP_THREADS / 64; ++k) { const unsigned c = s_cnt[threadIdx.x][k]; s_cnt[threadIdx.x][k] = run; run += c; }
-        P.tcount[(size_t)threadIdx.x * (size_t)P.setup_blocks + blockIdx.x] = run;
+        P.tcount[(size_t)threadIdx.x * (size_t)P.setup_blocks + block] = run;
     }
     __syncthreads();
     // the block's jobs go to its own slots; k_queue_offsets + k_queue_compact then line the blocks' runs up in block
@@ -130,7 +176,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(RT_WAVES_EU_SETUP, 8))) __lau
     for (pl = 0; pl < P.npoint; ++pl) {
         const bool need = (needmask >> pl) & 1u;
         const unsigned long long m = __ballot(need);
-        if (need) P.qsparse[((size_t)pl * (size_t)P.setup_blocks + blockIdx.x) * RT_SETUP_THREADS + s_cnt[pl][wv] + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)pix;
+        if (need) P.qsparse[((size_t)pl * (size_t)P.setup_blocks + block) * RT_SETUP_THREADS + s_cnt[pl][wv] + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)pix;
     }
 }
 
@@ -647,7 +693,11 @@ __global__ void RT_HOT(RT_WAVES_EU_MF_SHADOW) k_shadow_mfma(const RenderParams P
     RT_WAVE_T0
     const int pl = (int)P.qcount[RT_QCOUNT_ORDER + blockIdx.y];      // costliest light first (k_queue_offsets)
     const unsigned count = P.qcount[pl];
+#if RT_WAVES_PER_BLOCK == 1
+    const unsigned wave = P.worder_s ? P.worder_s[(size_t)pl * (size_t)P.wstride_s + blockIdx.x] : blockIdx.x;   // longest wave of the frame before first
+#else
     const unsigned wave = blockIdx.x * RT_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+#endif
     if (wave * 256u >= count) return;
     const unsigned long long t_start = wall_clock64();
     const int lane = (int)(threadIdx.x & 63), c = lane & 31, h = lane >> 5;
@@ -855,10 +905,14 @@ __global__ void RT_HOT(RT_WAVES_EU_MF_SHADOW) k_shadow_mfma(const RenderParams P
     if (lane == 0 && nexact) stat_add(P, 2, (unsigned long long)nexact);
     if (lane == 0) stat_add(P, 7, (unsigned long long)nblocks);
     if (lane == 0 && Q.nrec) stat_add(P, 4, (unsigned long long)Q.nrec);
+    const unsigned ticks = (unsigned)(wall_clock64() - t_start);
     if (lane == 0 && (wave & 7u) == 3u) {       // every eighth wave reports how long it took (100 MHz ticks): the lights' order next time
-        atomicAdd(&P.qcount[RT_QCOUNT_HIST + 2 * pl], (unsigned)(wall_clock64() - t_start));
+        atomicAdd(&P.qcount[RT_QCOUNT_HIST + 2 * pl], ticks);
         atomicAdd(&P.qcount[RT_QCOUNT_HIST + 2 * pl + 1], 1u);
     }
+#if RT_WAVES_PER_BLOCK == 1
+    if (lane == 0 && P.wcost_s) P.wcost_s[(size_t)pl * (size_t)P.wstride_s + wave] = ticks;     // ... and every wave, for its own place in the order
+#endif
 #ifdef RT_WAVE_TIMES
     wave_ph[2] = (Q.t_s1 & 0xffff) | ((Q.t_ex & 0xffff) << 16) | ((Q.t_bits & 0xffff) << 32) | ((Q.t_loop & 0xffff) << 48);
     wave_record(P, 1u | ((unsigned)pl << 8), wave, wave_t0, nblocks, Q.nrec, nexact, wave_ph);
@@ -878,7 +932,12 @@ __global__ void RT_HOT(RT_WAVES_EU_MF_PRIMARY) k_primary_mfma(const RenderParams
     __shared__ float s_bun[RT_WAVES_PER_BLOCK][RT_BUNDLE_FLOATS];
     __shared__ float s_rec[RT_WAVES_PER_BLOCK][16 * 32];
     const int wv = (int)(threadIdx.x >> 6);
+#if RT_WAVES_PER_BLOCK == 1
+    const int wave = P.worder_p ? (int)P.worder_p[blockIdx.x] : (int)blockIdx.x;                 // longest wave of the frame before first
+    const unsigned long long t_start = wall_clock64();
+#else
     const int wave = (int)(blockIdx.x * RT_WAVES_PER_BLOCK) + wv;
+#endif
     const int lane = (int)(threadIdx.x & 63), c = lane & 31, h = lane >> 5;
     const int tx = wave % P.tiles_x, ty = wave / P.tiles_x;
     if (ty >= P.tiles_y) return;
@@ -1031,6 +1090,9 @@ __global__ void RT_HOT(RT_WAVES_EU_MF_PRIMARY) k_primary_mfma(const RenderParams
     if (lane == 0 && nexact) stat_add(P, 1, (unsigned long long)nexact);
     if (lane == 0) stat_add(P, 6, (unsigned long long)nblocks);
     if (lane == 0 && Q.nrec) stat_add(P, 4, (unsigned long long)Q.nrec);
+#if RT_WAVES_PER_BLOCK == 1
+    if (lane == 0 && P.wcost_p) P.wcost_p[wave] = (unsigned)(wall_clock64() - t_start);
+#endif
 #ifdef RT_WAVE_TIMES
     wave_ph[2] = (Q.t_s1 & 0xffff) | ((Q.t_ex & 0xffff) << 16) | ((Q.t_bits & 0xffff) << 32) | ((Q.t_loop & 0xffff) << 48);
     wave_record(P, 0u, (unsigned)wave, wave_t0, nblocks, Q.nrec, nexact, wave_ph);
@@ -1620,7 +1682,7 @@ __global__ void __launch_bounds__(256) k_cb_gather(const RenderParams P) {
 namespace rt {
 void launch_primary_mfma(const RenderParams &P, unsigned tblocks, hipStream_t st) { hipLaunchKernelGGL(k_primary_mfma, dim3(tblocks), dim3(RT_WAVES_PER_BLOCK * 64), 0, st, P); }
 void launch_shadow_mfma(const RenderParams &P, unsigned sblocks, unsigned nlights, hipStream_t st) { hipLaunchKernelGGL(k_shadow_mfma, dim3(sblocks, nlights), dim3(RT_WAVES_PER_BLOCK * 64), 0, st, P); }
-void launch_setup(const RenderParams &P, unsigned ublocks, hipStream_t st) { hipLaunchKernelGGL(k_setup, dim3(ublocks), dim3(RT_SETUP_THREADS), 0, st, P); }
+void launch_setup(const RenderParams &P, unsigned ublocks, hipStream_t st) { hipLaunchKernelGGL(k_setup, dim3(ublocks + (unsigned)P.wsort_blocks), dim3(RT_SETUP_THREADS), 0, st, P); }
 void launch_queue_offsets(const RenderParams &P, unsigned nlights, hipStream_t st) { hipLaunchKernelGGL(k_queue_offsets, dim3(nlights), dim3(1024), 0, st, P); }
 void launch_queue_compact(const RenderParams &P, unsigned ublocks, unsigned nlights, hipStream_t st) { hipLaunchKernelGGL(k_queue_compact, dim3(ublocks, nlights), dim3(RT_COMPACT_THREADS), 0, st, P); }
 void launch_final(const RenderParams &P, unsigned blocks, unsigned threads, hipStream_t st) { hipLaunchKernelGGL(k_final, dim3(blocks), dim3(threads), 0, st, P); }

@@ -96,6 +96,19 @@ struct RenderParams {
     uint16_t point_light[32];       // index in `lights` of the k-th point light of the current group of 32
     uint32_t *lit_w;                // the current group's word of `lit` (= lit + group * lit_stride)
     long long lit_stride;           // slots per group of 32 point lights in `lit`
+    // Wave history of this chunk (Lane::history; nullptr: none kept, waves run in launch order).  Every wave of the two big
+    // kernels leaves its duration (100 MHz ticks); the first work-groups of k_setup sort the waves by it, longest
+    // first, and the next frame of the same band maps blockIdx through that order: the kernel's tail is then made of its
+    // shortest waves instead of whichever came last (replayed through a list scheduler: 744 -> 587 us for the shadow kernel).
+    // The order decides WHEN a wave runs, never what it computes; it is always a permutation of the launch's work-groups.
+    uint32_t *wcost_p;              // per tile: duration of its k_primary_mfma wave in this frame
+    const uint32_t *worder_p;       // work-group -> tile for k_primary_mfma (nullptr: identity; the frame before wrote it)
+    uint32_t *worder_p_out;         // ... as sorted in this frame, for the next one
+    uint32_t *wcost_s;              // per (light, wave of 256 jobs): duration of its k_shadow_mfma wave, wstride_s per light
+    uint32_t *worder_s;             // work-group -> wave for k_shadow_mfma, per light (written by this frame's k_setup)
+    int wstride_s;                  // waves per light = blockIdx.x range of k_shadow_mfma
+    int whave;                      // 1: wcost_s holds the durations of the frame before (else the order is the identity)
+    int wsort_blocks;               // k_setup's first work-groups sort the history: 1 + lights, or 0
 };
 
 struct HitRec { double px, py, pz, nx, ny, nz; };
@@ -115,7 +128,7 @@ constexpr int RT_QCOUNT_HIST = RT_QCOUNT_CLEAR, RT_QCOUNT_ORDER = RT_QCOUNT_HIST
 // Launches (defined beside the kernels).  Grids are in work-groups; every launch goes to `st`.
 void launch_primary_mfma(const RenderParams &P, unsigned tblocks, hipStream_t st);
 void launch_shadow_mfma(const RenderParams &P, unsigned sblocks, unsigned nlights, hipStream_t st);
-void launch_setup(const RenderParams &P, unsigned ublocks, hipStream_t st);
+void launch_setup(const RenderParams &P, unsigned ublocks, hipStream_t st);            // (+ P.wsort_blocks work-groups in front that sort the wave history)
 void launch_queue_offsets(const RenderParams &P, unsigned nlights, hipStream_t st);
 void launch_queue_compact(const RenderParams &P, unsigned ublocks, unsigned nlights, hipStream_t st);
 void launch_final(const RenderParams &P, unsigned blocks, unsigned threads, hipStream_t st);

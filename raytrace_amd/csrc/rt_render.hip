@@ -486,6 +486,36 @@ int render_rows(rt_scene *s, DeviceScene &D, Lane &LN, const Workspace &W, size_
     }
 #endif
 
+    // Wave history (rt_params.h): kept per band for the plain pipeline — level 0 only, one group of lights, the growing
+    // work buffers (`timed` renders: the no-alloc entry point allocates nothing, so it keeps none).
+    WaveHistory *hist = nullptr;
+    size_t hist_tiles = 0, hist_swaves = 0;
+#if RT_WAVES_PER_BLOCK == 1
+    if (timed && use_mfma && s->opt_history && levels == 1 && ngroups == 1 && !point_lights.empty() && d_rgba && depth > 0 && !callbacks) {
+        if (LN.history_version != s->version || LN.history.size() > 64) {       // another scene (or too many bands): start over
+            if (!LN.history.empty()) HIP_TRY(hipDeviceSynchronize());
+            for (auto &kv : LN.history) if (kv.second.buf) (void)hipFree(kv.second.buf);
+            LN.history.clear();
+            LN.history_version = s->version;
+        }
+        hist_tiles = (size_t)((w + RT_TILE_W - 1) / RT_TILE_W) * ((crow + RT_TILE_H - 1) / RT_TILE_H);
+        hist_swaves = (crow * (size_t)w + 255) / 256;
+        const size_t words = hist_tiles + point_lights.size() * hist_swaves, chunks = ((size_t)nrows + crow - 1) / crow;
+        const std::array<uint64_t, 6> key = {(uint64_t)w, (uint64_t)h, (uint64_t)row0, (uint64_t)nrows, (uint64_t)crow,
+                                             (uint64_t)point_lights.size() | (uint64_t)s->eye_version << 16};
+        WaveHistory &H = LN.history[key];
+        if (!H.buf) {
+            HIP_TRY(hipMalloc(&H.buf, chunks * 2 * words * sizeof(uint32_t)));
+            HIP_TRY(hipMemsetAsync(H.buf, 0, chunks * 2 * words * sizeof(uint32_t), st));
+            H.words = words;
+        }
+        H.last_use = ++LN.history_clock;
+        hist = &H;
+    }
+#endif
+    const bool hist_ready = hist && hist->ready;
+    if (hist) hist->ready = false;         // (until this frame is enqueued whole)
+
     if (timed && (rc = next_event(LN, st, 0))) return rc;
     for (int sample = 0; sample < spp; ++sample) {
         P.sample = sample;
@@ -504,6 +534,15 @@ int render_rows(rt_scene *s, DeviceScene &D, Lane &LN, const Workspace &W, size_
             const long long tiles = (long long)P.tiles_x * P.tiles_y;
             const unsigned tblocks = (unsigned)((tiles + RT_WAVES_PER_BLOCK - 1) / RT_WAVES_PER_BLOCK);
             const unsigned pblocks = (unsigned)(((size_t)P.qcap + 255) / 256);
+            if (hist) {                // this chunk's part of the history: costs, then orders
+                uint32_t *base = (uint32_t *)hist->buf + (r / crow) * 2 * hist->words;
+                P.wcost_p = base; P.wcost_s = base + hist_tiles;
+                P.worder_p_out = base + hist->words; P.worder_s = P.worder_p_out + hist_tiles;
+                // (a later sample of the same frame finds the orders of the sample before: as good as the last frame's)
+                P.worder_p = (hist_ready || sample > 0) ? P.worder_p_out : nullptr;
+                P.whave = (hist_ready || sample > 0) ? 1 : 0;
+                P.wsort_blocks = 1 + (int)point_lights.size();
+            }
             if (depth == 0) {      // trace 0 = black (Main.hs:542): every pixel misses
                 HIP_TRY(hipMemsetAsync(P.hit_id + P.out_off, 0xff, (size_t)P.qcap * sizeof(int32_t), st));
             } else {
@@ -518,6 +557,7 @@ int render_rows(rt_scene *s, DeviceScene &D, Lane &LN, const Workspace &W, size_
             // grids: shadow waves of 256 jobs, one thread per slot; bounce levels have up to lcap slots
             const size_t slots_max = levels > 1 ? (size_t)P.lcap : (size_t)P.qcap;
             const unsigned sblocks = (unsigned)((slots_max + 256 * RT_WAVES_PER_BLOCK - 1) / (256 * RT_WAVES_PER_BLOCK));
+            P.wstride_s = (int)sblocks;     // (<= hist_swaves: a last, shorter chunk uses the front of its arrays)
             const unsigned lblocks = (unsigned)((slots_max + 255) / 256);
             int32_t *const hit0 = P.hit_id;
             const long long off0 = P.out_off;
@@ -584,6 +624,7 @@ int render_rows(rt_scene *s, DeviceScene &D, Lane &LN, const Workspace &W, size_
         if (timed && (rc = next_event(LN, st, 4))) return rc;
     }
     HIP_TRY(hipGetLastError());
+    if (hist) hist->ready = true;
     D.stats_pending = true;
     return RT_OK;
 }
@@ -651,6 +692,7 @@ void scene_destroy_impl(rt_scene *s) {
         void *ptrs[] = {d.arena.p, d.rgba, d.hit_out, d.stage_rgba, d.stage_hit};
         for (void *p : ptrs) if (p) (void)hipFree(p);
         for (Lane &l : d.lane) if (l.ws_arena.p) (void)hipFree(l.ws_arena.p);
+        for (Lane &l : d.lane) for (auto &kv : l.history) if (kv.second.buf) (void)hipFree(kv.second.buf);
         for (Lane &l : d.lane) for (void *e : l.evpool) if (e) (void)hipEventDestroy((hipEvent_t)e);
         for (void *x : d.xstream) if (x) (void)hipStreamDestroy((hipStream_t)x);
         for (void *e : d.band_done) if (e) (void)hipEventDestroy((hipEvent_t)e);

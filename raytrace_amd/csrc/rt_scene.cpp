@@ -1099,6 +1099,7 @@ int rt_scene_set_option(rt_scene *s, int option, int value) {
         if (value < -1 || value >= rt::RT_LANES) { set_error("rt_scene_set_option: RT_OPT_LANE takes -1 .. " + std::to_string(rt::RT_LANES - 1)); return RT_ERR_ARG; }
         s->opt_lane = value; return RT_OK;
     case RT_OPT_CONTINUE: s->opt_continue = value != 0; return RT_OK;
+    case RT_OPT_HISTORY: s->opt_history = value != 0; return RT_OK;
     }
     set_error("rt_scene_set_option: unknown option");
     return RT_ERR_ARG;

@@ -5,6 +5,8 @@
 // tree's depth-first order (that order decides equal-distance hits, Main.hs:213-214), the list of
 // lights, and the per-(apex, leaf) FP32 filter records derived from them.
 #pragma once
+#include <array>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -46,7 +48,17 @@ struct Workspace {
 // bands of a frame (rt_render's copy bands, rt_render_multi's pieces, a caller's own pieces: RT_OPT_LANE) alternate
 // between them, so that a band's kernels fill the tails of the other's and its copy to the host or to a peer device
 // runs beside the other band's kernels.
+// Wave history of one band (the same rows of the same frame of the same scene, rendered again and again): durations and
+// dispatch order of the waves of k_primary_mfma and k_shadow_mfma, per chunk (RenderParams::wcost_p ...).
+struct WaveHistory {
+    void *buf = nullptr;             // ONE allocation: chunks x 2 x words
+    size_t words = 0;                // per chunk and per array (cost, order): tiles + lights x shadow waves
+    bool ready = false;              // a whole frame has been enqueued with it: its orders are permutations
+    uint64_t last_use = 0;
+};
 struct Lane {
+    std::map<std::array<uint64_t, 6>, WaveHistory> history;   // by (w, h, row0, nrows, chunk rows, lights); dropped when the scene changes
+    uint64_t history_version = 0, history_clock = 0;
     Workspace ws;                    // views of ws_arena (ws_grow)
     DevBuf ws_arena;                 // ONE allocation
     const unsigned long long *last_counters = nullptr;     // where the counters of this lane's part of the last frame live
@@ -142,6 +154,7 @@ struct rt_scene {
     int opt_host_bands = 0;               // copy bands of rt_render (0: 2, one per 8 Mi pixels beyond 24 Mi)
     int opt_multi_stage = 0;              // rt_render_multi: also the home device's bands go through a staging buffer + peer copy
     bool opt_continue = false;            // rt_render_device calls add to the statistics of the frame in progress
+    bool opt_history = true;              // RT_OPT_HISTORY: waves of a band rendered before are dispatched longest first
     int opt_lane = -1;                    // -1: rt_render_device splits big bands over both lanes itself; 0, 1: the lane its calls use
     // arbitrary `fnorm` closures (Main.hs:956-965): per callback group, the caller's function
     std::vector<rt_normal_fn> normal_fn;

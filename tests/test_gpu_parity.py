@@ -624,6 +624,44 @@ def test_pieces_on_alternating_lanes(gpu_lib):
     sc.close()
 
 
+def test_wave_history_changes_nothing_but_the_order(gpu_lib):
+    """RT_OPT_HISTORY (on by default): from the second render of a band on, the waves of the two big kernels are dispatched
+    longest first, by the durations they left behind.  The bytes of frames 2, 3, 4 equal those of frame 1 (no history yet) and
+    of a scene that keeps no history, which in turn equal the oracle's; so do a band, a supersampled frame (the later
+    samples use the orders of the sample before), a frame of more than one chunk, and the counts."""
+    from raytrace_amd import _lib
+    world, lights = scenes.synthetic(ntri=600, ncuboid=60)
+    w, h = 1000, 531
+    plain = api.Scene(world, lights).set_option(_lib.RT_OPT_HISTORY, 0)
+    ref_rgba, ref_hit = plain.render(w, h)
+    ref_st = plain.stats()
+    osc = ob.OracleScene(world, lights)
+    ref = osc.render(w, h, row0=256, nrows=8, nthreads=16)
+    assert (ref_hit[256:264] == ref["hit_id"]).all() and (ref_rgba[256:264, :, :3] == ref["rgb"]).all()
+    ref4 = plain.render(w, h, spp=4, seed=11)
+    sc = api.Scene(world, lights)
+    for frame in range(4):
+        rgba, hit = sc.render(w, h)
+        st = sc.stats()
+        assert (rgba == ref_rgba).all() and (hit == ref_hit).all(), frame
+        assert st["primary_rays"] == ref_st["primary_rays"] and st["shadow_rays"] == ref_st["shadow_rays"], frame
+        rgba, hit = sc.render(w, h, row0=77, nrows=201)            # another band: a history of its own
+        assert (rgba == ref_rgba[77:278]).all() and (hit == ref_hit[77:278]).all(), frame
+        got4 = sc.render(w, h, spp=4, seed=11)
+        assert (got4[0] == ref4[0]).all() and (got4[1] == ref4[1]).all(), frame
+    sc.close(); plain.close()
+    # more than one chunk (16 Mi pixels) per band
+    sc = api.Scene(world, lights).set_option(_lib.RT_OPT_HOST_BANDS, 1)
+    w, h = 4096, 4200
+    first = sc.render(w, h)
+    for frame in range(2):
+        again = sc.render(w, h)
+        assert (again[0] == first[0]).all() and (again[1] == first[1]).all(), frame
+    ref = osc.render(w, h, row0=4184, nrows=8, nthreads=16)
+    assert (first[1][4184:4192] == ref["hit_id"]).all() and (first[0][4184:4192, :, :3] == ref["rgb"]).all()
+    sc.close()
+
+
 @pytest.mark.parametrize("name", sorted(__import__("known_answers").CASES))
 def test_hand_derived_pixel_on_the_gpu(gpu_lib, name):
     """The closed-form pixels of tests/known_answers.py (derived from Main.hs by hand, no oracle involved) through the
