@@ -105,16 +105,22 @@ __device__ __forceinline__ void stat_add(const RenderParams &P, int k, unsigned 
     atomicAdd(&P.counters[(size_t)(wave % RT_STAT_SLOTS) * 16 + k], v);
 }
 #ifdef RT_WAVE_TIMES
-// measurement builds: one record per wave {kernel | light << 8, wave, start, end (100 MHz wall clock), blocks scanned,
-// record tests, exact evaluations, hardware id}; dbg[0] counts the records
-__device__ __forceinline__ void wave_record(const RenderParams &P, unsigned kernel, unsigned wave, unsigned long long t0,
+// measurement builds: one record per wave {kernel | light << 8 | hardware id << 16, wave, start, end (100 MHz wall clock),
+// blocks scanned, record tests, exact evaluations, phases}, in a place of its own (`slot`: the launch's work-group number,
+// offset per kernel) — a counter that hands out places is ONE address for every wave of the frame, and the L2 serialises
+// atomics on one address at 12 ns each: 83 waves per microsecond, which is about the rate these kernels end waves at
+// (the first version of this tool measured its own counter).  Records that were not written have end = 0.
+__device__ __forceinline__ void wave_record(const RenderParams &P, unsigned kernel, unsigned long long slot, unsigned wave, unsigned long long t0,
                                             unsigned nblocks, unsigned nrec, unsigned nexact, const unsigned long long (&ph)[3]) {
     if (!P.dbg || (threadIdx.x & 63u) != 0u) return;
     const unsigned long long t1 = wall_clock64();
-    const unsigned long long k = atomicAdd(&P.dbg[0], 1ull);
+    const unsigned long long k = slot;
     if (k >= (1ull << 20)) return;
     unsigned long long *r = P.dbg + 8 + 8 * k;
-    r[0] = kernel; r[1] = wave; r[2] = t0; r[3] = t1;
+    // where the wave ran: HW_ID (wave slot [3:0], SIMD [5:4], CU [11:8], SH [12], SE [15:13]) and XCC_ID [3:0]
+    const unsigned hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (15 << 11)), xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));
+    r[0] = (unsigned long long)kernel | ((unsigned long long)(hw & 0xffffu) << 16) | ((unsigned long long)(xcc & 0xfu) << 32);
+    r[1] = wave; r[2] = t0; r[3] = t1;
     r[4] = (unsigned long long)nblocks | ((unsigned long long)nrec << 16) | ((unsigned long long)nexact << 40);
     r[5] = ph[0]; r[6] = ph[1]; r[7] = ph[2];      // phase boundaries: after the ray set-up, after bound + guard proofs, after the scan
 }

@@ -915,7 +915,7 @@ __global__ void RT_HOT(RT_WAVES_EU_MF_SHADOW) k_shadow_mfma(const RenderParams P
 #endif
 #ifdef RT_WAVE_TIMES
     wave_ph[2] = (Q.t_s1 & 0xffff) | ((Q.t_ex & 0xffff) << 16) | ((Q.t_bits & 0xffff) << 32) | ((Q.t_loop & 0xffff) << 48);
-    wave_record(P, 1u | ((unsigned)pl << 8), wave, wave_t0, nblocks, Q.nrec, nexact, wave_ph);
+    wave_record(P, 1u | ((unsigned)pl << 8), (unsigned long long)P.tiles_x * P.tiles_y + (unsigned long long)gridDim.x * blockIdx.y + blockIdx.x, wave, wave_t0, nblocks, Q.nrec, nexact, wave_ph);
 #endif
 }
 
@@ -1095,7 +1095,7 @@ __global__ void RT_HOT(RT_WAVES_EU_MF_PRIMARY) k_primary_mfma(const RenderParams
 #endif
 #ifdef RT_WAVE_TIMES
     wave_ph[2] = (Q.t_s1 & 0xffff) | ((Q.t_ex & 0xffff) << 16) | ((Q.t_bits & 0xffff) << 32) | ((Q.t_loop & 0xffff) << 48);
-    wave_record(P, 0u, (unsigned)wave, wave_t0, nblocks, Q.nrec, nexact, wave_ph);
+    wave_record(P, 0u, blockIdx.x, (unsigned)wave, wave_t0, nblocks, Q.nrec, nexact, wave_ph);
 #endif
 }
 
@@ -1595,7 +1595,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(RT_WAVES_EU_GEN, 8))) __launc
     if (lane == 0 && Q.nrec) stat_add(P, 4, (unsigned long long)Q.nrec);
 #ifdef RT_WAVE_TIMES
     wave_ph[2] = (Q.t_s1 & 0xffff) | ((Q.t_ex & 0xffff) << 16) | ((Q.t_bits & 0xffff) << 32) | ((Q.t_loop & 0xffff) << 48);
-    wave_record(P, 2u, wave, wave_t0, nblocks, Q.nrec, nexact, wave_ph);
+    wave_record(P, 2u, blockIdx.x, wave, wave_t0, nblocks, Q.nrec, nexact, wave_ph);
 #endif
 }
 

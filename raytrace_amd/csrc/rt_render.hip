@@ -480,7 +480,7 @@ int render_rows(rt_scene *s, DeviceScene &D, Lane &LN, const Workspace &W, size_
     {
         static unsigned long long *dbg = nullptr;
         if (!dbg) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dbg), (8 + 8 * (1ull << 20)) * sizeof(unsigned long long)));
-        HIP_TRY(hipMemsetAsync(dbg, 0, 64, st));
+        HIP_TRY(hipMemsetAsync(dbg, 0, (8 + 8 * (1ull << 20)) * sizeof(unsigned long long), st));
         P.dbg = dbg;
         g_wave_dbg = dbg;
     }
@@ -892,7 +892,7 @@ int device_stats(rt_scene *s, DeviceScene &D, rt_stats *out) {
         if (const char *path = getenv("RT_WAVE_TIMES_FILE")) {
             std::vector<unsigned long long> rec(8 + 8 * (1ull << 20));
             HIP_TRY(hipMemcpy(rec.data(), g_wave_dbg, rec.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-            if (FILE *f = fopen(path, "wb")) { fwrite(rec.data(), 8, 8 + 8 * (size_t)std::min<unsigned long long>(rec[0], 1ull << 20), f); fclose(f); }
+            if (FILE *f = fopen(path, "wb")) { fwrite(rec.data(), 8, rec.size(), f); fclose(f); }
         }
 #endif
     }

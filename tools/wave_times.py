@@ -15,11 +15,15 @@ w, h = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 and not mirror 
 world, lights = scenes.mirror_bench() if mirror else scenes.synthetic()
 sc = api.Scene(world, lights)
 sc.set_option(_lib.RT_OPT_HOST_BANDS, 1)           # one band: the records describe the whole frame
+if os.environ.get("RT_NO_HISTORY"):                # waves in launch order (default: longest first from the second frame on)
+    sc.set_option(_lib.RT_OPT_HISTORY, 0)
 for _ in range(3):
     sc.render(w, h, depth=2 if mirror else 4)
     st = sc.stats()
 raw = np.fromfile(path, dtype=np.uint64)
-n = int(raw[0]); rec = raw[8:8 + 8 * n].reshape(n, 8)
+rec = raw[8:].reshape(-1, 8)
+rec = rec[rec[:, 3] != 0]                                     # (a record per work-group slot; end = 0: not written)
+n = len(rec)
 if os.environ.get("RT_WAVE_TIMES_KEEP"):                      # keep the raw records (for scheduling experiments off the box)
     np.save(os.environ["RT_WAVE_TIMES_KEEP"], rec)
 print(f"{n} wave records; kernel ms: primary {st['ms_primary']:.3f} shadow {st['ms_shadow']:.3f}")
