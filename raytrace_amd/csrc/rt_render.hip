@@ -786,20 +786,25 @@ int render_impl(rt_scene *s, int w, int h, int depth, int spp, uint64_t seed, in
     int nb = s->opt_host_bands > 0 ? s->opt_host_bands : std::max(2, (int)(npix >> 23));
     nb = nb < 1 ? 1 : (nb > RT_HOST_BANDS_MAX ? RT_HOST_BANDS_MAX : nb);
     if (nrows < 2 * RT_TILE_H) nb = 1;
-    int brows = (nrows + nb - 1) / nb;
-    brows = (brows + RT_TILE_H - 1) / RT_TILE_H * RT_TILE_H;
-    int used = 0;
-    for (int r = 0; r < nrows && rc == RT_OK; r += brows, ++used) {
-        const int rows = nrows - r < brows ? nrows - r : brows;
+    int bstart[RT_HOST_BANDS_MAX + 1];                   // band k = rows [bstart[k], bstart[k + 1]) of the call's rows
+    {
+        int brows = (nrows + nb - 1) / nb;
+        brows = (brows + RT_TILE_H - 1) / RT_TILE_H * RT_TILE_H;
+        int k = 0;
+        for (int r = 0; r < nrows; r += brows) bstart[k++] = r;
+        nb = k;
+        bstart[nb] = nrows;
+    }
+    for (int used = 0; used < nb && rc == RT_OK; ++used) {
+        const int r = bstart[used], rows = bstart[used + 1] - r;
         const size_t off = (size_t)r * (size_t)w;
         const int lane = used % RT_LANES;
         rc = render_band(s, t_device, w, h, depth, spp, seed, row0 + r, rows, rgba_out ? (direct ? direct : D.rgba) + 4 * off : nullptr,
                          D.hit_out + off, lst[lane], r > 0, hit_id_out ? (hipEvent_t)D.hits_done[used] : nullptr, lane);
         if (rc == RT_OK && !hip_ok(hipEventRecord((hipEvent_t)D.band_done[used], lst[lane]), "hipEventRecord")) rc = RT_ERR_HIP;
     }
-    int band = 0;
-    for (int r = 0; r < nrows && rc == RT_OK; r += brows, ++band) {
-        const int rows = nrows - r < brows ? nrows - r : brows;
+    for (int band = 0; band < nb && rc == RT_OK; ++band) {
+        const int r = bstart[band], rows = bstart[band + 1] - r;
         const size_t off = (size_t)r * (size_t)w, n = (size_t)rows * (size_t)w;
         if (hit_id_out) {
             if (!hip_ok(hipStreamWaitEvent(hst, (hipEvent_t)D.hits_done[band], 0), "hipStreamWaitEvent")) { rc = RT_ERR_HIP; break; }
