@@ -280,6 +280,11 @@ def main():
         ntri, nrect, nlt = 200, 1, 1
         wname = "Main.hs default scene (gaussian height field, linearInterpolation)"
     scene = api.Scene(world, lights, lib=L)
+    # N > 1: the bands travel between GPUs, so the frame is 3 bytes per pixel there (RT_OPT_RGB24: the reference's PixelRGB8,
+    # what its BMP writer takes); N = 1 keeps the RGBA8 frame of the earlier rounds (`same_frame_as_multi_gpu` has both)
+    bpp = 3 if world_size > 1 else 4
+    if bpp == 3:
+        scene.set_option(_lib.RT_OPT_RGB24, 1)
     if args.filter == "valu":
         scene.set_option(_lib.RT_OPT_FILTER, 1)
     if args.no_cull:
@@ -302,7 +307,7 @@ def main():
         if rank == 0:
             info[:32] = torch.tensor(scene.row_costs(w, h, 32, depth=args.depth, spp=args.spp), dtype=torch.float64)
             # the same frame on this GPU alone, same code path: the honest N = 1 point of the scaling curve
-            full = torch.empty((h, w, 4), dtype=torch.uint8, device=dev)
+            full = torch.empty((h, w, bpp), dtype=torch.uint8, device=dev)
             fhit = torch.empty((h, w), dtype=torch.int32, device=dev)
             for k in range(3):
                 torch.cuda.synchronize()
@@ -321,13 +326,13 @@ def main():
         n1_same_frame_ms = float(info[32])
         # the frame on paper first (every rank computes the same plan): pieces per band and their sizes, rank 0's larger share
         plan_parts, plan_fr, plan_weights, predicted_ms, plan_detail = plan_frame(
-            n1_same_frame_ms, n, float(w) * h * 4 / n, args.link_gbps, args.piece_overhead_ms)
+            n1_same_frame_ms, n, float(w) * h * bpp / n, args.link_gbps, args.piece_overhead_ms)
         if args.pieces > 0:
             plan_parts, plan_fr = args.pieces, piece_fractions(args.pieces)
         bands = split_rows(info[:32].numpy(), h, n, weights=plan_weights)
     row0, nrows = bands[rank]
     # frame buffer: rank 0 owns the whole image (bands of the other ranks land in it), others own a band
-    frame = torch.empty((h if rank == 0 else nrows, w, 4), dtype=torch.uint8, device=dev)
+    frame = torch.empty((h if rank == 0 else nrows, w, bpp), dtype=torch.uint8, device=dev)
     mine = frame[row0:row0 + nrows] if rank == 0 else frame
     hit = torch.empty((nrows, w), dtype=torch.int32, device=dev)
     # The renders go to a torch stream that is ALSO torch's current stream while the gather is enqueued: RCCL orders its
@@ -355,7 +360,7 @@ def main():
                                 stream=rs.cuda_stream)
             return
         pending, host = [], []
-        host_frame = torch.empty((h, w, 4), dtype=torch.uint8) if staged and rank == 0 else None
+        host_frame = torch.empty((h, w, bpp), dtype=torch.uint8) if staged and rank == 0 else None
         rs.record_event(marks["start"])
         lanes[1].wait_event(marks["start"])            # (the previous step ended with lane 1 joined to lane 0)
         for k in range(pieces):
@@ -462,7 +467,7 @@ def main():
         step()
         sync()
         if rank == 0:
-            alone = torch.empty((h, w, 4), dtype=torch.uint8, device=dev)
+            alone = torch.empty((h, w, bpp), dtype=torch.uint8, device=dev)
             scene.render_device(w, h, alone.data_ptr(), None, depth=args.depth, spp=args.spp, seed=20260355, stream=rs.cuda_stream,
                                 lane=0, cont=False)
             torch.cuda.synchronize()
@@ -603,15 +608,31 @@ def main():
                     ts.append(time.perf_counter() - t0)
                 legs[name] = {"ms": min(ts[1:]) * 1e3, "median_ms": float(np.median(ts[1:])) * 1e3, "mrays": primary / min(ts[1:]) / 1e6}
             same = bool((torch.from_numpy(dests["pageable"][0]).to(dev) == frame).all())
+            # ... and what the reference's own caller asks for: the image alone, 3 bytes per pixel (PixelRGB8, Main.hs:621)
+            scene.set_option(_lib.RT_OPT_RGB24, 1)
+            rgb_h = api.host_buffer((h, w, 3), np.uint8)
+            ts = []
+            for _ in range(6):
+                t0 = time.perf_counter()
+                scene.render(w, h, depth=args.depth, spp=args.spp, seed=20260355, out_rgba=rgb_h, want_hit=False)
+                ts.append(time.perf_counter() - t0)
+            legs["page_locked_rgb24_image_only"] = {"ms": min(ts[1:]) * 1e3, "median_ms": float(np.median(ts[1:])) * 1e3, "mrays": primary / min(ts[1:]) / 1e6,
+                                                    "equals_rgba_frame": bool((torch.from_numpy(np.asarray(rgb_h)).to(dev) == frame[:, :, :3]).all())}
+            scene.set_option(_lib.RT_OPT_RGB24, 0)
+            del rgb_h
             out["rt_render"] = {"page_locked": legs["page_locked"], "pageable": legs["pageable"], "frame_equals_device_render": same,
+                                "page_locked_rgb24_image_only": legs["page_locked_rgb24_image_only"],
                                 "note": "wall time of rt_render(scene, w, h, ...) into caller-owned host buffers, RGBA8 + int32 hit IDs, best of 5 "
-                                        "after one warm-up; rendered as row bands whose copies overlap the next band's kernels"}
+                                        "after one warm-up; rendered as two row bands on the scene's two lanes; into page-locked memory k_final "
+                                        "stores the colours straight over PCIe.  page_locked_rgb24_image_only: RT_OPT_RGB24, no hit IDs — the 24-bit "
+                                        "image the reference's main writes"}
             out["rt_render_mrays"] = legs["page_locked"]["mrays"]
             del dests
             if args.workload == "synthetic" and (w, h) != (MULTI_W, MULTI_H):
                 # configs[3]'s frame on this one GPU: the N = 1 point that the N > 1 lines of this script compare with
-                big = torch.empty((MULTI_H, MULTI_W, 4), dtype=torch.uint8, device=dev)
+                big = torch.empty((MULTI_H, MULTI_W, 3), dtype=torch.uint8, device=dev)
                 bhit = torch.empty((MULTI_H, MULTI_W), dtype=torch.int32, device=dev)
+                scene.set_option(_lib.RT_OPT_RGB24, 1)       # (3 bytes per pixel, as the ranks of the N > 1 runs render it)
                 ts = []
                 for _ in range(4):
                     torch.cuda.synchronize()
@@ -625,8 +646,8 @@ def main():
                 scene.render_device(MULTI_W, MULTI_H, big.data_ptr(), bhit.data_ptr(), depth=args.depth, spp=args.spp, seed=20260355,
                                     stream=rs.cuda_stream, lane=0, cont=False)
                 bst = scene.stats()
-                scene.set_option(_lib.RT_OPT_LANE, -1)
-                out["same_frame_as_multi_gpu"] = {"width": MULTI_W, "height": MULTI_H, "ms": min(ts[1:]) * 1e3,
+                scene.set_option(_lib.RT_OPT_LANE, -1).set_option(_lib.RT_OPT_RGB24, 0)
+                out["same_frame_as_multi_gpu"] = {"width": MULTI_W, "height": MULTI_H, "bytes_per_pixel": 3, "ms": min(ts[1:]) * 1e3,
                                                   "mrays": MULTI_W * MULTI_H * args.spp / min(ts[1:]) / 1e6,
                                                   "ms_on_one_lane": bst["ms_total"],
                                                   "kernel_ms_on_one_lane": {"k_primary": bst["ms_primary"], "k_setup": bst["ms_setup"], "k_shadow": bst["ms_shadow"], "k_final": bst["ms_final"]},

@@ -125,8 +125,12 @@ int  rt_scene_set_dialect(rt_scene *, int dialect);
  *   RT_OPT_HISTORY     1 (default): every wave of the two big kernels leaves its duration behind, and the next render of
  *                      the same band of the same scene dispatches the waves longest first, which shortens the kernels'
  *                      tails (a few hundred KB of device memory per band; the no-alloc entry point keeps none).  The order
- *                      decides when a wave runs, never what it computes.  0: launch order. */
-enum { RT_OPT_CULL = 0, RT_OPT_FILTER = 1, RT_OPT_HOST_BANDS = 2, RT_OPT_MULTI_STAGE = 3, RT_OPT_LANE = 4, RT_OPT_CONTINUE = 5, RT_OPT_HISTORY = 6 };
+ *                      decides when a wave runs, never what it computes.  0: launch order.
+ *   RT_OPT_RGB24       1: every colour output of the render calls (`rgba_out`, `d_rgba`) is 3 bytes per pixel, R G B —
+ *                      the reference's PixelRGB8 (Main.hs:621), what rt_write_bmp and a 24-bit BMP take — instead of
+ *                      4 (R G B 255, default 0): a quarter less to carry over PCIe and between devices.  Buffers are
+ *                      then 3 * w * nrows bytes.  Same colours. */
+enum { RT_OPT_CULL = 0, RT_OPT_FILTER = 1, RT_OPT_HOST_BANDS = 2, RT_OPT_MULTI_STAGE = 3, RT_OPT_LANE = 4, RT_OPT_CONTINUE = 5, RT_OPT_HISTORY = 6, RT_OPT_RGB24 = 7 };
 int  rt_scene_set_option(rt_scene *, int option, int value);
 
 /* ---- scene construction (replaces the closure-building constructors) -------------------- */

@@ -27,7 +27,7 @@ class rt_stats(C.Structure):
 
 # an `fnorm` closure as a C callback: void fn(int n, const double *xy, double *normals, void *user)
 NORMAL_FN = C.CFUNCTYPE(None, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p)
-RT_OPT_CULL, RT_OPT_FILTER, RT_OPT_HOST_BANDS, RT_OPT_MULTI_STAGE, RT_OPT_LANE, RT_OPT_CONTINUE, RT_OPT_HISTORY = 0, 1, 2, 3, 4, 5, 6
+RT_OPT_CULL, RT_OPT_FILTER, RT_OPT_HOST_BANDS, RT_OPT_MULTI_STAGE, RT_OPT_LANE, RT_OPT_CONTINUE, RT_OPT_HISTORY, RT_OPT_RGB24 = 0, 1, 2, 3, 4, 5, 6, 7
 
 
 # every symbol include/raytrace_gpu.h declares: name -> (restype, argtypes)

@@ -340,6 +340,7 @@ class Scene:
     """Owns an rt_scene.  Built from (world, lights) in the reference's depth-first leaf order."""
 
     def __init__(self, world: Shape, lights, lib=None):
+        self.bytes_per_pixel = 4               # of the colour outputs (3 after set_option(RT_OPT_RGB24, 1))
         self._L = lib or _lib.lib()
         self._callbacks = {}                      # id(fnorm) -> ctypes callback object (kept alive; one thunk per distinct fnorm)
         self._callback_error = None               # first exception an fnorm raised during a render (re-raised after it)
@@ -441,16 +442,18 @@ class Scene:
 
     def render(self, w, h, depth=4, spp=1, seed=0, row0=0, nrows=None, want_rgba=True, want_hit=True,
                out_rgba=None, out_hit=None):
-        """Host-buffer render (rt_render).  Returns (rgba[nrows,w,4] uint8, hit_id[nrows,w] int32).
+        """Host-buffer render (rt_render).  Returns (rgba[nrows,w,4] uint8, hit_id[nrows,w] int32); with
+        set_option(RT_OPT_RGB24, 1) the colours are [nrows,w,3].
 
         out_rgba / out_hit: caller-owned arrays of exactly that shape and dtype (e.g. from host_buffer(),
         which makes the copy back DMA); by default fresh pageable numpy arrays are returned."""
         nrows = h - row0 if nrows is None else nrows
-        for out, shape, dt in ((out_rgba, (nrows, w, 4), np.uint8), (out_hit, (nrows, w), np.int32)):
+        bpp = self.bytes_per_pixel
+        for out, shape, dt in ((out_rgba, (nrows, w, bpp), np.uint8), (out_hit, (nrows, w), np.int32)):
             if out is not None and (out.shape != shape or out.dtype != dt or not out.flags.c_contiguous):
                 raise ValueError(f"render: output array must be C-contiguous {shape} {np.dtype(dt).name}")
         want_rgba, want_hit = want_rgba or out_rgba is not None, want_hit or out_hit is not None
-        rgba = (out_rgba if out_rgba is not None else np.empty((nrows, w, 4), np.uint8)) if want_rgba else None
+        rgba = (out_rgba if out_rgba is not None else np.empty((nrows, w, bpp), np.uint8)) if want_rgba else None
         hit = (out_hit if out_hit is not None else np.empty((nrows, w), np.int32)) if want_hit else None
         self._check(self._L.rt_render(self._h, w, h, depth, spp, seed, row0, nrows,
                                      rgba.ctypes.data if want_rgba else None,
@@ -462,6 +465,8 @@ class Scene:
         """rt_scene_set_option: _lib.RT_OPT_CULL / RT_OPT_FILTER / RT_OPT_HOST_BANDS / RT_OPT_MULTI_STAGE / RT_OPT_LANE /
         RT_OPT_CONTINUE."""
         self._check(self._L.rt_scene_set_option(self._h, option, value), "rt_scene_set_option")
+        if option == _lib.RT_OPT_RGB24:
+            self.bytes_per_pixel = 3 if value else 4
         return self
 
     def prepare(self, w, h):
@@ -478,7 +483,7 @@ class Scene:
         """rt_render_multi: the whole image on several devices of this process (bands of equal measured cost,
         gathered on devices[0] over xGMI, then copied to host memory)."""
         devs = (C.c_int * len(devices))(*devices)
-        rgba = np.empty((h, w, 4), np.uint8) if want_rgba else None
+        rgba = np.empty((h, w, self.bytes_per_pixel), np.uint8) if want_rgba else None
         hit = np.empty((h, w), np.int32) if want_hit else None
         self._check(self._L.rt_render_multi(self._h, w, h, depth, spp, seed, len(devices), devs,
                                            rgba.ctypes.data if want_rgba else None,

@@ -334,6 +334,22 @@ __device__ __forceinline__ int round8(double v) {
 }
 __device__ __forceinline__ double hs_max0(double v) { return 0.0 <= v ? v : 0.0; }    // max 0 v
 
+// RT_OPT_RGB24: pixel `idx` of a 3-bytes-per-pixel buffer.  Lanes l, l + 1, l + 2, l + 3 of a wave hold the pixels
+// idx, .., idx + 3 with idx % 4 == 0 when `packed` (the image width is a multiple of 4: every row, every 8-pixel patch
+// row and every chunk then starts on such an index, and a group of four is inside the image or outside as a whole): the
+// twelve bytes of a group are three aligned dwords, dword k = (colour k >> 8k) | (colour k + 1 << (24 - 8k)), stored by
+// lanes 0 .. 2 of the group.  Otherwise three byte stores per pixel.  Call with EVERY lane of the wave (`act`: this lane
+// has a pixel).
+__device__ __forceinline__ void store_rgb24(uint8_t *out, long long idx, uint32_t rgb, bool act, bool packed) {
+    if (!packed) {
+        if (act) { uint8_t *o = out + 3 * idx; o[0] = (uint8_t)rgb; o[1] = (uint8_t)(rgb >> 8); o[2] = (uint8_t)(rgb >> 16); }
+        return;
+    }
+    const uint32_t next = __shfl_down(rgb, 1);
+    const unsigned k = (unsigned)idx & 3u;
+    if (act && k < 3u) *reinterpret_cast<uint32_t *>(out + 3 * (idx - (long long)k) + 4 * k) = (rgb >> (8u * k)) | (next << (24u - 8u * k));
+}
+
 // x ** specularity (Main.hs:483).  A DELIBERATE departure from the reference's expression: materials carry small whole
 // exponents (1, 20, 100, 400 in the reference's scenes) and for whole n <= 512 the power is taken by squaring.  Every
 // squaring doubles the relative error of its operand, so the result is off by up to about n * 2^-53 (4e-14 at n = 400),

@@ -1178,8 +1178,9 @@ __global__ void __attribute__((amdgpu_waves_per_eu(RT_WAVES_EU_FINAL, 8))) __lau
             store_ray(P.next_rays, base + (unsigned)lane, child);
         }
     }
-    if (!act) return;
     const uint32_t rgb = (uint32_t)cr | ((uint32_t)cg << 8) | ((uint32_t)cb << 16);
+    if (!P.colour && P.rgba && P.bpp == 3) { store_rgb24(P.rgba, P.out_off + pix, rgb, act, P.rgb_packed != 0); return; }    // (every lane)
+    if (!act) return;
     if (P.colour) {
         P.colour[pix] = rgb;
     } else if (P.rgba) {
@@ -1623,8 +1624,10 @@ __global__ void __launch_bounds__(256) k_combine(const RayRec *__restrict__ rays
 // level-0 colours -> RGBA8 (spp == 1) or the sample accumulator
 __global__ void __launch_bounds__(256) k_store(const RenderParams P) {
     const int pix = (int)(blockIdx.x * 256 + threadIdx.x);
-    if (pix >= P.qcap) return;
-    const uint32_t rgb = P.colour[pix];
+    const bool act = pix < P.qcap;
+    const uint32_t rgb = act ? P.colour[pix] : 0u;
+    if (P.rgba && P.bpp == 3) { store_rgb24(P.rgba, P.out_off + pix, rgb, act, P.rgb_packed != 0); return; }
+    if (!act) return;
     if (P.rgba) reinterpret_cast<uint32_t *>(P.rgba)[P.out_off + pix] = rgb | 0xff000000u;
     else {
         uint32_t *a = P.accum + 3 * (P.out_off + pix);
@@ -1633,11 +1636,16 @@ __global__ void __launch_bounds__(256) k_store(const RenderParams P) {
 }
 
 // spp > 1: mean of the per-sample 8-bit colours, (sum + spp/2) / spp
-__global__ void k_resolve(const uint32_t *__restrict__ accum, uint8_t *__restrict__ rgba, size_t npix, uint32_t spp) {
+__global__ void k_resolve(const uint32_t *__restrict__ accum, uint8_t *__restrict__ rgba, size_t npix, uint32_t spp, int bpp, int rgb_packed) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= npix) return;
-    const uint32_t r = (accum[3 * i] + spp / 2) / spp, g = (accum[3 * i + 1] + spp / 2) / spp, b = (accum[3 * i + 2] + spp / 2) / spp;
-    reinterpret_cast<uint32_t *>(rgba)[i] = r | (g << 8) | (b << 16) | 0xff000000u;
+    const bool act = i < npix;
+    uint32_t rgb = 0u;
+    if (act) {
+        const uint32_t r = (accum[3 * i] + spp / 2) / spp, g = (accum[3 * i + 1] + spp / 2) / spp, b = (accum[3 * i + 2] + spp / 2) / spp;
+        rgb = r | (g << 8) | (b << 16);
+    }
+    if (bpp == 3) { store_rgb24(rgba, (long long)i, rgb, act, rgb_packed != 0); return; }
+    if (act) reinterpret_cast<uint32_t *>(rgba)[i] = rgb | 0xff000000u;
 }
 
 // RT_NORMAL_CALLBACK (an arbitrary fnorm, Main.hs:956-965): lists the slots of this chunk / level whose nearest hit lies
@@ -1691,8 +1699,8 @@ void launch_combine(const RayRec *rays, const uint32_t *col, const unsigned *cou
     hipLaunchKernelGGL(k_combine, dim3(blocks), dim3(256), 0, st, rays, col, count, cap, parent_col);
 }
 void launch_store(const RenderParams &P, unsigned blocks, hipStream_t st) { hipLaunchKernelGGL(k_store, dim3(blocks), dim3(256), 0, st, P); }
-void launch_resolve(const uint32_t *accum, uint8_t *rgba, size_t npix, uint32_t spp, hipStream_t st) {
-    hipLaunchKernelGGL(k_resolve, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, accum, rgba, npix, spp);
+void launch_resolve(const uint32_t *accum, uint8_t *rgba, size_t npix, uint32_t spp, int bpp, int rgb_packed, hipStream_t st) {
+    hipLaunchKernelGGL(k_resolve, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, accum, rgba, npix, spp, bpp, rgb_packed);
 }
 void launch_cb_gather(const RenderParams &P, unsigned blocks, hipStream_t st) { hipLaunchKernelGGL(k_cb_gather, dim3(blocks), dim3(256), 0, st, P); }
 

@@ -109,6 +109,8 @@ struct RenderParams {
     int wstride_s;                  // waves per light = blockIdx.x range of k_shadow_mfma
     int whave;                      // 1: wcost_s holds the durations of the frame before (else the order is the identity)
     int wsort_blocks;               // k_setup's first work-groups sort the history: 1 + lights, or 0
+    int bpp;                        // bytes per pixel of `rgba`: 4 (R, G, B, 255) or 3 (R, G, B: RT_OPT_RGB24, the reference's PixelRGB8)
+    int rgb_packed;                 // bpp == 3 and w % 4 == 0: four pixels are stored as three whole dwords (store_rgb24)
 };
 
 struct HitRec { double px, py, pz, nx, ny, nz; };
@@ -135,7 +137,7 @@ void launch_final(const RenderParams &P, unsigned blocks, unsigned threads, hipS
 void launch_general(const RenderParams &P, unsigned runs, hipStream_t st);
 void launch_combine(const RayRec *rays, const uint32_t *col, const unsigned *count, unsigned cap, uint32_t *parent_col, unsigned blocks, hipStream_t st);
 void launch_store(const RenderParams &P, unsigned blocks, hipStream_t st);
-void launch_resolve(const uint32_t *accum, uint8_t *rgba, size_t npix, uint32_t spp, hipStream_t st);
+void launch_resolve(const uint32_t *accum, uint8_t *rgba, size_t npix, uint32_t spp, int bpp, int rgb_packed, hipStream_t st);
 void launch_cb_gather(const RenderParams &P, unsigned blocks, hipStream_t st);
 #ifdef RT_VALU_FILTER       // the cross-check build's FP32 vector-ALU kernels (rt_kernels_valu.hip)
 void launch_primary_valu(const RenderParams &P, bool shared_y, unsigned tblocks, hipStream_t st);

@@ -265,6 +265,7 @@ int lane_stream(DeviceScene &D, int lane, hipStream_t &out) {
     return RT_OK;
 }
 
+inline size_t bpp(const rt_scene *s) { return s->opt_rgb24 ? 3 : 4; }      // bytes per pixel of the colour output (RT_OPT_RGB24)
 constexpr size_t RT_SPLIT_PIXELS = 12u << 20;    // rt_render_device splits bands of this many pixels over the two lanes
 constexpr size_t RT_CHUNK_PIXELS = 16u << 20;   // rows are processed in chunks of about 16 Mi pixels
 
@@ -474,6 +475,8 @@ int render_rows(rt_scene *s, DeviceScene &D, Lane &LN, const Workspace &W, size_
     P.nlights = (int)s->lights.size(); P.nleaves = (int)s->leaves.size(); P.npoint = std::min(32, s->npoint);
     P.w = w; P.h = h;
     P.talk = s->talk ? 1 : 0;
+    P.bpp = s->opt_rgb24 ? 3 : 4;
+    P.rgb_packed = (P.bpp == 3 && w % 4 == 0) ? 1 : 0;
     P.spp = spp; P.seed_lo = (uint32_t)seed; P.seed_hi = (uint32_t)(seed >> 32);
     const bool callbacks = !s->normal_fn.empty();
 #ifdef RT_WAVE_TIMES
@@ -620,7 +623,7 @@ int render_rows(rt_scene *s, DeviceScene &D, Lane &LN, const Workspace &W, size_
         }
     }
     if (d_rgba && spp > 1) {
-        launch_resolve(W.accum, (uint8_t *)d_rgba, npix, (uint32_t)spp, st);
+        launch_resolve(W.accum, (uint8_t *)d_rgba, npix, (uint32_t)spp, P.bpp, P.rgb_packed, st);
         if (timed && (rc = next_event(LN, st, 4))) return rc;
     }
     HIP_TRY(hipGetLastError());
@@ -734,7 +737,7 @@ int render_device_impl(rt_scene *s, int w, int h, int depth, int spp, uint64_t s
         if (cs != st0) HIP_TRY(hipStreamWaitEvent(st0, (hipEvent_t)D.fork_ev, 0));
         HIP_TRY(hipStreamWaitEvent(st1, (hipEvent_t)D.fork_ev, 0));
         rc = render_band(s, t_device, w, h, depth, spp, seed, row0, top, d_rgba, d_hit_id, st0, false, nullptr, 0);
-        const int rc1 = rc ? rc : render_band(s, t_device, w, h, depth, spp, seed, row0 + top, nrows - top, d_rgba ? (uint8_t *)d_rgba + 4 * off : nullptr,
+        const int rc1 = rc ? rc : render_band(s, t_device, w, h, depth, spp, seed, row0 + top, nrows - top, d_rgba ? (uint8_t *)d_rgba + bpp(s) * off : nullptr,
                                               d_hit_id ? (int32_t *)d_hit_id + off : nullptr, st1, true, nullptr, 1);
         // always join: whatever the lanes were given is ordered before what the caller enqueues next
         bool ok = hip_ok(hipEventRecord((hipEvent_t)D.join_ev, st1), "hipEventRecord") && hip_ok(hipStreamWaitEvent(cs, (hipEvent_t)D.join_ev, 0), "hipStreamWaitEvent");
@@ -765,13 +768,13 @@ int render_impl(rt_scene *s, int w, int h, int depth, int spp, uint64_t seed, in
         hipPointerAttribute_t attr{};
         if (hipPointerGetAttributes(&attr, rgba_out) == hipSuccess && attr.type == hipMemoryTypeHost && attr.devicePointer) {
             hipPointerAttribute_t last{};
-            uint8_t *end = rgba_out + 4 * npix - 1;
-            if (hipPointerGetAttributes(&last, end) == hipSuccess && last.type == hipMemoryTypeHost && last.devicePointer == (uint8_t *)attr.devicePointer + (4 * npix - 1))
+            uint8_t *end = rgba_out + bpp(s) * npix - 1;
+            if (hipPointerGetAttributes(&last, end) == hipSuccess && last.type == hipMemoryTypeHost && last.devicePointer == (uint8_t *)attr.devicePointer + (bpp(s) * npix - 1))
                 direct = (uint8_t *)attr.devicePointer;
         } else (void)hipGetLastError();                     // (an ordinary pointer: not an error)
     }
 #endif
-    if (!direct && (rc = ensure(D.rgba, D.rgba_cap, 4 * npix))) return rc;
+    if (!direct && (rc = ensure(D.rgba, D.rgba_cap, bpp(s) * npix))) return rc;
     if ((rc = ensure(D.hit_out, D.hit_out_cap, npix))) return rc;
     hipStream_t lst[RT_LANES], cst = (hipStream_t)D.copy_stream, hst = (hipStream_t)D.copy_stream2;
     for (int k = 0; k < RT_LANES; ++k) if ((rc = lane_stream(D, k, lst[k]))) return rc;
@@ -799,7 +802,7 @@ int render_impl(rt_scene *s, int w, int h, int depth, int spp, uint64_t seed, in
         const int r = bstart[used], rows = bstart[used + 1] - r;
         const size_t off = (size_t)r * (size_t)w;
         const int lane = used % RT_LANES;
-        rc = render_band(s, t_device, w, h, depth, spp, seed, row0 + r, rows, rgba_out ? (direct ? direct : D.rgba) + 4 * off : nullptr,
+        rc = render_band(s, t_device, w, h, depth, spp, seed, row0 + r, rows, rgba_out ? (direct ? direct : D.rgba) + bpp(s) * off : nullptr,
                          D.hit_out + off, lst[lane], r > 0, hit_id_out ? (hipEvent_t)D.hits_done[used] : nullptr, lane);
         if (rc == RT_OK && !hip_ok(hipEventRecord((hipEvent_t)D.band_done[used], lst[lane]), "hipEventRecord")) rc = RT_ERR_HIP;
     }
@@ -812,7 +815,7 @@ int render_impl(rt_scene *s, int w, int h, int depth, int spp, uint64_t seed, in
         }
         if (rgba_out && !direct) {
             if (!hip_ok(hipStreamWaitEvent(cst, (hipEvent_t)D.band_done[band], 0), "hipStreamWaitEvent")) { rc = RT_ERR_HIP; break; }
-            if (!hip_ok(hipMemcpyAsync(rgba_out + 4 * off, D.rgba + 4 * off, 4 * n, hipMemcpyDeviceToHost, cst), "hipMemcpyAsync")) rc = RT_ERR_HIP;
+            if (!hip_ok(hipMemcpyAsync(rgba_out + bpp(s) * off, D.rgba + bpp(s) * off, bpp(s) * n, hipMemcpyDeviceToHost, cst), "hipMemcpyAsync")) rc = RT_ERR_HIP;
         }
     }
     // always drain both streams, also after an error: nothing may still be writing the caller's buffers on return
@@ -1033,7 +1036,7 @@ int render_multi_impl(rt_scene *s, int w, int h, int depth, int spp, uint64_t se
         split_rows(s->multi_cost.data(), ncost, h, ngpus, RT_TILE_H, b0, bn, weight);
     }
     // 2. buffers: the whole frame on the home device, a staging buffer per other device
-    if (rgba_out && (rc = ensure(H.rgba, H.rgba_cap, 4 * npix))) return finish(rc);
+    if (rgba_out && (rc = ensure(H.rgba, H.rgba_cap, bpp(s) * npix))) return finish(rc);
     if ((rc = ensure(H.hit_out, H.hit_out_cap, npix))) return finish(rc);
     size_t stage_pix[RT_MAX_DEVICES] = {0};
     for (int k = 0; k < ngpus; ++k) {
@@ -1051,7 +1054,7 @@ int render_multi_impl(rt_scene *s, int w, int h, int depth, int spp, uint64_t se
         DeviceScene &D = s->dev[d];
         if ((rc = device_prepare(*s, D, d, w, h))) return finish(rc);
         if ((rc = copy_tools(D))) return finish(rc);
-        if (rgba_out && (rc = ensure(D.stage_rgba, D.stage_rgba_cap, 4 * stage_pix[d]))) return finish(rc);
+        if (rgba_out && (rc = ensure(D.stage_rgba, D.stage_rgba_cap, bpp(s) * stage_pix[d]))) return finish(rc);
         if ((rc = ensure(D.stage_hit, D.stage_hit_cap, stage_pix[d]))) return finish(rc);
         if (d != home) {                  // direct xGMI copies into the home device's memory
             const hipError_t e = hipDeviceEnablePeerAccess(home, 0);
@@ -1079,7 +1082,7 @@ int render_multi_impl(rt_scene *s, int w, int h, int depth, int spp, uint64_t se
                 if (B.dev != dev || B.pn[p] <= 0) continue;
                 const size_t foff = (size_t)B.p0[p] * (size_t)w, n = (size_t)B.pn[p] * (size_t)w;
                 const size_t soff = B.stage_off + (size_t)(B.p0[p] - B.row0) * (size_t)w;
-                uint8_t *dst = !rgba_out ? nullptr : (B.staged ? D.stage_rgba + 4 * soff : H.rgba + 4 * foff);
+                uint8_t *dst = !rgba_out ? nullptr : (B.staged ? D.stage_rgba + bpp(s) * soff : H.rgba + bpp(s) * foff);
                 int32_t *dhit = B.staged ? D.stage_hit + soff : H.hit_out + foff;
                 // consecutive pieces alternate between the device's two lanes: the next piece's kernels fill the tails of this one's
                 const int lane = npiece++ % RT_LANES;
@@ -1093,7 +1096,7 @@ int render_multi_impl(rt_scene *s, int w, int h, int depth, int spp, uint64_t se
                 if (ok && B.staged) {
                     hipStream_t cs = (hipStream_t)D.copy_stream;
                     ok = hip_ok(hipStreamWaitEvent(cs, er, 0), "hipStreamWaitEvent") &&
-                         (!rgba_out || hip_ok(hipMemcpyPeerAsync(H.rgba + 4 * foff, home, dst, dev, 4 * n, cs), "hipMemcpyPeerAsync")) &&
+                         (!rgba_out || hip_ok(hipMemcpyPeerAsync(H.rgba + bpp(s) * foff, home, dst, dev, bpp(s) * n, cs), "hipMemcpyPeerAsync")) &&
                          hip_ok(hipMemcpyPeerAsync(H.hit_out + foff, home, dhit, dev, n * sizeof(int32_t), cs), "hipMemcpyPeerAsync") &&
                          hip_ok(hipEventRecord(ea, cs), "hipEventRecord");
                 }
@@ -1126,7 +1129,7 @@ int render_multi_impl(rt_scene *s, int w, int h, int depth, int spp, uint64_t se
             hipEvent_t arrived = ev[((size_t)k * PIECES + p) * 2 + (B.staged ? 1 : 0)];
             hipStream_t cs = (hipStream_t)H.copy_stream2;
             if (!hip_ok(hipStreamWaitEvent(cs, arrived, 0), "hipStreamWaitEvent")) return finish(RT_ERR_HIP);
-            if (rgba_out && !hip_ok(hipMemcpyAsync(rgba_out + 4 * foff, H.rgba + 4 * foff, 4 * n, hipMemcpyDeviceToHost, cs), "hipMemcpyAsync")) return finish(RT_ERR_HIP);
+            if (rgba_out && !hip_ok(hipMemcpyAsync(rgba_out + bpp(s) * foff, H.rgba + bpp(s) * foff, bpp(s) * n, hipMemcpyDeviceToHost, cs), "hipMemcpyAsync")) return finish(RT_ERR_HIP);
             if (hit_id_out && !hip_ok(hipMemcpyAsync(hit_id_out + foff, H.hit_out + foff, n * sizeof(int32_t), hipMemcpyDeviceToHost, cs), "hipMemcpyAsync")) return finish(RT_ERR_HIP);
         }
     if (!hip_ok(hipStreamSynchronize((hipStream_t)H.copy_stream2), "hipStreamSynchronize")) return finish(RT_ERR_HIP);
@@ -1205,7 +1208,7 @@ int render_device_noalloc_impl(rt_scene *s, int w, int h, int depth, int spp, ui
         const int rows = nrows - r < rows_fit ? nrows - r : rows_fit;
         const size_t off = (size_t)r * (size_t)w;
         if ((rc = render_rows(s, D, D.lane[0], W, (size_t)rows, w, h, depth, spp, seed, row0 + r, rows,
-                              d_rgba ? (uint8_t *)d_rgba + 4 * off : nullptr, d_hit_id ? (int32_t *)d_hit_id + off : nullptr,
+                              d_rgba ? (uint8_t *)d_rgba + bpp(s) * off : nullptr, d_hit_id ? (int32_t *)d_hit_id + off : nullptr,
                               st, r > 0, false))) return rc;
     }
     if (nrows == 0) { D.last_primary = 0; for (Lane &l : D.lane) { l.used = false; l.ev_used = 0; } D.stats_pending = false; }

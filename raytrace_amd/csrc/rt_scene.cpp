@@ -1100,6 +1100,7 @@ int rt_scene_set_option(rt_scene *s, int option, int value) {
         s->opt_lane = value; return RT_OK;
     case RT_OPT_CONTINUE: s->opt_continue = value != 0; return RT_OK;
     case RT_OPT_HISTORY: s->opt_history = value != 0; return RT_OK;
+    case RT_OPT_RGB24: s->opt_rgb24 = value != 0; return RT_OK;
     }
     set_error("rt_scene_set_option: unknown option");
     return RT_ERR_ARG;

@@ -154,6 +154,7 @@ struct rt_scene {
     int opt_host_bands = 0;               // copy bands of rt_render (0: 2, one per 8 Mi pixels beyond 24 Mi)
     int opt_multi_stage = 0;              // rt_render_multi: also the home device's bands go through a staging buffer + peer copy
     bool opt_continue = false;            // rt_render_device calls add to the statistics of the frame in progress
+    bool opt_rgb24 = false;               // RT_OPT_RGB24: colour outputs are 3 bytes per pixel
     bool opt_history = true;              // RT_OPT_HISTORY: waves of a band rendered before are dispatched longest first
     int opt_lane = -1;                    // -1: rt_render_device splits big bands over both lanes itself; 0, 1: the lane its calls use
     // arbitrary `fnorm` closures (Main.hs:956-965): per callback group, the caller's function

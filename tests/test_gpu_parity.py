@@ -624,6 +624,56 @@ def test_pieces_on_alternating_lanes(gpu_lib):
     sc.close()
 
 
+def test_rgb24_outputs(gpu_lib):
+    """RT_OPT_RGB24: the colour outputs are 3 bytes per pixel (the reference's PixelRGB8).  Same colours as the RGBA8
+    frame through every way out: rt_render into pageable and page-locked memory with several bands, a band of rows,
+    rt_render_device (also the no-alloc entry point and the split over two lanes), 4 samples per pixel, a reflective
+    scene (bounce levels), rt_render_multi — for a width that is a multiple of 4 (four pixels = three dwords) and for
+    widths that are not (byte stores)."""
+    from raytrace_amd import _lib
+    from hip_buffers import DeviceBuffer
+    for (world, lights), depth in ((scenes.synthetic(ntri=600, ncuboid=60), 4), (scenes.mirror_room(), 4)):
+        for w, h in ((1000, 203), (1001, 67), (998, 40)):
+            sc = api.Scene(world, lights)
+            ref, ref_hit = sc.render(w, h, depth=depth)
+            ref4, _ = sc.render(w, h, depth=depth, spp=4, seed=5)
+            sc.set_option(_lib.RT_OPT_RGB24, 1)
+            for bands in (1, 2, 3):
+                sc.set_option(_lib.RT_OPT_HOST_BANDS, bands)
+                rgb, hit = sc.render(w, h, depth=depth)
+                assert rgb.shape == (h, w, 3) and (rgb == ref[:, :, :3]).all() and (hit == ref_hit).all(), (w, h, bands)
+                pin = api.host_buffer((h, w, 3), np.uint8)
+                pin[:] = 0x5a
+                sc.render(w, h, depth=depth, out_rgba=pin, want_hit=False)
+                assert (pin == ref[:, :, :3]).all(), (w, h, bands)
+            rgb, _ = sc.render(w, h, depth=depth, row0=16, nrows=19)
+            assert (rgb == ref[16:35, :, :3]).all()
+            rgb, _ = sc.render(w, h, depth=depth, spp=4, seed=5)
+            assert (rgb == ref4[:, :, :3]).all()
+            dev = DeviceBuffer((h + 1, w, 3), np.uint8, fill=0x5a)           # (one row of slack: nothing may be written behind the frame)
+            sc.render_device(w, h, dev.ptr, None, depth=depth)
+            got = dev.numpy()
+            assert (got[:h] == ref[:, :, :3]).all() and (got[h] == 0x5a).all()
+            sc.prepare(w, h)
+            dev2 = DeviceBuffer((h + 1, w, 3), np.uint8, fill=0x5a)
+            sc.render_device_noalloc(w, h, dev2.ptr, None, depth=depth)
+            got = dev2.numpy()
+            assert (got[:h] == ref[:, :, :3]).all() and (got[h] == 0x5a).all()
+            rgb, hit = sc.render_multi(w, h, [0, 0, 0], depth=depth)
+            assert rgb.shape == (h, w, 3) and (rgb == ref[:, :, :3]).all() and (hit == ref_hit).all()
+            sc.close()
+    # a band big enough for rt_render_device to split it over the two lanes
+    world, lights = scenes.synthetic(ntri=600, ncuboid=60)
+    sc = api.Scene(world, lights)
+    w, h = 4096, 3200
+    ref, _ = sc.render(w, h)
+    sc.set_option(_lib.RT_OPT_RGB24, 1)
+    dev = DeviceBuffer((h, w, 3), np.uint8, fill=0x5a)
+    sc.render_device(w, h, dev.ptr, None)
+    assert (dev.numpy() == ref[:, :, :3]).all()
+    sc.close()
+
+
 def test_wave_history_changes_nothing_but_the_order(gpu_lib):
     """RT_OPT_HISTORY (on by default): from the second render of a band on, the waves of the two big kernels are dispatched
     longest first, by the durations they left behind.  The bytes of frames 2, 3, 4 equal those of frame 1 (no history yet) and

@@ -246,6 +246,8 @@ def test_scene_options_and_the_cross_check_build():
     with pytest.raises(RuntimeError, match=">= 0"):
         sc.set_option(_lib.RT_OPT_HOST_BANDS, -1)
     sc.set_option(_lib.RT_OPT_LANE, 1).set_option(_lib.RT_OPT_LANE, 0).set_option(_lib.RT_OPT_LANE, -1)
+    sc.set_option(_lib.RT_OPT_CONTINUE, 1).set_option(_lib.RT_OPT_CONTINUE, 0).set_option(_lib.RT_OPT_HISTORY, 0).set_option(_lib.RT_OPT_HISTORY, 1)
+    assert sc.bytes_per_pixel == 4 and sc.set_option(_lib.RT_OPT_RGB24, 1).bytes_per_pixel == 3 and sc.set_option(_lib.RT_OPT_RGB24, 0).bytes_per_pixel == 4
     with pytest.raises(RuntimeError, match="RT_OPT_LANE"):
         sc.set_option(_lib.RT_OPT_LANE, 2)
     sc.close()
