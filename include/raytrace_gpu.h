@@ -107,7 +107,7 @@ int  rt_scene_set_dialect(rt_scene *, int dialect);
  *                      256 rays; 0: every wave scans every block (the plain all-pairs scan).  Same pixels either way.
  *   RT_OPT_FILTER      0 (default): first stage on the matrix cores; 1: the FP32 vector-ALU kernels, which exist only
  *                      in the cross-check build libraytrace_gpu_valu.so (RT_ERR_UNSUPPORTED in the product library).
- *   RT_OPT_HOST_BANDS  bands of rt_render, 1..8 (0 = default: 2, one per 8 Mi pixels beyond 24 Mi).  Consecutive bands run on
+ *   RT_OPT_HOST_BANDS  bands of rt_render, 1..8 (0 = default: 2 or 3, one per 8 Mi pixels beyond 24 Mi).  Consecutive bands run on
  *                      the scene's two lanes, so band k + 1's kernels fill the tails of band k's; a band's hit IDs
  *                      travel to the host as soon as its nearest-hit kernel has ended, its colours beside the next band.
  *   RT_OPT_MULTI_STAGE 1: rt_render_multi sends the bands of devices[0] through a staging buffer and a peer copy too,

@@ -759,12 +759,15 @@ int render_impl(rt_scene *s, int w, int h, int depth, int spp, uint64_t seed, in
     if (npix == 0) return RT_OK;
     if ((rc = device_prepare(*s, D, t_device, w, h))) return rc;
     if ((rc = copy_tools(D))) return rc;
-    // Colours into page-locked memory that this device can address (rt_host_alloc): k_final stores its coalesced 256-byte
-    // lines straight through PCIe into the caller's buffer, so no copy of the colours is left exposed behind the last
-    // kernel (33 MB at 4K: 0.6 ms).  Hit IDs still go through device memory: the shading kernels read them back.
+    // Colours AND hit IDs into page-locked memory that this device can address (rt_host_alloc): k_final stores its
+    // coalesced lines straight through PCIe into the caller's buffer, so no copy of the colours is left behind the last
+    // kernel while the copy engine is busy with the hit IDs (33 + 33 MB at 4K; hit IDs always go through device memory:
+    // the shading kernels read them back).  Colours alone: a copy per band on the copy engine, which then has the link to
+    // itself and runs beside the next band's kernels, is faster (4K frame, tools/host_render_timing.py: 1.70 against 1.82
+    // ms; 3 bytes per pixel 1.63 against 1.71) — k_final's waves wait on the link and hold their slots while they do.
     uint8_t *direct = nullptr;
 #ifndef RT_NO_DIRECT_RGBA
-    if (rgba_out) {
+    if (rgba_out && hit_id_out) {
         hipPointerAttribute_t attr{};
         if (hipPointerGetAttributes(&attr, rgba_out) == hipSuccess && attr.type == hipMemoryTypeHost && attr.devicePointer) {
             hipPointerAttribute_t last{};
@@ -782,11 +785,13 @@ int render_impl(rt_scene *s, int w, int h, int depth, int spp, uint64_t seed, in
     // kernels run beside band k's, filling the tails of its kernels, and band k's colours travel while band k + 1 still
     // computes — as k_final's own stores over PCIe when the destination is page-locked memory this device can address, as a
     // copy on a stream of its own otherwise.  The hit IDs of a band are copied as soon as its nearest-hit kernel has ended
-    // (the shading kernels only read them).  Default: 2 bands (one per lane) up to 24 Mi pixels, one per 8 Mi
-    // pixels beyond; measured on the 4K benchmark frame into page-locked memory (tools/host_render_timing.py): 1 band
-    // 1.93 ms, 2 bands 1.86, 3 bands 1.99, 4 bands 2.03 — the bands are short enough for launch gaps to show.  Into pageable memory the copies stage through the runtime's
+    // (the shading kernels only read them).  Default: 2 bands (one per lane) when k_final stores the colours itself, 3
+    // when the copy engine carries them (bands 1 and 2 run side by side and travel beside band 3), up to 24 Mi pixels; one
+    // per 8 Mi pixels beyond.  Measured on the 4K benchmark frame into page-locked memory (tools/host_render_timing.py,
+    // colours + hit IDs): 1 band 1.85 ms, 2 bands 1.80, 3 bands 1.99, 4 bands 2.03 — the bands are short enough for launch
+    // gaps to show; on ONE lane a band costs 0.15 - 0.27 ms.  Into pageable memory the copies stage through the runtime's
     // bounce buffers and block this thread, which is why every band is enqueued first.
-    int nb = s->opt_host_bands > 0 ? s->opt_host_bands : std::max(2, (int)(npix >> 23));
+    int nb = s->opt_host_bands > 0 ? s->opt_host_bands : std::max(direct || !rgba_out ? 2 : 3, (int)(npix >> 23));
     nb = nb < 1 ? 1 : (nb > RT_HOST_BANDS_MAX ? RT_HOST_BANDS_MAX : nb);
     if (nrows < 2 * RT_TILE_H) nb = 1;
     int bstart[RT_HOST_BANDS_MAX + 1];                   // band k = rows [bstart[k], bstart[k + 1]) of the call's rows
