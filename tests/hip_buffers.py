@@ -27,6 +27,15 @@ def hip():
         H.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
         H.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
         H.hipDeviceSynchronize.argtypes = []
+        H.hipStreamCreateWithFlags.argtypes = [C.POINTER(C.c_void_p), C.c_uint]
+        H.hipStreamDestroy.argtypes = [C.c_void_p]
+        H.hipStreamSynchronize.argtypes = [C.c_void_p]
+        H.hipStreamBeginCapture.argtypes = [C.c_void_p, C.c_int]
+        H.hipStreamEndCapture.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        H.hipGraphInstantiate.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        H.hipGraphLaunch.argtypes = [C.c_void_p, C.c_void_p]
+        H.hipGraphExecDestroy.argtypes = [C.c_void_p]
+        H.hipGraphDestroy.argtypes = [C.c_void_p]
         _hip = H
     return _hip
 

@@ -4,7 +4,9 @@ shared scratch (a band that needs several sub-bands, supersampling, a mirror sce
 import numpy as np
 import pytest
 
-from hip_buffers import DeviceBuffer
+import ctypes as C
+
+from hip_buffers import DeviceBuffer, hip
 from raytrace_amd import api, scenes
 
 pytestmark = pytest.mark.gpu
@@ -69,4 +71,37 @@ def test_noalloc_entry_point_matches_render_device(gpu_lib):
     sc.prepare(64, 64)
     with pytest.raises(RuntimeError, match="callbacks"):
         sc.render_device_noalloc(64, 64, rgba.ptr, None)
+    sc.close()
+
+
+def test_noalloc_call_is_capturable_into_a_hip_graph(gpu_lib):
+    """Under HIP stream capture (global mode: any allocating or synchronising call fails) the call is recorded into a graph;
+    the graph is launched twice and the frame equals rt_render_device's."""
+    H = hip()
+    world, lights = scenes.synthetic(ntri=600, ncuboid=60)
+    sc = api.Scene(world, lights)
+    w, h = 1000, 531
+    sc.prepare(w, h)
+    ref_rgba, ref_hit = DeviceBuffer((h, w, 4), np.uint8), DeviceBuffer((h, w), np.int32)
+    sc.render_device(w, h, ref_rgba.ptr, ref_hit.ptr)
+    ref = (ref_rgba.numpy(), ref_hit.numpy())
+    rgba, hit = DeviceBuffer((h, w, 4), np.uint8, fill=0x5a), DeviceBuffer((h, w), np.int32, fill=0x5a)
+    stream, graph, gexec = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    assert H.hipStreamCreateWithFlags(C.byref(stream), 1) == 0                    # hipStreamNonBlocking
+    assert H.hipStreamBeginCapture(stream, 0) == 0                                # hipStreamCaptureModeGlobal: any forbidden call fails
+    try:
+        sc.render_device_noalloc(w, h, rgba.ptr, hit.ptr, stream=stream.value)
+    finally:
+        rc = H.hipStreamEndCapture(stream, C.byref(graph))
+    assert rc == 0 and graph.value
+    # nothing has run yet: the buffers still hold their fill
+    assert H.hipDeviceSynchronize() == 0
+    assert (hit.numpy() == 0x5a5a5a5a).all()
+    assert H.hipGraphInstantiate(C.byref(gexec), graph, None, None, 0) == 0
+    for _ in range(2):
+        assert H.hipGraphLaunch(gexec, stream) == 0
+        assert H.hipStreamSynchronize(stream) == 0
+        assert (rgba.numpy() == ref[0]).all() and (hit.numpy() == ref[1]).all()
+        assert H.hipMemset(C.c_void_p(hit.ptr), 0x5a, hit.nbytes) == 0 and H.hipDeviceSynchronize() == 0
+    assert H.hipGraphExecDestroy(gexec) == 0 and H.hipGraphDestroy(graph) == 0 and H.hipStreamDestroy(stream) == 0
     sc.close()
