@@ -257,6 +257,7 @@ foreign import ccall unsafe "rt_set_normal_callback" c_set_normal_callback :: Sc
 foreign import ccall "wrapper"                   mkNormalFn        :: NormalFn -> IO (FunPtr NormalFn)
 foreign import ccall unsafe "rt_add_point_light" c_add_point_light :: ScenePtr -> CDouble -> CDouble -> Ptr CDouble -> IO CInt
 foreign import ccall unsafe "rt_add_ambient"     c_add_ambient     :: ScenePtr -> CDouble -> IO CInt
+foreign import ccall unsafe "rt_scene_set_option" c_scene_set_option :: ScenePtr -> CInt -> CInt -> IO CInt
 foreign import ccall unsafe "rt_host_alloc"      c_host_alloc      :: CSize -> IO (Ptr Word8)
 foreign import ccall        "&rt_host_free"      p_host_free       :: FunPtr (Ptr Word8 -> IO ())
 -- long calls that may call back into Haskell (fnorm): `safe`, so other Haskell threads keep running and the callback may enter
@@ -351,14 +352,16 @@ hostBuffer bytes = do
 -- one-process-per-GPU job renders.
 renderBand :: Int -> Int -> Int -> Light -> Shape -> Int -> Int -> IO (ForeignPtr Word8)
 renderBand w h depth lights world row0 nrows = withScene lights world $ \s -> do
-  buf <- hostBuffer (w * nrows * 4)
+  -- RT_OPT_RGB24 (= 7): 3 bytes per pixel, the PixelRGB8 generateImage wants; a quarter less over PCIe than RGBA8
+  void $ c_scene_set_option s 7 1 >>= check "rt_scene_set_option"
+  buf <- hostBuffer (w * nrows * 3)
   withForeignPtr buf $ \p ->
     void $ c_render s (fromIntegral w) (fromIntegral h) (fromIntegral depth) 1 0 (fromIntegral row0) (fromIntegral nrows) p nullPtr >>= check "rt_render"
   return buf
 
 pixelAt :: ForeignPtr Word8 -> Int -> Int -> Int -> PixelRGB8
 pixelAt buf w x y = unsafePerformIO $ withForeignPtr buf $ \p ->
-  PixelRGB8 <$> peekByteOff p (4*(y*w+x)) <*> peekByteOff p (4*(y*w+x)+1) <*> peekByteOff p (4*(y*w+x)+2)
+  PixelRGB8 <$> peekByteOff p (3*(y*w+x)) <*> peekByteOff p (3*(y*w+x)+1) <*> peekByteOff p (3*(y*w+x)+2)
 
 -- | Main.hs:623-637.  `parallelTrace w h camera (trace n lights world)` renders the frame once, on the GPU, when the
 -- first pixel is demanded (the reference forces its Repa array at that moment), and serves every (x, y) from it.
@@ -373,7 +376,8 @@ parallelTrace w h _camera (MkTracer depth lights world) =
 parallelTraceMulti :: [Int] -> Int -> Int -> Camera -> Tracer -> Int -> Int -> PixelRGB8
 parallelTraceMulti devices w h _camera (MkTracer depth lights world) =
   let frame = unsafePerformIO $ withScene lights world $ \s -> do
-        buf <- hostBuffer (w * h * 4)
+        void $ c_scene_set_option s 7 1 >>= check "rt_scene_set_option"      -- RT_OPT_RGB24
+        buf <- hostBuffer (w * h * 3)
         withForeignPtr buf $ \p -> withArray (map fromIntegral devices) $ \pd ->
           void $ c_render_multi s (fromIntegral w) (fromIntegral h) (fromIntegral depth) 1 0 (fromIntegral (length devices)) pd p nullPtr >>= check "rt_render_multi"
         return buf
