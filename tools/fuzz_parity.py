@@ -182,6 +182,12 @@ def main():
         if mode == "valu":
             sc.set_option(_lib.RT_OPT_FILTER, 1)
         rgba, hit = sc.render(w, h, depth=depth, spp=spp, seed=i, row0=row0, nrows=nrows)
+        # ... again: the second render of a band dispatches its waves by the first one's durations (RT_OPT_HISTORY), and every
+        # other scene also as 3 bytes per pixel (RT_OPT_RGB24); both must give the same bytes
+        if i & 1:
+            sc.set_option(_lib.RT_OPT_RGB24, 1)
+        rgba2, hit2 = sc.render(w, h, depth=depth, spp=spp, seed=i, row0=row0, nrows=nrows)
+        again_ok = bool((rgba2[:, :, :3] == rgba[:, :, :3]).all() and (hit2 == hit).all())
         leaves = sc.num_leaves
         sc.close()
         d_id = hit != ref["hit_id"]
@@ -189,8 +195,9 @@ def main():
             d_id &= (ref["flags"] & ob.FLAG_TIE) == 0
         n_id = int(d_id.sum())
         n_rgb = int((rgba[:, :, :3] != ref["rgb"]).any(axis=2).sum())
-        print(f"scene {i}: {leaves} leaves, {len(lights)} lights, {w}x{h} depth {depth} spp {spp}: hit-ID mismatches {n_id}, colour mismatches {n_rgb}", flush=True)
-        if n_id or n_rgb:
+        print(f"scene {i}: {leaves} leaves, {len(lights)} lights, {w}x{h} depth {depth} spp {spp}: hit-ID mismatches {n_id}, colour mismatches {n_rgb}"
+              f"{'' if again_ok else '; SECOND RENDER DIFFERS'}", flush=True)
+        if n_id or n_rgb or not again_ok:
             bad += 1
     print(f"FUZZ: {n} scenes (seed {seed}{'' if mode == 'main' else ', ' + mode}), {bad} with a mismatch")
     sys.exit(1 if bad else 0)
