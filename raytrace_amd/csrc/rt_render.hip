@@ -476,7 +476,7 @@ int render_rows(rt_scene *s, DeviceScene &D, Lane &LN, const Workspace &W, size_
     P.w = w; P.h = h;
     P.talk = s->talk ? 1 : 0;
     P.bpp = s->opt_rgb24 ? 3 : 4;
-    P.rgb_packed = (P.bpp == 3 && w % 4 == 0) ? 1 : 0;
+    P.rgb_packed = (P.bpp == 3 && w % 4 == 0 && (reinterpret_cast<uintptr_t>(d_rgba) & 3u) == 0) ? 1 : 0;   // (whole dwords need an aligned buffer)
     P.spp = spp; P.seed_lo = (uint32_t)seed; P.seed_hi = (uint32_t)(seed >> 32);
     const bool callbacks = !s->normal_fn.empty();
 #ifdef RT_WAVE_TIMES
@@ -512,7 +512,6 @@ int render_rows(rt_scene *s, DeviceScene &D, Lane &LN, const Workspace &W, size_
             HIP_TRY(hipMemsetAsync(H.buf, 0, chunks * 2 * words * sizeof(uint32_t), st));
             H.words = words;
         }
-        H.last_use = ++LN.history_clock;
         hist = &H;
     }
 #endif

@@ -54,11 +54,10 @@ struct WaveHistory {
     void *buf = nullptr;             // ONE allocation: chunks x 2 x words
     size_t words = 0;                // per chunk and per array (cost, order): tiles + lights x shadow waves
     bool ready = false;              // a whole frame has been enqueued with it: its orders are permutations
-    uint64_t last_use = 0;
 };
 struct Lane {
     std::map<std::array<uint64_t, 6>, WaveHistory> history;   // by (w, h, row0, nrows, chunk rows, lights); dropped when the scene changes
-    uint64_t history_version = 0, history_clock = 0;
+    uint64_t history_version = 0;        // rt_scene::version the histories belong to
     Workspace ws;                    // views of ws_arena (ws_grow)
     DevBuf ws_arena;                 // ONE allocation
     const unsigned long long *last_counters = nullptr;     // where the counters of this lane's part of the last frame live

@@ -654,6 +654,10 @@ def test_rgb24_outputs(gpu_lib):
             sc.render_device(w, h, dev.ptr, None, depth=depth)
             got = dev.numpy()
             assert (got[:h] == ref[:, :, :3]).all() and (got[h] == 0x5a).all()
+            odd = DeviceBuffer((3 * w * h + 8,), np.uint8, fill=0x5a)         # a buffer that does not start on a dword: byte stores
+            sc.render_device(w, h, odd.ptr + 1, None, depth=depth)
+            got = odd.numpy()
+            assert got[0] == 0x5a and (got[1:1 + 3 * w * h].reshape(h, w, 3) == ref[:, :, :3]).all() and (got[1 + 3 * w * h:] == 0x5a).all()
             sc.prepare(w, h)
             dev2 = DeviceBuffer((h + 1, w, 3), np.uint8, fill=0x5a)
             sc.render_device_noalloc(w, h, dev2.ptr, None, depth=depth)
