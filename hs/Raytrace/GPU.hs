@@ -20,8 +20,9 @@
 --
 -- What differs from the reference, and why:
 --   * `Shape` is a tree of constructor calls (the closure tree as data); `intersect`/`boundingBox` are gone.
---   * `Light` is a list of sources; `pointLight world ...` keeps its first argument (Main.hs:467) but ignores it: shadow
---     rays are cast against the world that is traced, which is what every scene of the reference passes anyway.
+--   * `Light` is a list of sources; `pointLight world ...` keeps its first argument (Main.hs:467): when it is the value
+--     that is traced (every scene of the reference) shadow rays meet the traced world, any other Shape is handed to the
+--     library as a shadow world of that light.
 --   * `trace n lights world` is data (`Tracer`), not a function of a ray; `Camera` is data.
 --   * `parallelTrace` renders the whole frame on the GPU the first time a pixel is asked for (Main.hs:629-635 does the
 --     same with `computeP`), then serves lookups from the frame.
@@ -44,7 +45,7 @@ module Raytrace.GPU
 
 import Codec.Picture (PixelRGB8 (..))
 import Control.Exception (bracket)
-import Control.Monad (forM_, void, when)
+import Control.Monad (forM, forM_, void, when)
 import Data.Int (Int32)
 import Data.IORef
 import Data.Word (Word64, Word8)
@@ -52,6 +53,7 @@ import Foreign
 import Foreign.C.String (CString, peekCString)
 import Foreign.C.Types
 import System.IO.Unsafe (unsafePerformIO)
+import System.Mem.StableName (makeStableName)
 
 -------------------------------------------------------------------------------
 -- Vector3D — Main.hs:20-86, verbatim semantics
@@ -173,17 +175,18 @@ cylinder = Cyl
 -------------------------------------------------------------------------------
 -- Lights — Main.hs:418-492
 
-data LightSrc = Point Double Double Vector3D | Ambient Double
+data LightSrc = Point Shape Double Double Vector3D | Ambient Double   -- a point light closes over the world its shadow rays meet
 newtype Light = MkLight [LightSrc]
 instance Semigroup Light where
   MkLight a <> MkLight b = MkLight (a ++ b)
 instance Monoid Light where
   mempty = MkLight []
 
--- | Main.hs:467.  The first argument (the world the shadow rays are cast against) is kept for source compatibility and
--- ignored: the library casts them against the world that is traced.
+-- | Main.hs:467.  The first argument is the world the light's shadow rays are cast against.  When it is the very value
+-- that is traced (every scene of the reference), the library tests them against the traced world; any other Shape is
+-- handed over as a shadow world of its own (rt_begin_shadow_world ... rt_add_point_light_world).
 pointLight :: Shape -> Double -> Double -> Vector3D -> Light
-pointLight _world kd ks lpos = MkLight [Point kd ks lpos]
+pointLight world kd ks lpos = MkLight [Point world kd ks lpos]
 ambient :: Double -> Light                                          -- Main.hs:490
 ambient f = MkLight [Ambient f]
 
@@ -257,6 +260,9 @@ foreign import ccall unsafe "rt_set_normal_callback" c_set_normal_callback :: Sc
 foreign import ccall "wrapper"                   mkNormalFn        :: NormalFn -> IO (FunPtr NormalFn)
 foreign import ccall unsafe "rt_add_point_light" c_add_point_light :: ScenePtr -> CDouble -> CDouble -> Ptr CDouble -> IO CInt
 foreign import ccall unsafe "rt_add_ambient"     c_add_ambient     :: ScenePtr -> CDouble -> IO CInt
+foreign import ccall unsafe "rt_begin_shadow_world" c_begin_shadow_world :: ScenePtr -> IO CInt
+foreign import ccall unsafe "rt_end_shadow_world"   c_end_shadow_world   :: ScenePtr -> IO CInt
+foreign import ccall unsafe "rt_add_point_light_world" c_add_point_light_world :: ScenePtr -> CInt -> CDouble -> CDouble -> Ptr CDouble -> IO CInt
 foreign import ccall unsafe "rt_scene_set_option" c_scene_set_option :: ScenePtr -> CInt -> CInt -> IO CInt
 foreign import ccall unsafe "rt_host_alloc"      c_host_alloc      :: CSize -> IO (Ptr Word8)
 foreign import ccall        "&rt_host_free"      p_host_free       :: FunPtr (Ptr Word8 -> IO ())
@@ -327,9 +333,32 @@ emit keep s shape = case shape of
     withArray (map realToFrac [scaleInv, ox, oy, oz]) $ \pp ->
       void $ c_set_normal_callback s first (n - first) pp fp nullPtr >>= check "rt_set_normal_callback"
 
-emitLight :: ScenePtr -> LightSrc -> IO ()
-emitLight s (Point kd ks p) = withV3 p $ \pp -> void $ c_add_point_light s (realToFrac kd) (realToFrac ks) pp >>= check "rt_add_point_light"
-emitLight s (Ambient f)     = void $ c_add_ambient s (realToFrac f) >>= check "rt_add_ambient"
+-- The lights.  "The same world" is decided by identity of the heap object (StableName), which is what `pointLight world`
+-- with the `world` that is then traced gives; a Shape that merely looks the same becomes a shadow world (same picture,
+-- twice the leaves).  Shadow worlds are emitted once per distinct Shape, after the traced world, before the lights.
+emitLights :: IORef [FunPtr NormalFn] -> ScenePtr -> Shape -> [LightSrc] -> IO ()
+emitLights keep s world ls = do
+  traced <- makeStableName $! world                       -- ($!: an unevaluated thunk and its value may get different names)
+  known  <- newIORef []                                   -- [(StableName Shape, world number)]
+  worlds <- forM ls $ \l -> case l of
+    Ambient _ -> return 0
+    Point lw _ _ _ -> do
+      sn <- makeStableName $! lw
+      if sn == traced then return 0 else do
+        seen <- readIORef known
+        case lookup sn seen of
+          Just k  -> return k
+          Nothing -> do
+            k <- c_begin_shadow_world s >>= check "rt_begin_shadow_world"
+            emit keep s lw
+            void $ c_end_shadow_world s >>= check "rt_end_shadow_world"
+            modifyIORef known ((sn, k) :)
+            return k
+  forM_ (zip ls worlds) $ \(l, k) -> case l of
+    Ambient f -> void $ c_add_ambient s (realToFrac f) >>= check "rt_add_ambient"
+    Point _ kd ks p -> withV3 p $ \pp -> void $
+      (if k == 0 then c_add_point_light s (realToFrac kd) (realToFrac ks) pp
+                 else c_add_point_light_world s k (realToFrac kd) (realToFrac ks) pp) >>= check "rt_add_point_light"
 
 withScene :: Light -> Shape -> (ScenePtr -> IO a) -> IO a
 withScene (MkLight ls) world act = do
@@ -337,7 +366,7 @@ withScene (MkLight ls) world act = do
   bracket (alloca $ \pp -> c_scene_create pp >>= check "rt_scene_create" >> peek pp)
           (\s -> c_scene_destroy s >> readIORef keep >>= mapM_ freeHaskellFunPtr) $ \s -> do
     emit keep s world
-    mapM_ (emitLight s) ls
+    emitLights keep s world ls
     act s
 
 hostBuffer :: Int -> IO (ForeignPtr Word8)

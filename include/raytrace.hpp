@@ -87,10 +87,12 @@ inline Shape cylinder(Material topM, Material botM, Material mantleM, Vector3D p
 }
 
 // ---- Light ------------------------------------------------------------------------------------
-struct LightSrc { bool point; double diffuse, specular, f; Vector3D pos; };
+struct LightSrc { bool point; double diffuse, specular, f; Vector3D pos; Shape world; };   // world: the Shape a point light closed over (null: the traced one)
 using Light = std::vector<LightSrc>;                                                           // a sum of sources, Main.hs:436-441
-inline Light pointLight(double diffuse, double specular, Vector3D lpos) { return {{true, diffuse, specular, 0, lpos}}; }   // Main.hs:467 (world bound at trace)
-inline Light ambient(double f) { return {{false, 0, 0, f, {0, 0, 0}}}; }                       // Main.hs:490
+inline Light pointLight(double diffuse, double specular, Vector3D lpos) { return {{true, diffuse, specular, 0, lpos, nullptr}}; }   // Main.hs:467 (world bound at trace)
+// pointLight world diffuse specular lpos, as Main.hs:467 has it: the light tests its shadow rays against `world`, whatever is traced
+inline Light pointLight(Shape world, double diffuse, double specular, Vector3D lpos) { return {{true, diffuse, specular, 0, lpos, std::move(world)}}; }
+inline Light ambient(double f) { return {{false, 0, 0, f, {0, 0, 0}, nullptr}}; }              // Main.hs:490
 inline Light operator+(Light a, const Light &b) { a.insert(a.end(), b.begin(), b.end()); return a; }
 inline Light mconcat(const std::vector<Light> &ls) { Light out; for (const Light &l : ls) out.insert(out.end(), l.begin(), l.end()); return out; }
 
@@ -197,6 +199,28 @@ inline void emit(rt_scene *s, const Shape &sh) {
                                      const_cast<FNormFn *>(&n.fnorm)), "normals"); break; }
     }
 }
+// the lights; a point light that closed over a Shape other than the traced world gets that Shape as a shadow world (once per Shape)
+inline void emit_lights(rt_scene *s, const Tracer &tr) {
+    std::vector<std::pair<const ShapeNode *, int>> own;
+    auto world_of = [&](const LightSrc &l) {
+        if (!l.point || !l.world || l.world == tr.world) return 0;
+        for (const auto &kv : own) if (kv.first == l.world.get()) return kv.second;
+        const int id = rt_begin_shadow_world(s);
+        check(id, "rt_begin_shadow_world");
+        emit(s, l.world);
+        check(rt_end_shadow_world(s), "rt_end_shadow_world");
+        own.emplace_back(l.world.get(), id);
+        return id;
+    };
+    std::vector<int> worlds;
+    for (const LightSrc &l : tr.lights) worlds.push_back(world_of(l));
+    for (size_t i = 0; i < tr.lights.size(); ++i) {
+        const LightSrc &l = tr.lights[i];
+        const double p[3] = {l.pos.x, l.pos.y, l.pos.z};
+        check(!l.point ? rt_add_ambient(s, l.f) : (worlds[i] ? rt_add_point_light_world(s, worlds[i], l.diffuse, l.specular, p)
+                                                             : rt_add_point_light(s, l.diffuse, l.specular, p)), "light");
+    }
+}
 } // namespace detail
 
 // parallelTrace w h camera (trace depth lights world) — Main.hs:623-637: the whole image in one call.
@@ -206,10 +230,7 @@ inline Image parallelTrace(int w, int h, Camera camera, const Tracer &tr, bool w
     detail::check(rt_scene_create(&s), "rt_scene_create");
     std::unique_ptr<rt_scene, void (*)(rt_scene *)> guard(s, rt_scene_destroy);
     detail::emit(s, tr.world);
-    for (const LightSrc &l : tr.lights) {
-        const double p[3] = {l.pos.x, l.pos.y, l.pos.z};
-        detail::check(l.point ? rt_add_point_light(s, l.diffuse, l.specular, p) : rt_add_ambient(s, l.f), "light");
-    }
+    detail::emit_lights(s, tr);
     Image img; img.w = w; img.h = h; img.rgba.resize((size_t)w * h * 4);
     if (want_hit_ids) img.hit_id.resize((size_t)w * h);
     detail::check(rt_render(s, w, h, tr.depth, 1, 0, 0, h, img.rgba.data(), want_hit_ids ? img.hit_id.data() : nullptr), "rt_render");
@@ -224,10 +245,7 @@ inline Image parallelTraceMulti(const std::vector<int> &devices, int w, int h, C
     detail::check(rt_scene_create(&s), "rt_scene_create");
     std::unique_ptr<rt_scene, void (*)(rt_scene *)> guard(s, rt_scene_destroy);
     detail::emit(s, tr.world);
-    for (const LightSrc &l : tr.lights) {
-        const double p[3] = {l.pos.x, l.pos.y, l.pos.z};
-        detail::check(l.point ? rt_add_point_light(s, l.diffuse, l.specular, p) : rt_add_ambient(s, l.f), "light");
-    }
+    detail::emit_lights(s, tr);
     Image img; img.w = w; img.h = h; img.rgba.resize((size_t)w * h * 4);
     if (want_hit_ids) img.hit_id.resize((size_t)w * h);
     detail::check(rt_render_multi(s, w, h, tr.depth, 1, 0, (int)devices.size(), devices.data(), img.rgba.data(),

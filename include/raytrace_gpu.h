@@ -180,6 +180,16 @@ int  rt_add_point_light(rt_scene *, double diffuse, double specular, const doubl
 int  rt_add_ambient(rt_scene *, double f);
 
 /* ---- introspection (host logic tests; no device needed) --------------------------------- */
+/* `pointLight world kd ks pos` (Main.hs:467-474) closes over the Shape its shadow rays are cast against, and that Shape need
+ * not be the one that is traced (every scene of the reference passes the traced world; rt_add_point_light does that).
+ * A shadow world is a second shape tree: between rt_begin_shadow_world (returns its number, >= 1) and rt_end_shadow_world
+ * the rt_add_* / rt_begin_* calls build it instead of the traced world; rt_add_point_light_world names the world (0 = the
+ * traced one) a light tests its shadow rays against.  The traced world must be complete before the first shadow world
+ * begins: hit IDs stay its depth-first leaf order.  Shadow-world shapes are never seen by camera or reflected rays. */
+int  rt_begin_shadow_world(rt_scene *);
+int  rt_end_shadow_world(rt_scene *);
+int  rt_add_point_light_world(rt_scene *, int world, double diffuse, double specular, const double pos[3]);
+
 int  rt_scene_num_leaves(const rt_scene *);
 int  rt_scene_num_lights(const rt_scene *);
 /* out[0..19]: kind(0 rect,1 tri,2 sphere), normal mode, normal xyz, d, p0 xyz, e1 xyz, e2 xyz, c0..c3 */

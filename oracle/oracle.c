@@ -139,7 +139,8 @@ typedef struct {
     orc_fnorm fnorm; void *fnorm_user;
 } node;
 
-typedef struct { int kind; double diffuse, specular, f; v3 pos; } lightsrc; /* kind 0 point, 1 ambient */
+typedef struct { int kind; double diffuse, specular, f; v3 pos; int world; } lightsrc; /* kind 0 point, 1 ambient; world: the
+   Shape a point light closes over (`pointLight world ...`, Main.hs:467), a node of this scene, or -1 = the traced one */
 
 struct orc_scene {
     int talk;      /* 1: the rules of src/Talk.hs (orc_scene_set_talk) */
@@ -374,11 +375,16 @@ static int add_light(orc_scene *s, lightsrc l) {
     return s->nlights++;
 }
 int orc_point_light(orc_scene *s, double diffuse, double specular, const double pos[3]) {
-    lightsrc l = { 0, diffuse, specular, 0, P(pos) };
+    lightsrc l = { 0, diffuse, specular, 0, P(pos), -1 };
+    return add_light(s, l);
+}
+/* pointLight world' kd ks pos with a world' that is not the traced one: Main.hs:467-474 tests `intersect world' shadowRay` */
+int orc_point_light_world(orc_scene *s, int world, double diffuse, double specular, const double pos[3]) {
+    lightsrc l = { 0, diffuse, specular, 0, P(pos), world };
     return add_light(s, l);
 }
 int orc_ambient(orc_scene *s, double f) {
-    lightsrc l = { 1, 0, 0, f, V(0, 0, 0) };
+    lightsrc l = { 1, 0, 0, f, V(0, 0, 0), -1 };
     return add_light(s, l);
 }
 
@@ -587,13 +593,14 @@ static px8 shade(const orc_scene *s, int world, const hit *h, const ray *r, int 
     const orc_material *m = &s->mats[h->mat];
     for (int i = 0; i < s->nlights; ++i) {
         const lightsrc *L = &s->lights[i];
+        const int lworld = L->world >= 0 ? L->world : world;      /* the Shape the light closed over */
         px8 c = { 0, 0, 0 };
         if (L->kind == 1) c = scalePixel(L->f, m->diffuse);                            /* :490-492, Talk.hs:230-235 */
         else if (s->talk) {                                                            /* Talk.hs:237-248 */
             v3 to_light = normalize_talk(vsub(L->pos, h->pos));                        /* :239 */
             ray rl = mkray(vadd(h->pos, scalar(0.00001, to_light)), to_light);         /* :240 */
             hit sh;
-            if (isect_node(s, world, &rl, &sh, 0) && dot(vsub(L->pos, sh.pos), to_light) >= 0) { /* :241-242 */
+            if (isect_node(s, lworld, &rl, &sh, 0) && dot(vsub(L->pos, sh.pos), to_light) >= 0) { /* :241-242 */
                 /* black */
             } else {
                 double f = hs_min(1, hs_max(0, dot(to_light, h->normal)) * L->diffuse); /* :244 */
@@ -604,7 +611,7 @@ static px8 shade(const orc_scene *s, int world, const hit *h, const ray *r, int 
             double sp = m->specularity;
             ray rl = mkray(vadd(h->pos, scalar(0.00001, to_light)), to_light);
             hit sh;
-            if (isect_node(s, world, &rl, &sh, use_bbox) && sh.t <= rayDistance(&rl, L->pos)) { /* :474 */
+            if (isect_node(s, lworld, &rl, &sh, use_bbox) && sh.t <= rayDistance(&rl, L->pos)) { /* :474 */
                 /* black */
             } else {
                 double lndot = dot(to_light, h->normal);

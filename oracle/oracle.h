@@ -80,6 +80,7 @@ int orc_linear_interpolation_gaussian(orc_scene *, double x1, double y1, double 
 
 /* Lights (the scene's light list is `mconcat` of everything added, Main.hs:436-441). */
 int orc_point_light(orc_scene *, double diffuse, double specular, const double pos[3]); /* Main.hs:467-487 */
+int orc_point_light_world(orc_scene *, int world, double diffuse, double specular, const double pos[3]); /* ... closing over `world` (a node) */
 int orc_ambient(orc_scene *, double f);                                                 /* Main.hs:490-492 */
 
 /* Number of leaves below `root` and leaf order (depth-first, left to right) */

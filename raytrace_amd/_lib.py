@@ -62,6 +62,9 @@ SYMBOLS = {
     "rt_set_normal_mode": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, _D3, C.c_int]),
     "rt_add_point_light": (C.c_int, [C.c_void_p, C.c_double, C.c_double, _D3]),
     "rt_add_ambient": (C.c_int, [C.c_void_p, C.c_double]),
+    "rt_begin_shadow_world": (C.c_int, [C.c_void_p]),
+    "rt_end_shadow_world": (C.c_int, [C.c_void_p]),
+    "rt_add_point_light_world": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_double)]),
     "rt_scene_num_leaves": (C.c_int, [C.c_void_p]),
     "rt_scene_num_lights": (C.c_int, [C.c_void_p]),
     "rt_scene_get_leaf": (C.c_int, [C.c_void_p, C.c_int, _D3]),

@@ -237,13 +237,15 @@ def talk_pointLight(intensity, lp):                                  # Talk.hs:2
 
 # ---------------------------------------------------------------------------------------------
 # Lights — Main.hs:423-492.  A Light value is a list of sources (`mconcat`); the world a point
-# light casts its shadow rays against is the world being traced.
+# light casts its shadow rays against is the Shape it closed over (`pointLight world ...`, Main.hs:467): None = the world
+# being traced, which is what every scene of the reference passes.
 
 @dataclass
 class PointLight:
     diffuse: float
     specular: float
     pos: Vec
+    world: Optional["Shape"] = None
 
 
 @dataclass
@@ -251,8 +253,13 @@ class Ambient:
     f: float
 
 
-def pointLight(diffuse, specular, lpos):
-    return [PointLight(diffuse, specular, tuple(lpos))]
+def pointLight(*args, world=None):
+    """pointLight diffuse specular lpos, or — the reference's own argument order, Main.hs:467 — pointLight world diffuse
+    specular lpos: the light then tests its shadow rays against `world` whatever is traced."""
+    if len(args) == 4:
+        world, args = args[0], args[1:]
+    diffuse, specular, lpos = args
+    return [PointLight(diffuse, specular, tuple(lpos), world)]
 
 
 def ambient(f):
@@ -351,8 +358,16 @@ class Scene:
             self._check(self._L.rt_scene_set_dialect(self._h, 1), "rt_scene_set_dialect")
             world = world.child
         self._add(world)
+        own = {}                                  # id(Shape) -> shadow world: a light that closed over another Shape (Main.hs:467)
         for l in lights:
-            if isinstance(l, PointLight):
+            if isinstance(l, PointLight) and l.world is not None and l.world is not world and id(l.world) not in own:
+                own[id(l.world)] = self._check(self._L.rt_begin_shadow_world(self._h), "rt_begin_shadow_world")
+                self._add(l.world)
+                self._check(self._L.rt_end_shadow_world(self._h), "rt_end_shadow_world")
+        for l in lights:
+            if isinstance(l, PointLight) and l.world is not None and l.world is not world:
+                self._check(self._L.rt_add_point_light_world(self._h, own[id(l.world)], l.diffuse, l.specular, _lib.vec3(l.pos)))
+            elif isinstance(l, PointLight):
                 self._check(self._L.rt_add_point_light(self._h, l.diffuse, l.specular, _lib.vec3(l.pos)))
             elif isinstance(l, Ambient):
                 self._check(self._L.rt_add_ambient(self._h, l.f))

@@ -61,10 +61,19 @@ static inline double hmin(double x, double y) { return x <= y ? x : y; }   // Ha
 static inline double hmax(double x, double y) { return x <= y ? y : x; }
 
 static void attach(rt_scene &s, int node) {
-    if (s.open.empty()) s.top.push_back(node);
+    if (s.open.empty()) (s.cur_world ? s.shadow_top[(size_t)s.cur_world - 1] : s.top).push_back(node);
     else s.nodes[s.open.back()].kids.push_back(node);
 }
+// Shapes of the traced world come first: a hit ID is the leaf's place in the traced world's depth-first order.
+static bool world_accepts_shapes(const rt_scene &s, const char *who) {
+    if (s.cur_world == 0 && !s.shadow_top.empty()) {
+        set_error(std::string(who) + ": the traced world must be complete before the first rt_begin_shadow_world");
+        return false;
+    }
+    return true;
+}
 static int open_group(rt_scene &s, int kind) {
+    if (!world_accepts_shapes(s, kind == 1 ? "rt_begin_mconcat" : "rt_begin_mappend")) return RT_ERR_ARG;
     s.nodes.push_back(GNode{kind, -1, {}});
     const int id = (int)s.nodes.size() - 1;
     attach(s, id);
@@ -81,6 +90,7 @@ static int close_group(rt_scene &s, int kind, const char *who) {
 
 static int push_leaf(rt_scene &s, LeafD &L, const Box &bb) {
     s.leaf_bb.push_back(bb);
+    s.leaf_world.push_back(s.cur_world);
     s.nodes.push_back(GNode{0, (int)s.leaves.size(), {}});
     attach(s, (int)s.nodes.size() - 1);
     L.guard = 0;
@@ -574,19 +584,25 @@ static void order_guards(rt_scene &s) {
 }
 bool compute_guards(rt_scene &s) {
     if (!s.open.empty()) { set_error("rt_render: an rt_begin_mconcat/rt_begin_mappend bracket is still open"); return false; }
+    if (s.cur_world != 0) { set_error("rt_render: an rt_begin_shadow_world is still open"); return false; }
     s.guards.clear();
     s.guard_cached = 0;
     if (s.talk) {                                         // Talk.hs:185-194: the monoid has no bounding boxes
         for (LeafD &L : s.leaves) L.guard = -1;
         return true;
     }
-    if (s.top.empty()) return true;
-    if (s.top.size() == 1) assign_guards(s, s.top[0], -1);
-    else {
-        s.nodes.push_back(GNode{1, -1, s.top});                // implicit top-level mconcat
-        assign_guards(s, (int)s.nodes.size() - 1, -1);
-        s.nodes.pop_back();
-    }
+    auto one_world = [&](const std::vector<int> &top) {
+        if (top.empty()) return;
+        if (top.size() == 1) assign_guards(s, top[0], -1);
+        else {
+            s.nodes.push_back(GNode{1, -1, top});              // implicit top-level mconcat
+            assign_guards(s, (int)s.nodes.size() - 1, -1);
+            s.nodes.pop_back();
+        }
+    };
+    one_world(s.top);
+    for (const std::vector<int> &top : s.shadow_top) one_world(top);     // (every world is a tree of its own)
+    if (s.guards.empty()) return true;
     order_guards(s);
     return true;
 }
@@ -875,14 +891,15 @@ void build_filter_records(rt_scene &s, int w, int h, bool eye_only) {
         for (size_t k = 0; k < gstride * 8; ++k) s.mf_cone[(size_t)apex * gstride * 8 + k] = 0.f;
     };
     // the apexes are independent of one another (disjoint slices of every array): one host thread each
-    struct ApexJob { double A[3], dmax[3], eye_d; int apex; };
+    struct ApexJob { double A[3], dmax[3], eye_d; int apex, world; };
     std::vector<ApexJob> jobs;
-    auto fill = [&](const double A[3], const double dmax[3], double eye_d, int apex) {
+    auto fill = [&](const double A[3], const double dmax[3], double eye_d, int apex, int world) {
         reset_apex(apex);
         std::vector<LeafCone> cone(nplanar);
         std::vector<double> cu(nplanar), cv(nplanar);
         std::vector<int> live, always, never;
         for (size_t k = 0; k < nplanar; ++k) {
+            if (s.leaf_world[(size_t)planar[k]] != world) continue;      // not in this apex's world: stays padding (never a candidate)
             cone[k] = leaf_cone(s.leaves[planar[k]], A, dmax);
             if (cone[k].status == 0) {
                 const double *a = cone[k].axis;
@@ -919,15 +936,16 @@ void build_filter_records(rt_scene &s, int w, int h, bool eye_only) {
         }
         for (size_t g = 0; g < gstride; ++g) block_cone(&ordered[g * MF_LEAVES], MF_LEAVES, &s.mf_cone[((size_t)apex * gstride + g) * 8]);
 #ifdef RT_VALU_FILTER
-        for (size_t k = 0; k < ntri; ++k) s.tri_rec[(size_t)apex * ntri + k] = make_rec(s.leaves[s.tri_gid[k]], A, dmax, eye_d);
-        for (size_t k = 0; k < nrect; ++k) s.rect_rec[(size_t)apex * nrect + k] = make_rec(s.leaves[s.rect_gid[k]], A, dmax, eye_d);
+        for (size_t k = 0; k < ntri; ++k) s.tri_rec[(size_t)apex * ntri + k] = s.leaf_world[(size_t)s.tri_gid[k]] == world ? make_rec(s.leaves[s.tri_gid[k]], A, dmax, eye_d) : never_rec();
+        for (size_t k = 0; k < nrect; ++k) s.rect_rec[(size_t)apex * nrect + k] = s.leaf_world[(size_t)s.rect_gid[k]] == world ? make_rec(s.leaves[s.rect_gid[k]], A, dmax, eye_d) : never_rec();
 #endif
-        for (size_t k = 0; k < nsph; ++k) s.sph_rec[(size_t)apex * nsph + k] = make_sphere_rec(s.leaves[s.sph_gid[k]], A, dmax);
+        for (size_t k = 0; k < nsph; ++k)
+            s.sph_rec[(size_t)apex * nsph + k] = s.leaf_world[(size_t)s.sph_gid[k]] == world ? make_sphere_rec(s.leaves[s.sph_gid[k]], A, dmax) : never_rec();
     };
-    auto add_job = [&](const double A[3], const double dmax[3], double eye_d) {
+    auto add_job = [&](const double A[3], const double dmax[3], double eye_d, int world) {
         ApexJob j{};
         for (int i = 0; i < 3; ++i) { j.A[i] = A[i]; j.dmax[i] = dmax[i]; }
-        j.eye_d = eye_d; j.apex = (int)jobs.size();
+        j.eye_d = eye_d; j.apex = (int)jobs.size(); j.world = world;
         jobs.push_back(j);
         return j.apex;
     };
@@ -935,10 +953,11 @@ void build_filter_records(rt_scene &s, int w, int h, bool eye_only) {
         // depend on the image size (d = -tan(fov/2)/2); only the bound on |posX|, |posY| does, through the margins.
         const CameraD cam = fixed_camera(1, 1);
         const double A[3] = {0.0, 0.0, -cam.d};
-        add_job(A, s.eye_dmax, cam.d);
+        add_job(A, s.eye_dmax, cam.d, 0);
     }
     if (!eye_only) {
-        for (LightD &Lt : s.lights) {
+        for (size_t li = 0; li < s.lights.size(); ++li) {
+            LightD &Lt = s.lights[li];
             if (Lt.kind != 0) continue;
             const double A[3] = {Lt.px, Lt.py, Lt.pz};
             double dmax[3];
@@ -946,7 +965,7 @@ void build_filter_records(rt_scene &s, int w, int h, bool eye_only) {
                 const double a = std::fabs(lo[i] - A[i]), b = std::fabs(hi[i] - A[i]);
                 dmax[i] = (s.leaves.empty() ? 1.0 : std::fmax(a, b)) * 1.001 + 1e-3;
             }
-            Lt.rec_offset = add_job(A, dmax, 0.0);
+            Lt.rec_offset = add_job(A, dmax, 0.0, s.light_world[li]);          // the light's own world (pointLight world ..., Main.hs:467)
         }
     }
     {
@@ -954,8 +973,8 @@ void build_filter_records(rt_scene &s, int w, int h, bool eye_only) {
         for (size_t j0 = 0; j0 < jobs.size(); j0 += width) {
             std::vector<std::thread> pool;
             for (size_t j = j0 + 1; j < std::min(jobs.size(), j0 + width); ++j)
-                pool.emplace_back([&, j] { fill(jobs[j].A, jobs[j].dmax, jobs[j].eye_d, jobs[j].apex); });
-            fill(jobs[j0].A, jobs[j0].dmax, jobs[j0].eye_d, jobs[j0].apex);
+                pool.emplace_back([&, j] { fill(jobs[j].A, jobs[j].dmax, jobs[j].eye_d, jobs[j].apex, jobs[j].world); });
+            fill(jobs[j0].A, jobs[j0].dmax, jobs[j0].eye_d, jobs[j0].apex, jobs[j0].world);
             for (std::thread &t : pool) t.join();
         }
     }
@@ -974,10 +993,11 @@ void build_filter_records(rt_scene &s, int w, int h, bool eye_only) {
             spatial_order(s, s.tri_gid, lo, hi, dall, s.gen_tri_gid, s.gen_tri_sph, s.gen_tri_rows, s.gen_tri_ssph);
             spatial_order(s, s.rect_gid, lo, hi, dall, s.gen_rect_gid, s.gen_rect_sph, s.gen_rect_rows, s.gen_rect_ssph);
             auto with_gid = [](GenRec r, int32_t gid) { std::memcpy(&r.c[15], &gid, 4); return r; };       // the spare float carries the leaf index
-            for (size_t k = 0; k < ntri; ++k) s.gen_tri[k] = with_gid(make_gen_rec(s.leaves[s.gen_tri_gid[k]], omax), s.gen_tri_gid[k]);
-            for (size_t k = 0; k < nrect; ++k) s.gen_rect[k] = with_gid(make_gen_rec(s.leaves[s.gen_rect_gid[k]], omax), s.gen_rect_gid[k]);
+            // (reflected rays meet the traced world only: leaves of shadow worlds keep the never record)
+            for (size_t k = 0; k < ntri; ++k) if (s.leaf_world[(size_t)s.gen_tri_gid[k]] == 0) s.gen_tri[k] = with_gid(make_gen_rec(s.leaves[s.gen_tri_gid[k]], omax), s.gen_tri_gid[k]);
+            for (size_t k = 0; k < nrect; ++k) if (s.leaf_world[(size_t)s.gen_rect_gid[k]] == 0) s.gen_rect[k] = with_gid(make_gen_rec(s.leaves[s.gen_rect_gid[k]], omax), s.gen_rect_gid[k]);
             s.gen_sph.assign(nsph + 1, never);
-            for (size_t k = 0; k < nsph; ++k) s.gen_sph[k] = make_sphere_gen_rec(s.leaves[s.sph_gid[k]], omax);
+            for (size_t k = 0; k < nsph; ++k) if (s.leaf_world[(size_t)s.sph_gid[k]] == 0) s.gen_sph[k] = make_sphere_gen_rec(s.leaves[s.sph_gid[k]], omax);
         }
     }
 }
@@ -1131,18 +1151,21 @@ int rt_scene_set_dialect(rt_scene *s, int dialect) {
 int rt_add_rectangle(rt_scene *s, const rt_material *m, const double point[3],
                      const double width[3], const double height[3]) {
     if (!s || !m || !point || !width || !height) { set_error("rt_add_rectangle: NULL argument"); return RT_ERR_ARG; }
+    if (!world_accepts_shapes(*s, "rt_add_rectangle")) return RT_ERR_ARG;
     return add_rect(*s, *m, from(point), from(width), from(height));
 }
 
 int rt_add_triangle(rt_scene *s, const rt_material *m, const double pa[3], const double pb[3],
                     const double pc[3]) {
     if (!s || !m || !pa || !pb || !pc) { set_error("rt_add_triangle: NULL argument"); return RT_ERR_ARG; }
+    if (!world_accepts_shapes(*s, "rt_add_triangle")) return RT_ERR_ARG;
     RT_TALK_ONLY_RECT(s, "rt_add_triangle");
     return add_tri(*s, *m, from(pa), from(pb), from(pc));
 }
 
 int rt_add_sphere(rt_scene *s, const rt_material *m, const double center[3], double radius) {
     if (!s || !m || !center) { set_error("rt_add_sphere: NULL argument"); return RT_ERR_ARG; }
+    if (!world_accepts_shapes(*s, "rt_add_sphere")) return RT_ERR_ARG;
     RT_TALK_ONLY_RECT(s, "rt_add_sphere");
     return add_sphere(*s, *m, from(center), radius);
 }
@@ -1152,6 +1175,7 @@ int rt_add_sphere(rt_scene *s, const rt_material *m, const double center[3], dou
 int rt_add_cuboid(rt_scene *s, const rt_material *mats, int nmats, const double point[3],
                   double l, double h, double d) {
     if (!s || !mats || !point) { set_error("rt_add_cuboid: NULL argument"); return RT_ERR_ARG; }
+    if (!world_accepts_shapes(*s, "rt_add_cuboid")) return RT_ERR_ARG;
     if (nmats <= 0) { set_error("colorcuboid: list of materials must not be empty."); return RT_ERR_ARG; } // :302
     RT_TALK_ONLY_RECT(s, "rt_add_cuboid");      // Talk.hs's cube has other faces (Talk.hs:197-218): build it from rectangles
     const D3 p = from(point);
@@ -1173,6 +1197,7 @@ int rt_add_cuboid(rt_scene *s, const rt_material *mats, int nmats, const double 
 int rt_add_cylinder(rt_scene *s, const rt_material *top, const rt_material *bot,
                     const rt_material *mantle, const double point[3], int n, double h, double r) {
     if (!s || !top || !bot || !mantle || !point) { set_error("rt_add_cylinder: NULL argument"); return RT_ERR_ARG; }
+    if (!world_accepts_shapes(*s, "rt_add_cylinder")) return RT_ERR_ARG;
     if (n < 1) { set_error("rt_add_cylinder: n must be >= 1"); return RT_ERR_ARG; }
     RT_TALK_ONLY_RECT(s, "rt_add_cylinder");
     const D3 c = from(point);
@@ -1259,9 +1284,34 @@ int rt_add_point_light(rt_scene *s, double diffuse, double specular, const doubl
     L.kind = 0; L.px = pos[0]; L.py = pos[1]; L.pz = pos[2];
     L.diffuse = diffuse; L.specular = specular; L.rec_offset = -1;
     s->lights.push_back(L);
+    s->light_world.push_back(0);
     s->npoint++;
     s->dirty = true;
     return (int)s->lights.size() - 1;
+}
+
+// pointLight world' kd ks pos with a world' of its own (Main.hs:467-474: `intersect world shadowRay` is the light's closure)
+int rt_add_point_light_world(rt_scene *s, int world, double diffuse, double specular, const double pos[3]) {
+    if (!s || !pos) { set_error("rt_add_point_light_world: NULL argument"); return RT_ERR_ARG; }
+    if (world < 0 || (size_t)world > s->shadow_top.size()) { set_error("rt_add_point_light_world: no such world"); return RT_ERR_ARG; }
+    const int id = rt_add_point_light(s, diffuse, specular, pos);
+    if (id >= 0) s->light_world[(size_t)id] = world;
+    return id;
+}
+
+int rt_begin_shadow_world(rt_scene *s) {
+    if (!s) { set_error("rt_begin_shadow_world: NULL scene"); return RT_ERR_ARG; }
+    if (!s->open.empty() || s->cur_world != 0) { set_error("rt_begin_shadow_world: inside an open bracket or another shadow world"); return RT_ERR_ARG; }
+    s->shadow_top.emplace_back();
+    s->cur_world = (int)s->shadow_top.size();
+    s->dirty = true;
+    return s->cur_world;
+}
+int rt_end_shadow_world(rt_scene *s) {
+    if (!s) { set_error("rt_end_shadow_world: NULL scene"); return RT_ERR_ARG; }
+    if (s->cur_world == 0 || !s->open.empty()) { set_error("rt_end_shadow_world: no shadow world is open, or a bracket inside it still is"); return RT_ERR_ARG; }
+    s->cur_world = 0;
+    return RT_OK;
 }
 
 int rt_add_ambient(rt_scene *s, double f) {
@@ -1269,6 +1319,7 @@ int rt_add_ambient(rt_scene *s, double f) {
     LightD L{};
     L.kind = 1; L.f = f; L.rec_offset = -1;
     s->lights.push_back(L);
+    s->light_world.push_back(0);
     s->dirty = true;
     return (int)s->lights.size() - 1;
 }

@@ -117,7 +117,15 @@ struct rt_scene {
     std::vector<rt::Box> leaf_bb;         // boundingBox of every leaf (Main.hs:243-245, 384)
     std::vector<rt::GNode> nodes;         // the mappend/mconcat tree
     std::vector<int> open;                // stack of open brackets (node indices)
-    std::vector<int> top;                 // children outside any bracket
+    std::vector<int> top;                 // children outside any bracket (of the traced world)
+    // `pointLight world ...` (Main.hs:467-474) closes over a Shape of its own: the world its shadow rays are cast against,
+    // which need not be the traced one.  Shadow world k >= 1 is a second shape tree (rt_begin_shadow_world); its leaves live
+    // in `leaves` behind the traced world's (hit IDs stay the traced world's depth-first order) and are seen only by the
+    // lights that name it: every apex's streams are built from the leaves of ITS world.
+    std::vector<std::vector<int>> shadow_top;   // children outside any bracket of shadow world k (index k - 1)
+    std::vector<int32_t> leaf_world;      // per leaf: 0 = the traced world, k = shadow world k
+    std::vector<int32_t> light_world;     // per light: the world its shadow rays meet (0: the traced world)
+    int cur_world = 0;                    // the world shapes are being added to
     std::vector<rt::AuxD> aux;
     std::vector<rt::GuardD> guards;       // guard-box chains, rebuilt by compute_guards
     int guard_cached = 0;                 // guards [0, guard_cached): the boxes above the most leaves, parents first (<= 64)

@@ -68,8 +68,23 @@ def mantle_normal():
     return cyl, api.pointLight(1.0, 0.7, (0.0, 0.0, -1.0)), 4, 4, (2, 1), {(2, 2): (9, (100, 50, 25))}
 
 
+def light_with_its_own_world(occluder_in_lights_world=True):
+    """`pointLight world kd ks pos` closes over the Shape its shadow rays meet (Main.hs:467-474), and that need not be the
+    traced one.  (a) Traced: the wall alone; the light closes over the plate of shadowed_pixel, which the camera never
+    sees: the centre pixel is in its shadow all the same — ambient only, (50, 25, 12).  (b) Traced: wall and plate; the
+    light closes over mempty (`intersect mempty` is Nothing, Main.hs:204): nothing shadows anything, and the pixel gets
+    phong_pixel's (82, 41, 20) + ambient (50, 25, 12) = (132, 66, 32)."""
+    plate = api.rectangle(api.white, (0.0, 1.5, -3.0), (1.0, 0.0, 0.0), (0.0, 0.0, 1.0))
+    if occluder_in_lights_world:
+        lights = api.mconcat_lights([api.pointLight(plate, 0.5, 0.6, (0.0, 3.0, -1.0)), api.ambient(0.25)])
+        return _wall(), lights, 4, 4, (2, 1), {(2, 2): (0, (50, 25, 12))}
+    lights = api.mconcat_lights([api.pointLight(api.mconcat([]), 0.5, 0.6, (0.0, 3.0, -1.0)), api.ambient(0.25)])
+    return api.mconcat([_wall(), plate]), lights, 4, 4, (2, 1), {(2, 2): (0, (132, 66, 32))}
+
+
 CASES = {
     "phong_pixel": phong_pixel, "shadowed_pixel": shadowed_pixel,
+    "light_world_occluder_unseen": lambda: light_with_its_own_world(True), "light_world_empty": lambda: light_with_its_own_world(False),
     "triangle_edge_on": lambda: triangle_edge(True), "triangle_edge_off": lambda: triangle_edge(False),
     "camera_4k_quirk": camera_4k_quirk, "mantle_normal": mantle_normal,
 }

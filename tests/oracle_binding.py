@@ -46,6 +46,7 @@ def lib():
         L.orc_linear_interpolation_gaussian.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double,
                                                         C.c_double, _D3, C.c_double]
         L.orc_point_light.argtypes = [C.c_void_p, C.c_double, C.c_double, _D3]
+        L.orc_point_light_world.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, _D3]
         L.orc_ambient.argtypes = [C.c_void_p, C.c_double]
         L.orc_num_leaves.argtypes = [C.c_void_p, C.c_int]
         L.orc_render.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int,
@@ -83,8 +84,13 @@ class OracleScene:
             assert self.L.orc_scene_set_talk(self.h, 1) == 0
             world = world.child
         self.root = self._node(world)
+        own = {}                                       # id(Shape) -> node: a light's own world (pointLight world ..., Main.hs:467)
         for l in lights:
-            if isinstance(l, api.PointLight):
+            if isinstance(l, api.PointLight) and l.world is not None and l.world is not world:
+                if id(l.world) not in own:
+                    own[id(l.world)] = self._node(l.world)
+                self.L.orc_point_light_world(self.h, own[id(l.world)], l.diffuse, l.specular, _v(l.pos))
+            elif isinstance(l, api.PointLight):
                 self.L.orc_point_light(self.h, l.diffuse, l.specular, _v(l.pos))
             else:
                 self.L.orc_ambient(self.h, l.f)

@@ -624,6 +624,47 @@ def test_pieces_on_alternating_lanes(gpu_lib):
     sc.close()
 
 
+def test_lights_with_worlds_of_their_own(gpu_lib):
+    """`pointLight world kd ks pos` (Main.hs:467-474): a light tests its shadow rays against the Shape it closed over.  Three
+    lights — one over a world of big cuboids, spheres and cylinders that is never traced, one over the traced world,
+    one over mempty — on a scene of small triangles and cuboids, and on the room of mirrors (reflected rays must not see
+    the lights' worlds either): whole frames against the oracle, bands, 4 samples, the cull off, the Talk.hs dialect."""
+    from raytrace_amd import _lib
+    rng = np.random.default_rng(77)
+    big = [api.cuboid(api.white, tuple(map(float, rng.uniform((-6, -1, -24), (6, 5, -8)))), 2.5, 1.5, 2.0) for _ in range(6)]
+    big += [api.sphere(api.white, tuple(map(float, rng.uniform((-6, 0, -20), (6, 5, -8)))), 1.2) for _ in range(4)]
+    big += [api.cylinder(api.white, api.white, api.white, (2.0, 2.0, -12.0), 9, 2.0, 1.1)]
+    occluders = api.mconcat(big)
+    for (world, base_lights), (w, h), depth in ((scenes.synthetic(ntri=500, ncuboid=50), (320, 200), 4), (scenes.mirror_room(), (240, 160), 4)):
+        lights = api.mconcat_lights([api.pointLight(occluders, 0.5, 0.6, (1.0, 9.0, -14.0)), api.pointLight(world, 0.3, 0.4, (-4.0, 6.0, -6.0)),
+                                     api.pointLight(api.mconcat([]), 0.2, 0.2, (5.0, 3.0, -2.0)), api.pointLight(occluders, 0.2, 0.3, (-7.0, 8.0, -20.0)),
+                                     api.ambient(0.1)])
+        osc = ob.OracleScene(world, lights)
+        ref = osc.render(w, h, depth=depth, nthreads=16)
+        plain = ob.OracleScene(world, [api.PointLight(l.diffuse, l.specular, l.pos) if isinstance(l, api.PointLight) else l for l in lights]).render(w, h, depth=depth, nthreads=16)
+        assert (ref["rgb"] != plain["rgb"]).any()                      # (the worlds do change the picture)
+        sc = api.Scene(world, lights)
+        for cull in (1, 0):
+            sc.set_option(_lib.RT_OPT_CULL, cull)
+            rgba, hit = sc.render(w, h, depth=depth)
+            assert (hit == ref["hit_id"]).all() and (rgba[:, :, :3] == ref["rgb"]).all(), cull
+        rgba2, hit2 = sc.render(w, h, depth=depth, row0=40, nrows=56)
+        assert (rgba2 == rgba[40:96]).all() and (hit2 == hit[40:96]).all()
+        ref4 = osc.render(w, h, depth=depth, spp=4, seed=3, row0=64, nrows=16, nthreads=16)
+        rgba4, hit4 = sc.render(w, h, depth=depth, spp=4, seed=3, row0=64, nrows=16)
+        assert (hit4 == ref4["hit_id"]).all() and (rgba4[:, :, :3] == ref4["rgb"]).all()
+        sc.close()
+    # Talk.hs's pointLight closes over a world too (Talk.hs:237-243)
+    world, lights = scenes.talkhs_main2()
+    lights2 = [api.PointLight(l.diffuse, l.specular, l.pos, api.mconcat([])) if isinstance(l, api.PointLight) else l for l in lights]
+    ref = ob.OracleScene(world, lights2).render(160, 120)
+    sc = api.Scene(world, lights2)
+    rgba, hit = sc.render(160, 120)
+    sc.close()
+    assert (hit == ref["hit_id"]).all() and (rgba[:, :, :3] == ref["rgb"]).all()
+    assert (ref["rgb"] != ob.OracleScene(world, lights).render(160, 120)["rgb"]).any()
+
+
 def test_rgb24_outputs(gpu_lib):
     """RT_OPT_RGB24: the colour outputs are 3 bytes per pixel (the reference's PixelRGB8).  Same colours as the RGBA8
     frame through every way out: rt_render into pageable and page-locked memory with several bands, a band of rows,

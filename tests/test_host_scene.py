@@ -104,6 +104,42 @@ def test_guard_chains_follow_the_tree():
     sc.close()
 
 
+def test_a_light_may_close_over_a_world_of_its_own():
+    """`pointLight world kd ks pos` (Main.hs:467-474): a shadow world is a second shape tree whose leaves live behind the
+    traced world's (hit IDs unchanged), have guard chains of their own, and appear only in the streams of the lights that
+    name it — never in the eye's, another light's or the reflected rays'."""
+    L = _lib.lib()
+    wall = api.rectangle(api.red, (0.0, 0.0, -5.0), (4.0, 0.0, 0.0), (0.0, 4.0, 0.0))
+    plate = api.rectangle(api.white, (0.0, 1.5, -3.0), (1.0, 0.0, 0.0), (0.0, 0.0, 1.0))
+    lid = api.rectangle(api.white, (0.0, 2.5, -3.0), (1.0, 0.0, 0.0), (0.0, 0.0, 1.0))
+    other = api.mconcat([plate, lid])
+    lights = api.pointLight(other, 0.5, 0.6, (0.0, 3.0, -1.0)) + api.pointLight(0.5, 0.6, (1.0, 3.0, -1.0)) + api.pointLight(other, 0.1, 0.1, (2.0, 3.0, -1.0))
+    sc = api.Scene(wall, lights)
+    assert L.rt_scene_prepare_host(sc.handle, 64, 64) == 2            # the traced world is one leaf: no box; mconcat [plate, lid]: two
+    assert sc.num_leaves == 3                                          # `other` was emitted once for its two lights
+    assert L.rt_scene_get_guards(sc.handle, 0, None, 0) == 0 and L.rt_scene_get_guards(sc.handle, 1, None, 0) == 1 and L.rt_scene_get_guards(sc.handle, 2, None, 0) == 2
+    row = (C.c_uint16 * 8)()
+    has = [[L.rt_scene_get_mfma_row(sc.handle, apex, leaf, row) >= 0 for leaf in range(3)] for apex in range(4)]
+    assert has == [[True, False, False], [False, True, True], [True, False, False], [False, True, True]]
+    sc.close()
+    # the traced world comes first; brackets and worlds nest properly; a light names a world that exists
+    h = C.c_void_p()
+    assert L.rt_scene_create(C.byref(h)) == 0
+    m = api._cmat(api.red)
+    rect = lambda: L.rt_add_rectangle(h, C.byref(m), _lib.vec3((0, 0, -5)), _lib.vec3((1, 0, 0)), _lib.vec3((0, 1, 0)))
+    assert rect() == 0
+    assert L.rt_end_shadow_world(h) < 0 and b"no shadow world" in L.rt_last_error()
+    assert L.rt_begin_mconcat(h) == 0 and L.rt_begin_shadow_world(h) < 0 and L.rt_end_mconcat(h) == 0
+    assert L.rt_begin_shadow_world(h) == 1 and L.rt_begin_shadow_world(h) < 0
+    assert rect() == 1 and L.rt_end_shadow_world(h) == 0
+    assert rect() < 0 and b"traced world must be complete" in L.rt_last_error()
+    assert L.rt_begin_mconcat(h) < 0
+    assert L.rt_add_point_light_world(h, 2, 0.5, 0.5, _lib.vec3((0, 0, 0))) < 0 and b"no such world" in L.rt_last_error()
+    assert L.rt_add_point_light_world(h, 1, 0.5, 0.5, _lib.vec3((0, 0, 0))) == 0 and L.rt_add_point_light_world(h, 0, 0.5, 0.5, _lib.vec3((0, 0, 0))) == 1
+    assert L.rt_begin_shadow_world(h) == 2 and L.rt_scene_prepare_host(h, 64, 64) < 0 and b"still open" in L.rt_last_error()
+    L.rt_scene_destroy(h)
+
+
 def test_rotated_rectangle_box_uses_two_corners_only():
     """Main.hs:243-245: the `intersection` scene's floor rectangle gets the too-small box."""
     L = _lib.lib()
