@@ -5,7 +5,8 @@ and sample counts.  usage: tools/fuzz_parity.py [nscenes] [seed] [mode]   (GPU b
 mode: "main" (default), "valu" (the vector-ALU kernels of the cross-check build libraytrace_gpu_valu.so), "talk" (Talk.hs dialect: rectangles only),
 "extreme" (scales from 1e-3 to 1e3, geometry around the eye and the viewport plane, degenerate leaves, lights on vertices),
 "big" (90 to 3000 leaves in nested lists, small images), "height" (linearInterpolation height fields with the gaussian
-normals, up to 32 point lights).  Every mode also renders random row bands."""
+normals, up to 32 point lights), "worlds" (point lights that close over a Shape other than the traced world).  Every mode also
+renders random row bands."""
 import os
 import sys
 
@@ -72,6 +73,22 @@ def extreme_scene(rng):
         lp = verts[int(rng.integers(len(verts)))] if verts and rng.random() < 0.3 else pt() * 1.5
         lights.append(api.pointLight(float(rng.uniform(0.05, 0.9)), float(rng.uniform(0, 0.9)), tuple(map(float, lp))))
     return api.mconcat(shapes), api.mconcat_lights(lights)
+
+
+def worlds_scene(rng):
+    """`pointLight world ...` (Main.hs:467): most point lights close over a Shape of their own — another random scene, or
+    mempty — instead of the traced world."""
+    world, lights = random_scene(rng)
+    others = [random_scene(rng)[0] for _ in range(int(rng.integers(1, 3)))] + [api.mconcat([])]
+    out = []
+    for l in lights:
+        if isinstance(l, api.PointLight) and rng.random() < 0.6:
+            out.append(api.PointLight(l.diffuse, l.specular, l.pos, others[int(rng.integers(len(others)))]))
+        else:
+            out.append(l)
+    if not any(isinstance(l, api.PointLight) for l in out):
+        out.append(api.PointLight(0.4, 0.4, (0.0, 3.0, -2.0), others[0]))
+    return world, out
 
 
 def big_scene(rng):
@@ -164,7 +181,8 @@ def main():
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     mode = sys.argv[3] if len(sys.argv) > 3 else "main"
     L = _lib.valu_lib() if mode == "valu" else _lib.lib()       # "valu": the cross-check build, vector-ALU first stage
-    gen = {"main": random_scene, "valu": random_scene, "talk": talk_scene, "extreme": extreme_scene, "big": big_scene, "height": height_scene}[mode]
+    gen = {"main": random_scene, "valu": random_scene, "talk": talk_scene, "extreme": extreme_scene, "big": big_scene, "height": height_scene,
+           "worlds": worlds_scene}[mode]
     _lib.check(L.rt_init(0))
     rng = np.random.default_rng(seed)
     bad = 0
