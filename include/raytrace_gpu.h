@@ -114,8 +114,8 @@ int  rt_scene_set_dialect(rt_scene *, int dialect);
  *                      like those of the other devices (default 0: they are rendered in place; tests use 1).
  *   RT_OPT_LANE        A scene has two lanes per device: a set of work buffers and a stream each.  Kernels of two lanes run
  *                      beside each other and fill each other's tails.  -1 (default): rt_render_device renders a band of
- *                      12 Mi pixels or more as two halves, one per lane (on the lanes' own streams, forked from and joined
- *                      to the stream it is given; same pixels, ~7 % faster).  0 or 1: the following rt_render_device calls use that lane and are not
+ *                      12 Mi pixels or more — 3 Mi when reflected rays are traced — as two halves, one per lane (on the
+ *                      lanes' own streams, forked from and joined to the stream it is given; same pixels, 7 - 17 % faster).  0 or 1: the following rt_render_device calls use that lane and are not
  *                      split: a caller who cuts a frame into pieces renders them alternately on lane 0 and lane 1
  *                      (stream = NULL: the lane's own stream, or two streams of the caller's) and they overlap on the
  *                      device.  Two calls in flight on the SAME lane must be on the same stream (they share work buffers).

@@ -266,7 +266,14 @@ int lane_stream(DeviceScene &D, int lane, hipStream_t &out) {
 }
 
 inline size_t bpp(const rt_scene *s) { return s->opt_rgb24 ? 3 : 4; }      // bytes per pixel of the colour output (RT_OPT_RGB24)
-constexpr size_t RT_SPLIT_PIXELS = 12u << 20;    // rt_render_device splits bands of this many pixels over the two lanes
+#ifndef RT_SPLIT_PIECES_LEVELS
+#define RT_SPLIT_PIECES_LEVELS 2
+#endif
+#ifndef RT_SPLIT_KI_LEVELS
+#define RT_SPLIT_KI_LEVELS 3072
+#endif
+constexpr size_t RT_SPLIT_PIXELS = 12u << 20;                          // plain pipeline: two halves from 12 Mi pixels on
+constexpr size_t RT_SPLIT_PIXELS_LEVELS = (size_t)RT_SPLIT_KI_LEVELS << 10;   // with bounce levels: from 3 Mi pixels on    // rt_render_device splits bands of this many pixels over the two lanes
 constexpr size_t RT_CHUNK_PIXELS = 16u << 20;   // rows are processed in chunks of about 16 Mi pixels
 
 int render_levels(const rt_scene *s, int depth) {
@@ -698,7 +705,8 @@ void scene_destroy_impl(rt_scene *s) {
         for (Lane &l : d.lane) for (void *e : l.evpool) if (e) (void)hipEventDestroy((hipEvent_t)e);
         for (void *x : d.xstream) if (x) (void)hipStreamDestroy((hipStream_t)x);
         for (void *e : d.band_done) if (e) (void)hipEventDestroy((hipEvent_t)e);
-        for (void *e : {d.fork_ev, d.join_ev, d.join0_ev}) if (e) (void)hipEventDestroy((hipEvent_t)e);
+        if (d.fork_ev) (void)hipEventDestroy((hipEvent_t)d.fork_ev);
+        for (void *e : d.join_evs) if (e) (void)hipEventDestroy((hipEvent_t)e);
         for (void *e : d.hits_done) if (e) (void)hipEventDestroy((hipEvent_t)e);
         if (d.stream) (void)hipStreamDestroy((hipStream_t)d.stream);
         if (d.copy_stream) (void)hipStreamDestroy((hipStream_t)d.copy_stream);
@@ -713,35 +721,55 @@ int render_device_impl(rt_scene *s, int w, int h, int depth, int spp, uint64_t s
     int rc;
     if ((rc = check_render_args(s, w, h, depth, spp, row0, nrows))) return rc;
     if ((rc = enter())) return rc;
-    // A band of RT_SPLIT_PIXELS or more is rendered as two halves on the two lanes, forked from and joined to the caller's
-    // stream: the kernels of the halves run beside each other and fill each other's tails (tools/lane_split_timing.py:
-    // a 16384 x 2048 band 4.44 -> 4.12 ms, the 8K frame 4.80 -> 4.48; the 4K frame gains 0.03 ms from the overlap and
-    // loses 0.05 to the fork and joins, so it stays whole).  Not for a caller who drives the lanes (RT_OPT_LANE 0 or 1, RT_OPT_CONTINUE), nor for fnorm
-    // callbacks (a band with callbacks waits for the host in the middle: nothing would overlap).
+    // A big band is rendered as pieces that alternate between the two lanes, forked from and joined to the caller's
+    // stream: the kernels of the pieces run beside each other and fill each other's tails (tools/lane_split_timing.py).
+    //   * the plain pipeline (no bounce levels): two halves from RT_SPLIT_PIXELS on — a 16384 x 2048 band 4.44 -> 4.12 ms,
+    //     the 8K frame 4.80 -> 4.48; the 4K frame gains 0.03 ms from the overlap and loses 0.05 to the fork and joins, so
+    //     it stays whole;
+    //   * with bounce levels (reflective scene, trace depth > 1): RT_SPLIT_PIECES_LEVELS pieces from RT_SPLIT_PIXELS_LEVELS
+    //     on — the deeper levels are a string of short kernels over few rays (level 3 of the mirror workload: 3 % of the
+    //     rays, 10 % of the frame), which find the other lane's big kernels to run beside: the mirror workload at 4K 6.04 ->
+    //     5.17 ms with two halves (4 pieces 5.77, 8 pieces 7.23; 3 or 4 lanes 5.74 / 5.97), at 3200 x 1800 4.61 -> 3.98, at
+    //     2560 x 1440 3.16 -> 3.03; at 1920 x 1080 and below the frame is one chain of launch latencies (1.9 ms whatever
+    //     the size) and the halves only add to it (2.37 -> 2.47).
+    // Not for a caller who drives the lanes (RT_OPT_LANE 0 or 1, RT_OPT_CONTINUE), nor for fnorm callbacks (a band with
+    // callbacks waits for the host in the middle: nothing would overlap).
     const size_t npix = (size_t)w * (size_t)nrows;
-    if (s->opt_lane < 0 && !s->opt_continue && npix >= RT_SPLIT_PIXELS && nrows >= 4 * RT_TILE_H && s->normal_fn.empty()) {
+    const bool bounces = render_levels(s, depth) > 1;
+    int pieces = 1;
+    if (s->opt_lane < 0 && !s->opt_continue && s->normal_fn.empty()) {
+        if (bounces && npix >= RT_SPLIT_PIXELS_LEVELS) pieces = RT_SPLIT_PIECES_LEVELS;
+        else if (!bounces && npix >= RT_SPLIT_PIXELS) pieces = 2;
+        while (pieces > 1 && nrows < pieces * 2 * RT_TILE_H) pieces /= 2;
+    }
+    if (pieces > 1) {
         DeviceScene &D = s->dev[t_device];
         if ((rc = device_prepare(*s, D, t_device, w, h))) return rc;
-        // Both halves run on the LANES' OWN streams; the caller's stream carries only the fork and the joins.  (Streams share
+        // The pieces run on the LANES' OWN streams; the caller's stream carries only the fork and the joins.  (Streams share
         // few hardware queues, 4 by default: kernels of a caller's stream that happens to sit on lane 1's queue would
         // run behind lane 1's, not beside them — measured 1.65 ms instead of 1.32 for the 4K frame.)
-        hipStream_t cs = (hipStream_t)stream, st0 = (hipStream_t)D.stream, st1 = nullptr;
-        if (!cs) cs = st0;
-        if ((rc = lane_stream(D, 1, st1))) return rc;
-        for (void **e : {&D.fork_ev, &D.join_ev, &D.join0_ev})
-            if (!*e) { hipEvent_t ev; HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); *e = ev; }
-        const int top = (nrows / 2 + RT_TILE_H - 1) / RT_TILE_H * RT_TILE_H;
-        const size_t off = (size_t)top * (size_t)w;
+        hipStream_t cs = (hipStream_t)stream, lst[RT_LANES];
+        for (int l = 0; l < RT_LANES; ++l) if ((rc = lane_stream(D, l, lst[l]))) return rc;
+        if (!cs) cs = lst[0];
+        if (!D.fork_ev) { hipEvent_t ev; HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); D.fork_ev = ev; }
+        for (void *&e : D.join_evs) if (!e) { hipEvent_t ev; HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); e = ev; }
         HIP_TRY(hipEventRecord((hipEvent_t)D.fork_ev, cs));
-        if (cs != st0) HIP_TRY(hipStreamWaitEvent(st0, (hipEvent_t)D.fork_ev, 0));
-        HIP_TRY(hipStreamWaitEvent(st1, (hipEvent_t)D.fork_ev, 0));
-        rc = render_band(s, t_device, w, h, depth, spp, seed, row0, top, d_rgba, d_hit_id, st0, false, nullptr, 0);
-        const int rc1 = rc ? rc : render_band(s, t_device, w, h, depth, spp, seed, row0 + top, nrows - top, d_rgba ? (uint8_t *)d_rgba + bpp(s) * off : nullptr,
-                                              d_hit_id ? (int32_t *)d_hit_id + off : nullptr, st1, true, nullptr, 1);
+        for (int l = 0; l < RT_LANES; ++l) if (lst[l] != cs) HIP_TRY(hipStreamWaitEvent(lst[l], (hipEvent_t)D.fork_ev, 0));
+        int prow = (nrows + pieces - 1) / pieces;
+        prow = (prow + RT_TILE_H - 1) / RT_TILE_H * RT_TILE_H;
+        int k = 0;
+        for (int r = 0; r < nrows && rc == RT_OK; r += prow, ++k) {
+            const int rows = nrows - r < prow ? nrows - r : prow;
+            const size_t off = (size_t)r * (size_t)w;
+            rc = render_band(s, t_device, w, h, depth, spp, seed, row0 + r, rows, d_rgba ? (uint8_t *)d_rgba + bpp(s) * off : nullptr,
+                             d_hit_id ? (int32_t *)d_hit_id + off : nullptr, lst[k % RT_LANES], k > 0, nullptr, k % RT_LANES);
+        }
         // always join: whatever the lanes were given is ordered before what the caller enqueues next
-        bool ok = hip_ok(hipEventRecord((hipEvent_t)D.join_ev, st1), "hipEventRecord") && hip_ok(hipStreamWaitEvent(cs, (hipEvent_t)D.join_ev, 0), "hipStreamWaitEvent");
-        if (cs != st0) ok = hip_ok(hipEventRecord((hipEvent_t)D.join0_ev, st0), "hipEventRecord") && hip_ok(hipStreamWaitEvent(cs, (hipEvent_t)D.join0_ev, 0), "hipStreamWaitEvent") && ok;
-        return rc1 ? rc1 : (ok ? (int)RT_OK : (int)RT_ERR_HIP);
+        bool ok = true;
+        for (int l = 0; l < RT_LANES; ++l)
+            if (lst[l] != cs)
+                ok = hip_ok(hipEventRecord((hipEvent_t)D.join_evs[l], lst[l]), "hipEventRecord") && hip_ok(hipStreamWaitEvent(cs, (hipEvent_t)D.join_evs[l], 0), "hipStreamWaitEvent") && ok;
+        return rc ? rc : (ok ? (int)RT_OK : (int)RT_ERR_HIP);
     }
     // RT_OPT_LANE picks the work buffers (and, for stream == NULL, the stream): lane 1 continues the frame lane 0 began, RT_OPT_CONTINUE makes lane 0 continue too
     return render_band(s, t_device, w, h, depth, spp, seed, row0, nrows, d_rgba, d_hit_id, (hipStream_t)stream, s->opt_lane > 0 || s->opt_continue,

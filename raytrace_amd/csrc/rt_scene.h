@@ -87,7 +87,7 @@ struct DeviceScene {          // the scene on ONE device (HBM), owned by the rt_
     DevBuf gen_tri_ssph, gen_rect_ssph;                            // super-blocks of 32 blocks: bounding sphere = the frame of their rows
     void *helper = nullptr;          // rt_kernels.hip: Helper — the thread that makes the streams beside the first host index build
     void *stream = nullptr;          // hipStream_t: renders of this scene on this device (when the caller passes none), lane 0
-    void *fork_ev = nullptr, *join_ev = nullptr, *join0_ev = nullptr;   // hipEvent_t: rt_render_device's own split of a big band over lanes 0 and 1
+    void *fork_ev = nullptr, *join_evs[RT_LANES] = {};   // hipEvent_t: rt_render_device's own split of a big band over lanes 0 and 1
     void *xstream[RT_LANES] = {};    // hipStream_t: the same for lanes 1.. (entry 0 stays empty: lane 0 runs on `stream`)
     void *copy_stream = nullptr;     // hipStream_t: rt_render's copies to host memory, band by band; rt_render_multi's peer copies
     void *copy_stream2 = nullptr;    // hipStream_t: rt_render_multi's copies from the home device to host memory

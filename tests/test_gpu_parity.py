@@ -604,24 +604,24 @@ def test_pieces_on_alternating_lanes(gpu_lib):
         sc.close()
     # left to itself (RT_OPT_LANE -1) rt_render_device splits a band of 12 Mi pixels or more over the two lanes: same bytes
     # and the same counts as the unsplit call, on the library's stream and on a stream of the caller's, full frame and band
-    world, lights = scenes.synthetic(ntri=600, ncuboid=60)
-    sc = api.Scene(world, lights)
-    w, h = 4096, 3200
-    rgba, hit = DeviceBuffer((h, w, 4), np.uint8, fill=0x5a), DeviceBuffer((h, w), np.int32, fill=0x5a)
-    sc.set_option(_lib.RT_OPT_LANE, 0)
-    sc.render_device(w, h, rgba.ptr, hit.ptr)
-    one = sc.stats()
-    ref_rgba, ref_hit = rgba.numpy(), hit.numpy()
-    sc.set_option(_lib.RT_OPT_LANE, -1)
-    for row0, nrows in ((0, h), (24, 3171)):
-        rgba2, hit2 = DeviceBuffer((nrows, w, 4), np.uint8, fill=0x5a), DeviceBuffer((nrows, w), np.int32, fill=0x5a)
-        sc.render_device(w, h, rgba2.ptr, hit2.ptr, row0=row0, nrows=nrows)
-        st = sc.stats()
-        assert (rgba2.numpy() == ref_rgba[row0:row0 + nrows]).all() and (hit2.numpy() == ref_hit[row0:row0 + nrows]).all()
-        assert st["primary_rays"] == w * nrows and (nrows < h or st["shadow_rays"] == one["shadow_rays"])
-        sc.render_device(w, h, None, hit2.ptr, row0=row0, nrows=nrows)                 # hit IDs only, split too
-        assert (hit2.numpy() == ref_hit[row0:row0 + nrows]).all()
-    sc.close()
+    # (12 Mi pixels for the plain pipeline, 3 Mi with bounce levels: the room of mirrors at 2048 x 1600)
+    for (world, lights), (w, h), band in ((scenes.synthetic(ntri=600, ncuboid=60), (4096, 3200), (24, 3171)), (scenes.mirror_room(), (2048, 1600), (8, 1579))):
+        sc = api.Scene(world, lights)
+        rgba, hit = DeviceBuffer((h, w, 4), np.uint8, fill=0x5a), DeviceBuffer((h, w), np.int32, fill=0x5a)
+        sc.set_option(_lib.RT_OPT_LANE, 0)
+        sc.render_device(w, h, rgba.ptr, hit.ptr)
+        one = sc.stats()
+        ref_rgba, ref_hit = rgba.numpy(), hit.numpy()
+        sc.set_option(_lib.RT_OPT_LANE, -1)
+        for row0, nrows in ((0, h), band):
+            rgba2, hit2 = DeviceBuffer((nrows, w, 4), np.uint8, fill=0x5a), DeviceBuffer((nrows, w), np.int32, fill=0x5a)
+            sc.render_device(w, h, rgba2.ptr, hit2.ptr, row0=row0, nrows=nrows)
+            st = sc.stats()
+            assert (rgba2.numpy() == ref_rgba[row0:row0 + nrows]).all() and (hit2.numpy() == ref_hit[row0:row0 + nrows]).all()
+            assert st["primary_rays"] == w * nrows and (nrows < h or (st["shadow_rays"] == one["shadow_rays"] and st["bounce_rays"] == one["bounce_rays"]))
+            sc.render_device(w, h, None, hit2.ptr, row0=row0, nrows=nrows)                 # hit IDs only, split too
+            assert (hit2.numpy() == ref_hit[row0:row0 + nrows]).all()
+        sc.close()
 
 
 def test_lights_with_worlds_of_their_own(gpu_lib):
