@@ -751,6 +751,37 @@ static void spatial_order(const rt_scene &s, const std::vector<int32_t> &gids, c
             if (!(nv[k] > 0 && rad[k] > big) && keyed[k].first != 0xffffffffu) keyed[k].first |= 0x40000000u;   // (Morton keys use 30 bits)
     }
     std::stable_sort(keyed.begin(), keyed.end(), [](const std::pair<uint32_t, int32_t> &a, const std::pair<uint32_t, int32_t> &b) { return a.first < b.first; });
+#ifndef RT_GEN_ORDER_MORTON
+    // The ordinary leaves (after the big ones, before the degenerate ones) are then re-cut top down: a range is split at
+    // the block boundary nearest its middle, along the longest axis of its centroids' box, until it is one block.  A
+    // block of 32 consecutive Morton keys straddles cell boundaries of every level; the cuts follow the leaves instead,
+    // and the blocks' spheres come out a third smaller in cross-section (what a run's line of sight meets is pi r^2).
+    {
+        size_t nb0 = 0, ne0 = n;
+        while (nb0 < n && keyed[nb0].first < 0x40000000u) ++nb0;
+        while (ne0 > nb0 && keyed[ne0 - 1].first == 0xffffffffu) --ne0;
+        std::vector<std::pair<size_t, size_t>> todo(1, {nb0, ne0});
+        while (!todo.empty()) {
+            const size_t b0 = todo.back().first, e0 = todo.back().second;
+            todo.pop_back();
+            const size_t first = (b0 / 32 + 1) * 32;                 // block boundaries strictly inside (b0, e0)
+            if (first >= e0) continue;
+            const size_t inside = (e0 - 1 - first) / 32 + 1;
+            const size_t mid = first + ((inside - 1) / 2) * 32;
+            double blo[3] = {1e300, 1e300, 1e300}, bhi[3] = {-1e300, -1e300, -1e300};
+            for (size_t k = b0; k < e0; ++k)
+                for (int i = 0; i < 3; ++i) { const double v = cen[(size_t)keyed[k].second * 3 + i]; blo[i] = std::fmin(blo[i], v); bhi[i] = std::fmax(bhi[i], v); }
+            int ax = 0;
+            for (int i = 1; i < 3; ++i) if (bhi[i] - blo[i] > bhi[ax] - blo[ax]) ax = i;
+            std::nth_element(keyed.begin() + (std::ptrdiff_t)b0, keyed.begin() + (std::ptrdiff_t)mid, keyed.begin() + (std::ptrdiff_t)e0,
+                             [&](const std::pair<uint32_t, int32_t> &a, const std::pair<uint32_t, int32_t> &b) {
+                                 const double va = cen[(size_t)a.second * 3 + ax], vb = cen[(size_t)b.second * 3 + ax];
+                                 return va < vb || (va == vb && a.second < b.second);
+                             });
+            todo.push_back({b0, mid}); todo.push_back({mid, e0});
+        }
+    }
+#endif
     order.resize(n);
     const size_t nblk = (n + 31) / 32;
     spheres.assign((nblk + 1) * 4, 0.f);
@@ -768,14 +799,34 @@ static void spatial_order(const rt_scene &s, const std::vector<int32_t> &gids, c
         if (always || cnt == 0) { S[3] = INFINITY; continue; }
         for (int i = 0; i < 3; ++i) c[i] /= (double)cnt;
         double r2 = 0;
-        for (size_t k = b * 32; k < std::min(n, b * 32 + 32); ++k) {
-            const size_t src = (size_t)keyed[k].second;
-            for (int j = 0; j < nv[src]; ++j) {
-                double d2 = 0;
-                for (int i = 0; i < 3; ++i) { const double d = verts[src * 12 + j * 3 + i] - c[i]; d2 += d * d; }
-                r2 = std::fmax(r2, d2);
+        auto farthest = [&](const double *from, double *far) {
+            double best = -1;
+            for (size_t k = b * 32; k < std::min(n, b * 32 + 32); ++k) {
+                const size_t src = (size_t)keyed[k].second;
+                for (int j = 0; j < nv[src]; ++j) {
+                    double d2 = 0;
+                    for (int i = 0; i < 3; ++i) { const double d = verts[src * 12 + j * 3 + i] - from[i]; d2 += d * d; }
+                    if (d2 > best) { best = d2; if (far) for (int i = 0; i < 3; ++i) far[i] = verts[src * 12 + j * 3 + i]; }
+                }
             }
+            return best;
+        };
+#ifndef RT_GEN_ORDER_MORTON
+        // the centre walks towards the farthest vertex in ever smaller steps (Badoiu & Clarkson): close to the smallest
+        // enclosing sphere; the radius below is measured from wherever it ends up, so the bound holds whatever it found
+        {
+            double best_c[3] = {c[0], c[1], c[2]}, best_r2 = farthest(c, nullptr);
+            for (int it = 1; it <= 96; ++it) {
+                double far[3];
+                const double d2 = farthest(c, far);
+                if (d2 < best_r2) { best_r2 = d2; for (int i = 0; i < 3; ++i) best_c[i] = c[i]; }
+                for (int i = 0; i < 3; ++i) c[i] += (far[i] - c[i]) / (double)(it + 1);
+            }
+            if (farthest(c, nullptr) > best_r2) for (int i = 0; i < 3; ++i) c[i] = best_c[i];
+            if (!(std::isfinite(c[0]) && std::isfinite(c[1]) && std::isfinite(c[2]))) for (int i = 0; i < 3; ++i) c[i] = best_c[i];
         }
+#endif
+        r2 = farthest(c, nullptr);
         // (a convex polygon lies inside any sphere that holds its vertices)  centre rounded to float: the radius pays for it
         const double r = std::sqrt(r2) * (1.0 + 1e-6) + 1e-6 * (std::fabs(c[0]) + std::fabs(c[1]) + std::fabs(c[2]) + 1.0);
         S[0] = (float)c[0]; S[1] = (float)c[1]; S[2] = (float)c[2];
