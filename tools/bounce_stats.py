@@ -16,10 +16,17 @@ hit = torch.empty((h, w), dtype=torch.int32, device="cuda")
 prev = None
 first = None
 for depth in (1, 2, 3, 4):
+    # per-kernel times: the frame as ONE chain of launches (lane 0); the library's own schedule (reflective frames of
+    # 3 Mi pixels or more: two halves on two lanes, whose kernels overlap) gives the frame time printed beside it
+    sc.set_option(_lib.RT_OPT_LANE, -1)
+    for _ in range(2):
+        sc.render_device(w, h, rgba.data_ptr(), hit.data_ptr(), depth=depth)
+        auto = sc.stats()
+    sc.set_option(_lib.RT_OPT_LANE, 0)
     for _ in range(2):
         sc.render_device(w, h, rgba.data_ptr(), hit.data_ptr(), depth=depth)
         st = sc.stats()
-    line = f"depth {depth}: nearest-hit kernels {st['ms_primary']:.3f} ms, setup {st['ms_setup']:.3f}, shadow {st['ms_shadow']:.3f}, final {st['ms_final']:.3f}, total {st['ms_total']:.3f}; bounce rays {st['bounce_rays']}, bounce blocks {st['bounce_blocks']}, exact {st['exact_evals']}, records {st['record_tests']}"
+    line = f"depth {depth}: nearest-hit kernels {st['ms_primary']:.3f} ms, setup {st['ms_setup']:.3f}, shadow {st['ms_shadow']:.3f}, final {st['ms_final']:.3f}, total {st['ms_total']:.3f} (frame as the library schedules it: {auto['ms_total']:.3f}); bounce rays {st['bounce_rays']}, bounce blocks {st['bounce_blocks']}, exact {st['exact_evals']}, records {st['record_tests']}"
     if prev is not None and st["bounce_rays"] > prev["bounce_rays"]:
         dr = st["bounce_rays"] - prev["bounce_rays"]
         dms = st["ms_primary"] - prev["ms_primary"]
