@@ -374,6 +374,20 @@ __device__ __forceinline__ double pow_spec(double x, double sp) {
 // What a point light adds to a pixel it reaches: pointLight (Main.hs:476-487) or Talk.hs's pointLight (Talk.hs:244-248).
 // k_final adds it for the lights that reach the pixel; k_setup evaluates the same function first and casts no shadow
 // ray where it is (0, 0, 0) — a black material, a grazing light: the shadow test could not change the pixel.
+// Hit records live as two arrays: points and normals (k_shadow_mfma gathers the points of 5.6 M shadow rays per frame, and a
+// gather moves whole lines: the normals came along for nothing)
+__device__ __forceinline__ HitRec load_hit_point(const RenderParams &P, size_t pix) {
+    const HitVec p = P.hitpos[pix];
+    return HitRec{p.x, p.y, p.z, 0, 0, 0};
+}
+__device__ __forceinline__ HitRec load_hit(const RenderParams &P, size_t pix) {
+    const HitVec p = P.hitpos[pix], n = P.hitnrm[pix];
+    return HitRec{p.x, p.y, p.z, n.x, n.y, n.z};
+}
+__device__ __forceinline__ void store_hit(const RenderParams &P, size_t pix, const HitRec &H) {
+    P.hitpos[pix] = HitVec{H.px, H.py, H.pz};
+    P.hitnrm[pix] = HitVec{H.nx, H.ny, H.nz};
+}
 __device__ __forceinline__ void light_terms(const RenderParams &P, const LightD &Lt, const MaterialD &M, const HitRec &H,
                                             const RayD &ray, int &r, int &g, int &b) {
     double tx, ty, tz;
@@ -412,7 +426,7 @@ __device__ __forceinline__ void shadow_sphere_loop(const RenderParams &P, CRecPt
                 if ((z[r] >= cur.c[9]) & need[r]) {
                     uint32_t pr = pix[r];
                     asm volatile("" : "+v"(pr));
-                    const HitRec H = P.hitrec[pr];
+                    const HitRec H = load_hit_point(P, pr);
                     double tx, ty, tz;
                     to_light(false, Lt, H.px, H.py, H.pz, tx, ty, tz);
                     const RayD ray = mkray(H.px + 0.00001 * tx, H.py + 0.00001 * ty, H.pz + 0.00001 * tz, tx, ty, tz, P.eps);

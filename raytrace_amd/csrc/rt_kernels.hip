@@ -134,7 +134,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(RT_WAVES_EU_SETUP, 8))) __lau
             nx = sg * ux; ny = sg * uy; nz = sg * uz;
         }
         H.px = ix; H.py = iy; H.pz = iz; H.nx = nx; H.ny = ny; H.nz = nz;
-        P.hitrec[pix] = H;
+        store_hit(P, (size_t)pix, H);
     }
     if (act) P.lit_w[pix] = 0u;
     const int lane = (int)(threadIdx.x & 63), wv = (int)(threadIdx.x >> 6);
@@ -729,7 +729,7 @@ __global__ void RT_HOT(RT_WAVES_EU_MF_SHADOW) k_shadow_mfma(const RenderParams P
         uint32_t pix = 0u;
         if (ok) {
             pix = q[j];
-            const HitRec H = P.hitrec[pix];
+            const HitRec H = load_hit_point(P, pix);
             double tx, ty, tz;
             to_light(RT_TALK(P), Lt, H.px, H.py, H.pz, tx, ty, tz);
             const double o[3] = {H.px + 0.00001 * tx, H.py + 0.00001 * ty, H.pz + 0.00001 * tz};
@@ -863,7 +863,7 @@ __global__ void RT_HOT(RT_WAVES_EU_MF_SHADOW) k_shadow_mfma(const RenderParams P
 #endif
             const int kind = (int)((entry >> 8) & 1u), gid = (int)(entry >> 9);
             const LeafD &L = P.leaves[gid];
-            const HitRec H = P.hitrec[s_pix[wv][e]];
+            const HitRec H = load_hit_point(P, s_pix[wv][e]);
             double tx, ty, tz;
             to_light(RT_TALK(P), Lt, H.px, H.py, H.pz, tx, ty, tz);
             const RayD ray = mkray(H.px + 0.00001 * tx, H.py + 0.00001 * ty, H.pz + 0.00001 * tz, tx, ty, tz, P.eps);   // Main.hs:472
@@ -1123,7 +1123,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(RT_WAVES_EU_FINAL, 8))) __lau
     RayRec child = {0, 0, 0, 0, 0, 0, 0, 0u, 0u};
     if (id >= 0) {
         const MaterialD M = P.mats[P.leaves[id].mat];
-        const HitRec H = P.hitrec[pix];
+        const HitRec H = load_hit(P, (size_t)pix);
         uint32_t lit = 0u;
         const RayD ray = slot_ray(P, pix);
         int pl = 0;

@@ -262,7 +262,7 @@ __device__ __forceinline__ void shadow_loop(const RenderParams &P, CRecPtr recs,
                     if (cand[r] & (own[r] != gid)) {
                         uint32_t pr = pix[r];
                         asm volatile("" : "+v"(pr));   // keep the exact-path ray set-up inside this rare branch
-                        const HitRec H = P.hitrec[pr];
+                        const HitRec H = load_hit_point(P, pr);
                         double tx, ty, tz;
                         to_light(false, Lt, H.px, H.py, H.pz, tx, ty, tz);
                         const RayD ray = mkray(H.px + 0.00001 * tx, H.py + 0.00001 * ty, H.pz + 0.00001 * tz,
@@ -315,7 +315,7 @@ __global__ void RT_HOT(RT_WAVES_EU_SHADOW) k_shadow(const RenderParams P) {
         own[r] = need[r] ? P.hit_id[P.out_off + pix[r]] : -1;
         ddx[r] = ddy[r] = ddz[r] = 0.f;
         if (need[r]) {
-            const HitRec H = P.hitrec[pix[r]];
+            const HitRec H = load_hit_point(P, pix[r]);
             double tx, ty, tz;
             to_light(false, Lt, H.px, H.py, H.pz, tx, ty, tz);
             ddx[r] = (float)((H.px + 0.00001 * tx) - Lt.px);

@@ -25,6 +25,7 @@
 namespace rt {
 
 struct HitRec;
+struct HitVec;
 struct RenderParams {
     const LeafD *leaves;
     const AuxD *aux;
@@ -46,7 +47,7 @@ struct RenderParams {
     int32_t *hit_id;                // band-local output, indexed out_off + pix
     uint8_t *rgba;                  // band-local output (spp == 1) or nullptr
     uint32_t *accum;                // band-local 3 x u32 sums (spp > 1) or nullptr
-    HitRec *hitrec;                 // per chunk pixel: exact hit point and shading normal
+    HitVec *hitpos, *hitnrm;        // per chunk pixel: exact hit point; shading normal (two arrays: the shadow kernels gather points only)
     uint32_t *queue;                // npoint blocks of qcap shadow jobs (chunk pixel indices)
     unsigned *qcount;               // shadow jobs per point light
     uint32_t *qsparse;              // k_setup's output: per light, RT_SETUP_THREADS slots per block, the block's jobs first
@@ -113,7 +114,8 @@ struct RenderParams {
     int rgb_packed;                 // bpp == 3 and w % 4 == 0: four pixels are stored as three whole dwords (store_rgb24)
 };
 
-struct HitRec { double px, py, pz, nx, ny, nz; };
+struct HitRec { double px, py, pz, nx, ny, nz; };     // in registers; in memory: hitpos[pix], hitnrm[pix]
+struct HitVec { double x, y, z; };
 
 // Statistics counters: RT_STAT_SLOTS copies of the 8 counters, one 128-byte line each, picked by wave number.  Every
 // wave adds to them once, and atomics on ONE address are serialised by the L2 (12 ns each: 0.4 ms for the 32 400 waves

@@ -339,7 +339,7 @@ size_t ws_carve(unsigned char *base, size_t cap, const WsNeeds &n, Workspace &W)
     if (fits && base) W.qcount = reinterpret_cast<unsigned *>(reinterpret_cast<unsigned char *>(W.counters) + RT_COUNTER_BYTES);
     if (n.hit_id) take(W.hit_id, n.hit_id);
     if (n.accum) take(W.accum, n.accum);
-    if (n.hitrec) take(W.hitrec, n.hitrec);
+    if (n.hitrec) { take(W.hitrec, n.hitrec); W.hit_slots = n.hitrec / sizeof(HitRec); }
     if (n.lit) take(W.lit, n.lit);
     if (n.queue) take(W.queue, n.queue);
     if (n.qsparse) take(W.qsparse, n.qsparse);
@@ -458,7 +458,7 @@ int render_rows(rt_scene *s, DeviceScene &D, Lane &LN, const Workspace &W, size_
     P.tri_rec = (const FilterRec *)D.tri_rec.p; P.rect_rec = (const FilterRec *)D.rect_rec.p;
     P.tri_gid = (const int32_t *)D.tri_gid.p; P.rect_gid = (const int32_t *)D.rect_gid.p;
     P.counters = W.counters;
-    P.hitrec = reinterpret_cast<HitRec *>(W.hitrec); P.queue = W.queue; P.qcount = W.qcount; P.lit = W.lit;
+    P.hitpos = reinterpret_cast<HitVec *>(W.hitrec); P.hitnrm = P.hitpos ? P.hitpos + W.hit_slots : nullptr; P.queue = W.queue; P.qcount = W.qcount; P.lit = W.lit;
     P.qsparse = W.qsparse; P.tcount = W.tcount;
     P.cb_slot = W.cb_slot; P.cb_xy = W.cb_xy; P.cb_group = W.cb_group; P.cb_normal = W.cb_normal; P.cb_count = W.qcount + RT_QCOUNT_CB;
     P.gen_tri = (const GenRec *)D.gen_tri.p; P.gen_rect = (const GenRec *)D.gen_rect.p;

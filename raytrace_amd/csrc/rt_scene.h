@@ -30,7 +30,8 @@ struct Workspace {
     unsigned *qcount = nullptr;              // shadow jobs per point light [0..31]; rays per bounce level [32..96]; callback count; lights' cost history
     int32_t *hit_id = nullptr;               // per band pixel (only when the caller gives no buffer, or spp > 1)
     uint32_t *accum = nullptr;               // spp > 1: 3 x u32 per band pixel
-    char *hitrec = nullptr;                  // per chunk pixel: 48-byte HitRec
+    char *hitrec = nullptr;                  // per chunk pixel: 24-byte hit points, then (hit_slots on) 24-byte normals
+    size_t hit_slots = 0;
     uint32_t *queue = nullptr;               // shadow-job queues, npoint x chunk pixels
     uint32_t *qsparse = nullptr;             // k_setup's per-block runs of shadow jobs, before compaction
     unsigned *tcount = nullptr;              // shadow jobs per (light, k_setup block) -> offsets
