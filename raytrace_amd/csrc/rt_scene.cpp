@@ -652,8 +652,8 @@ static GenRec make_gen_rec(const LeafD &L, const double omax[3]) {
     return r;
 }
 
-// Reflected rays have no common apex, so their leaf records are ordered in space instead: along a Morton curve through
-// the leaves' centroids, cut into blocks of 32 with a bounding sphere each (k_general skips the blocks no ray of a
+// Reflected rays have no common apex, so their leaf records are ordered in space instead: the leaves' centroids are cut
+// top down at medians (after a first pass along a Morton curve) into blocks of 32 with a bounding sphere each (k_general skips the blocks no ray of a
 // 64-ray run can reach).  Any order gives the same image: the nearest hit is the minimum over (t, leaf index).
 //
 // Stage 0 of the bounce levels, on the matrix cores (k_general): the line of a ray (o, unit d) meets the bounding sphere
