@@ -380,13 +380,18 @@ __device__ __forceinline__ HitRec load_hit_point(const RenderParams &P, size_t p
     const HitVec p = P.hitpos[pix];
     return HitRec{p.x, p.y, p.z, 0, 0, 0};
 }
-__device__ __forceinline__ HitRec load_hit(const RenderParams &P, size_t pix) {
-    const HitVec p = P.hitpos[pix], n = P.hitnrm[pix];
+// The normal of a planar leaf with the geometric normal is the leaf's own (the same doubles): it is not stored per pixel
+// (24 of 48 bytes per pixel that k_setup would write and k_final read back; the leaves stay in the L2).
+__device__ __forceinline__ bool normal_is_the_leafs(const LeafD &L) { return L.kind != LEAF_SPHERE && L.nmode == RT_NORMAL_GEOMETRIC; }
+__device__ __forceinline__ HitRec load_hit(const RenderParams &P, size_t pix, const LeafD &L) {
+    const HitVec p = P.hitpos[pix];
+    if (normal_is_the_leafs(L)) return HitRec{p.x, p.y, p.z, L.nx, L.ny, L.nz};
+    const HitVec n = P.hitnrm[pix];
     return HitRec{p.x, p.y, p.z, n.x, n.y, n.z};
 }
-__device__ __forceinline__ void store_hit(const RenderParams &P, size_t pix, const HitRec &H) {
+__device__ __forceinline__ void store_hit(const RenderParams &P, size_t pix, const HitRec &H, bool leafs_normal) {
     P.hitpos[pix] = HitVec{H.px, H.py, H.pz};
-    P.hitnrm[pix] = HitVec{H.nx, H.ny, H.nz};
+    if (!leafs_normal) P.hitnrm[pix] = HitVec{H.nx, H.ny, H.nz};
 }
 __device__ __forceinline__ void light_terms(const RenderParams &P, const LightD &Lt, const MaterialD &M, const HitRec &H,
                                             const RayD &ray, int &r, int &g, int &b) {

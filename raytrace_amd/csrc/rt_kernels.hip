@@ -134,7 +134,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(RT_WAVES_EU_SETUP, 8))) __lau
             nx = sg * ux; ny = sg * uy; nz = sg * uz;
         }
         H.px = ix; H.py = iy; H.pz = iz; H.nx = nx; H.ny = ny; H.nz = nz;
-        store_hit(P, (size_t)pix, H);
+        store_hit(P, (size_t)pix, H, normal_is_the_leafs(L));
     }
     if (act) P.lit_w[pix] = 0u;
     const int lane = (int)(threadIdx.x & 63), wv = (int)(threadIdx.x >> 6);
@@ -1122,8 +1122,9 @@ __global__ void __attribute__((amdgpu_waves_per_eu(RT_WAVES_EU_FINAL, 8))) __lau
     bool spawn = false;
     RayRec child = {0, 0, 0, 0, 0, 0, 0, 0u, 0u};
     if (id >= 0) {
-        const MaterialD M = P.mats[P.leaves[id].mat];
-        const HitRec H = load_hit(P, (size_t)pix);
+        const LeafD &Lf = P.leaves[id];
+        const MaterialD M = P.mats[Lf.mat];
+        const HitRec H = load_hit(P, (size_t)pix, Lf);
         uint32_t lit = 0u;
         const RayD ray = slot_ray(P, pix);
         int pl = 0;
