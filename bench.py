@@ -26,6 +26,8 @@ Also on the JSON line:
                   SURVEY.md §8 d) is reported beside it as `algorithmic_tflops` / `speedup_vs_all_pairs`.
   rt_render     — the same frame through rt_render (host buffers, the call a Haskell caller makes, SURVEY.md §8 d):
                   into page-locked and into pageable memory, PCIe included.  Never `value`.
+  two_frames_in_flight — the same frames with consecutive ones on alternating lanes of the scene (two frame buffers): what a
+                  caller who renders a sequence gets per frame.  Throughput, not the time of a frame: never `value`.
   cpu_baseline  — the CPU oracle (a C restatement of the reference, NOT the Haskell program) on the
                   host cores, on a bounded band of the same frame (rank 0, N = 1 only).
 """
@@ -600,6 +602,28 @@ def main():
                                            "mfma_tflops": float(bst["mfma_blocks_primary"]) * 8 * MFMA_FLOPS / (bst["ms_primary"] * 1e-3) / 1e12,
                                            "mfma_frac": float(bst["mfma_blocks_primary"]) * 8 * MFMA_FLOPS / (bst["ms_primary"] * 1e-3) / 1e12 / PEAK_MFMA_F16_TFLOPS}
                 scene.set_option(_lib.RT_OPT_CULL, 1)
+            # a SEQUENCE of independent frames with two in flight: consecutive frames alternate between the scene's two lanes
+            # (RT_OPT_LANE: own work buffers, wave history and stream each; two frame buffers), so the kernels of frame k + 1
+            # fill the tails of frame k's.  Not `value`: a step there is a whole frame that has ended before the next begins.
+            if args.spp == 1:
+                frame_b, hit_b = torch.empty_like(frame), torch.empty_like(hit)
+                fl_streams = [rs, torch.cuda.Stream(dev)]
+                fl_out = [(frame_ptr, hit_ptr), (frame_b.data_ptr(), hit_b.data_ptr())]
+                nfl = max(20, args.steps)
+                for timed_pass in (False, True):
+                    sync()
+                    t0 = time.perf_counter()
+                    for k in range(nfl):
+                        scene.render_device(w, h, fl_out[k & 1][0], fl_out[k & 1][1], depth=args.depth, spp=1, seed=20260355,
+                                            stream=fl_streams[k & 1].cuda_stream, lane=k & 1, cont=False)
+                    sync()
+                    fl_ms = (time.perf_counter() - t0) / nfl * 1e3
+                out["two_frames_in_flight"] = {"ms_per_frame": fl_ms, "mrays": primary / fl_ms / 1e3, "frames": nfl,
+                                               "frames_equal": bool(torch.equal(frame_b, frame) and torch.equal(hit_b, hit)),
+                                               "note": "the same frames, consecutive ones alternating between the scene's two lanes (two frame buffers): "
+                                                       "throughput of a frame sequence, not the time of a frame; never `value`"}
+                scene.set_option(_lib.RT_OPT_LANE, -1).set_option(_lib.RT_OPT_CONTINUE, 0)
+                del frame_b, hit_b
             # the call SURVEY.md 8(d) defines the metric on: rt_render into HOST buffers (PCIe included)
             legs = {}
             dests = {"page_locked": (api.host_buffer((h, w, 4), np.uint8), api.host_buffer((h, w), np.int32)),
