@@ -55,6 +55,10 @@ class DeviceBuffer:
         if hip().hipDeviceSynchronize() != 0:
             raise RuntimeError("hipDeviceSynchronize failed")
 
+    def fill(self, value):
+        if hip().hipMemset(self.ptr, value, max(self.nbytes, 1)) != 0 or hip().hipDeviceSynchronize() != 0:
+            raise RuntimeError("hipMemset failed")
+
     def numpy(self):
         if hip().hipDeviceSynchronize() != 0:
             raise RuntimeError("hipDeviceSynchronize failed")

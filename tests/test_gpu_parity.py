@@ -624,6 +624,41 @@ def test_pieces_on_alternating_lanes(gpu_lib):
         sc.close()
 
 
+def test_consecutive_frames_on_alternating_lanes(gpu_lib):
+    """A sequence of frames with two in flight: consecutive frames go to alternating lanes of the scene, each lane on a
+    stream of its own and into a frame buffer of its own, nothing waits in between (bench.py: two_frames_in_flight).  Every
+    frame has the bytes of the frame rendered alone — also while the other lane renders another size or trace depth, and
+    from the second frame of a lane on, when its waves are dispatched by that lane's own history."""
+    import ctypes as C
+    from raytrace_amd import _lib
+    from hip_buffers import DeviceBuffer, hip
+    H = hip()
+    streams = [C.c_void_p(), C.c_void_p()]
+    for st in streams:
+        assert H.hipStreamCreateWithFlags(C.byref(st), 1) == 0                      # hipStreamNonBlocking
+    for (world, lights), sizes in ((scenes.synthetic(ntri=600, ncuboid=60), ((1000, 531, 4), (640, 400, 4))),
+                                   (scenes.mirror_room(), ((300, 200, 4), (300, 200, 2)))):
+        sc = api.Scene(world, lights)
+        refs = [sc.render(w, h, depth=d) for w, h, d in sizes]
+        bufs = [(DeviceBuffer((h, w, 4), np.uint8, fill=0x5a), DeviceBuffer((h, w), np.int32, fill=0x5a)) for w, h, _ in sizes]
+        assert H.hipDeviceSynchronize() == 0                                       # (the fills ran on the null stream)
+        for frame in range(8):                                                     # lane 0 renders sizes[0], lane 1 sizes[1]
+            ln = frame & 1
+            w, h, d = sizes[ln]
+            sc.render_device(w, h, bufs[ln][0].ptr, bufs[ln][1].ptr, depth=d, stream=streams[ln].value, lane=ln, cont=False)
+            if frame in (1, 5, 7):                                                 # after two, six and eight frames: both lanes' last frames
+                for st in streams:
+                    assert H.hipStreamSynchronize(st) == 0
+                for k in range(2):
+                    assert (bufs[k][0].numpy() == refs[k][0]).all() and (bufs[k][1].numpy() == refs[k][1]).all(), (frame, k)
+                    bufs[k][0].fill(0x5a); bufs[k][1].fill(0x5a)
+                assert H.hipDeviceSynchronize() == 0
+        sc.set_option(_lib.RT_OPT_LANE, -1).set_option(_lib.RT_OPT_CONTINUE, 0)
+        sc.close()
+    for st in streams:
+        assert H.hipStreamDestroy(st) == 0
+
+
 def test_lights_with_worlds_of_their_own(gpu_lib):
     """`pointLight world kd ks pos` (Main.hs:467-474): a light tests its shadow rays against the Shape it closed over.  Three
     lights — one over a world of big cuboids, spheres and cylinders that is never traced, one over the traced world,
